@@ -1,0 +1,83 @@
+"""Helpers shared by the oracle/golden tests and the GPU parity tests."""
+import os
+import numpy as np
+import torch
+
+import recipe
+from cases import make_cfg, sample_indices
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLD, name + ".npz")))
+
+
+def recipe_sd(shapes, salt, device="cpu", requires_grad=False):
+    sd = {}
+    for k, shp in shapes.items():
+        t = torch.from_numpy(recipe.weight_for(k, shp, salt)).to(device)
+        if requires_grad:
+            t.requires_grad_(True)
+        sd[k] = t
+    return sd
+
+
+def mfb_inputs(case, device="cpu"):
+    cfg = make_cfg(case)
+    N, T = case["N"], case["T"]
+    img = torch.from_numpy(recipe.img_features(N, cfg.img_feature_dim, cfg.img_feature_channel, case["salt"])).to(device)
+    q = torch.from_numpy(recipe.question_tokens(N, T, cfg.q_vocab_size, case["salt"])).to(device)
+    glove = None
+    if case["glove"]:
+        glove = torch.from_numpy(recipe.sym_tensor((N, T, cfg.emb_dim), 0.5, recipe.name_seed("glove", case["salt"]))).to(device)
+    hard = torch.from_numpy(recipe.hard_answers(N, cfg.a_vocab_size, case["salt"])).to(device)
+    soft = torch.from_numpy(recipe.soft_answers(N, cfg.a_vocab_size, case["salt"])).to(device)
+    return cfg, img, q, glove, hard, soft
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def check_tensor_digest(prefix, t, gold, tol):
+    a = t.detach().cpu().reshape(-1).double().numpy()
+    s, ab = float(gold[prefix + "/sum"]), float(gold[prefix + "/abs"])
+    assert abs(np.abs(a).sum() - ab) <= tol * max(ab, 1e-30) + 1e-12, (prefix, "abs", np.abs(a).sum(), ab)
+    assert abs(a.sum() - s) <= tol * max(ab, 1e-30) + 1e-12, (prefix, "sum", a.sum(), s)
+    if prefix + "/full" in gold:
+        assert rel_err(t.detach().cpu().numpy().reshape(-1), gold[prefix + "/full"].reshape(-1)) <= tol, prefix
+    else:
+        idx = sample_indices(prefix, a.size, 64)
+        assert rel_err(a[idx], gold[prefix + "/samp"]) <= tol, prefix
+
+
+def check_grads(named_grads, gold, tol, zero_ok_abs=1e-9):
+    """named_grads: {name: tensor or None}.  Compares norms + sampled entries.
+
+    Sampled entries are compared relative to the gradient's RMS magnitude
+    (norm / sqrt(numel)) so that near-zero samples do not dominate.
+    """
+    gmax = max([float(v) for kk, v in gold.items() if kk.startswith("gnorm/")] + [0.0])
+    zero_ok_abs = max(zero_ok_abs, 1e-6 * gmax)
+    for k, g in named_grads.items():
+        if ("gnone/" + k) in gold:
+            assert g is None or float(g.abs().max()) == 0.0, (k, "reference grad is None")
+            continue
+        assert g is not None, (k, "missing gradient")
+        a = g.detach().cpu().reshape(-1).double().numpy()
+        gn = float(gold["gnorm/" + k])
+        n = float(np.sqrt((a * a).sum()))
+        if gn <= zero_ok_abs:
+            # exactly-zero (dead) or pure rounding-noise gradients (e.g. the bias in
+            # front of a shift-invariant softmax): only require "still negligible"
+            assert n <= 10 * zero_ok_abs, (k, "reference gradient is (numerically) zero", n)
+            continue
+        assert abs(n - gn) <= tol * gn, (k, "norm", n, gn)
+        idx = sample_indices(k, a.size, 16)
+        rms = gn / np.sqrt(a.size)
+        d = np.abs(a[idx] - gold["gsamp/" + k].astype(np.float64)).max()
+        scale = max(np.abs(gold["gsamp/" + k]).max(), rms)
+        assert d <= tol * scale * 4, (k, "samples", d, scale)
