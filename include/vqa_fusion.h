@@ -1,0 +1,199 @@
+/*
+ * vqa_fusion.h -- C ABI of libvqa_fusion.so (gfx950 / MI355X only).
+ *
+ * Drop-in boundary for the attention-fusion hot path of
+ * klory/vqa-attention-networks.  The reference has NO native/FFI interface
+ * (SURVEY.md section 8b): its boundary is the Python nn.Module forward()
+ * signatures.  Each entry point below therefore names the *reference Python
+ * lines* whose arithmetic it replaces; the Python host layer
+ * (the host/ directory of vqa-attention-networks_amd) keeps the reference class names,
+ * constructors, forward() signatures and state_dict keys and calls these
+ * functions through ctypes with raw device pointers.  INTEGRATION.md shows
+ * the binding.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 unless stated otherwise;
+ *     row-major, innermost dimension contiguous;
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream);
+ *   - no function allocates, frees or synchronises; scratch memory is passed
+ *     in by the caller, so every call is hipGraph-capturable;
+ *   - return value: 0 on success, a hipError_t (>0) from the launch, or a
+ *     negative VQF_E_* code for argument errors;
+ *   - re-entrant: no mutable global state except the opt-in profiler.
+ *
+ * Shapes use the reference's symbols: N batch, T tokens, L image regions
+ * (196), D image channels (2048), H LSTM width, O = 1000 pooled outputs,
+ * k = 5 pooling window (mfb.py:42-43,100), so k*O = 5000.
+ */
+#ifndef VQA_FUSION_H
+#define VQA_FUSION_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VQF_OK 0
+#define VQF_E_BADARG (-1)      /* null pointer / non-positive size           */
+#define VQF_E_ALIGN (-2)       /* pointer or leading dimension not 16-B aligned where required */
+#define VQF_E_UNSUPPORTED (-3) /* shape outside what the kernel supports     */
+#define VQF_E_WORKSPACE (-4)   /* caller's scratch buffer too small          */
+
+#define VQF_POOL_K 5           /* mfb.py:100  .view(N, L, 1000, 5)           */
+
+/* GEMM epilogue flags */
+#define VQF_GEMM_RELU 1        /* C = max(C, 0)                              */
+#define VQF_GEMM_ACCUM 2       /* C += result (dgrad accumulation)           */
+
+/* ABI version and build information ("gfx950;fp32-mfma-32x32x2;...") */
+int vqf_abi_version(void);
+const char* vqf_build_info(void);
+
+/* --------------------------------------------------------------------------
+ * Dense projections on the fp32 MFMA pipe (v_mfma_f32_32x32x2_f32).
+ *
+ *   C[m,n] (+)= sum_k Aop[m,k] * Bop[n,k]  (+ bias[n])  (relu)
+ *   ta = 0: Aop[m,k] = A[m*lda + k]      ta = 1: Aop[m,k] = A[k*lda + m]
+ *   tb = 0: Bop[n,k] = B[n*ldb + k]      tb = 1: Bop[n,k] = B[k*ldb + n]
+ *
+ * Replaces every nn.Linear / 1x1 nn.Conv2d of the path and their autograd:
+ *   forward  (ta=0,tb=0): mfb.py:76,79,81,92,96,109,112,114,126-127,137;
+ *                         mhb_coAtt.py:81,83,94,98,111,113,124-125,136-137,148;
+ *                         hieCoAtten.py:25,30-31,35-36,54
+ *   dgrad    (ta=0,tb=1): dX = dY * W
+ *   wgrad    (ta=1,tb=1): dW = dY^T * X
+ * `ws`/`ws_bytes`: optional split-K scratch (may be NULL/0: no split).
+ * Vector (16-byte) loads are used when pointers and leading dimensions allow
+ * it; any shape/alignment is accepted.
+ */
+int vqf_gemm_f32(int ta, int tb, int M, int N, int K,
+                 const float* A, int lda, const float* B, int ldb,
+                 float* C, int ldc, const float* bias, int flags,
+                 void* ws, size_t ws_bytes, void* stream);
+
+/* Batched form: for b < batch, C_b = Aop_b * Bop_b^T with A_b = A + b*strideA etc.
+ * (element strides).  No bias, no split-K.  Per-sample products of
+ * hieCoAtten.py:32,38,41,45,48 and modules.py:65,91,94. */
+int vqf_gemm_f32_batched(int ta, int tb, int batch, int M, int N, int K,
+                         const float* A, int lda, long long strideA,
+                         const float* B, int ldb, long long strideB,
+                         float* C, int ldc, long long strideC, int flags, void* stream);
+
+/* db[n] = sum_m dY[m,n]   (bias gradients of the Linear/Conv layers).
+ * ws: scratch of at least vqf_colsum_ws_bytes(M,N) bytes. */
+size_t vqf_colsum_ws_bytes(int M, int N);
+int vqf_colsum_f32(const float* dY, int M, int N, int ldy, float* db,
+                   void* ws, size_t ws_bytes, void* stream);
+
+/* out[g,c] = sum_{j<J} in[(g*J + j), c]   (partial-slab reducer) */
+int vqf_group_reduce_f32(const float* in, int G, int J, int W, float* out, void* stream);
+
+/* dXpre = dX * (Y > 0); optional dbias[c] = sum_m dXpre[m,c].
+ * ReLU backward of the "multilayer" attention MLPs (mfb.py:78-80,111-113).
+ * ws as for vqf_colsum_f32 (only needed when dbias != NULL). */
+int vqf_relu_bwd_f32(const float* dX, const float* Y, int M, int C, float* dXpre,
+                     float* dbias, void* ws, size_t ws_bytes, void* stream);
+
+/* --------------------------------------------------------------------------
+ * Attention heads: hidden -> 2 glimpse logits, softmax, glimpse-weighted sum.
+ * Question side (S = T):  mfb.py:81-89   / mhb_coAtt.py:83-91
+ * Image side    (S = L):  mfb.py:114-123 / mhb_coAtt.py:113-121
+ */
+
+/* logits[m,g] = hid[m,:] . w2[g,:] + b2[g],  g in {0,1}; hid is (M,Hh). */
+int vqf_att_logits_fwd(const float* hid, const float* w2, const float* b2,
+                       int M, int Hh, float* logits, void* stream);
+
+/* Backward of the two-logit head THROUGH the preceding ReLU:
+ *   dhid_pre[m,j] = (dl[m,0] w2[0,j] + dl[m,1] w2[1,j]) * (hid[m,j] > 0)
+ *   dw2[g,j] = sum_m dl[m,g] hid[m,j];  db2[g] = sum_m dl[m,g]
+ *   dbias1[j] = sum_m dhid_pre[m,j]          (bias grad of the layer before)
+ * ws: at least vqf_att_logits_bwd_ws_bytes(M,Hh). */
+size_t vqf_att_logits_bwd_ws_bytes(int M, int Hh);
+int vqf_att_logits_bwd(const float* dlogits, const float* hid, const float* w2,
+                       int M, int Hh, float* dhid_pre, float* dw2, float* db2,
+                       float* dbias1, void* ws, size_t ws_bytes, void* stream);
+
+/* wts[n,g,:] = softmax_s(logits[n,:,g])   (unit_softmax != 0: wts == 1, the
+ * mfb.py:84,118 singleton-axis softmax);  pooled[n, g*C + c] = sum_s wts[n,g,s] feat[n,s,c].
+ * feat (N,S,C), logits (N*S,2), wts (N,2,S), pooled (N,2C).  S <= 1024. */
+int vqf_glimpse_pool_fwd(const float* feat, const float* logits, int N, int S, int C,
+                         int unit_softmax, float* wts, float* pooled, void* stream);
+
+/* Given dpooled (N,2C): dlogits (N*S,2) through the softmax (all zeros when
+ * unit_softmax), and, if dfeat != NULL, dfeat[n,s,c] = sum_g wts[n,g,s] dpooled[n,gC+c]
+ * (overwrites; the question side needs it, the image is data). */
+int vqf_glimpse_pool_bwd(const float* dpooled, const float* feat, const float* wts,
+                         int N, int S, int C, int unit_softmax,
+                         float* dlogits, float* dfeat, void* stream);
+
+/* --------------------------------------------------------------------------
+ * MFB fusion: product, dropout, k=5 sum-pool, signed sqrt, L2 normalise.
+ *   mfb.py:98-106 (L = 196 regions) and mfb.py:128-135 (L = 1, final block);
+ *   mhb_coAtt.py:100-108,126-145.
+ *
+ *  P    (N*L, 5*O)  projected image features (with bias)
+ *  q    (N,   5*O)  projected question, broadcast over the L rows of a sample
+ *  cascade (N*L, 5*O) or NULL: third factor of MHB's high-order block
+ *                   (mhb_coAtt.py:205, the dropped-out first-order product)
+ *  keep (N*L, 5*O)  uint8 keep-mask or NULL.  NULL and p_drop > 0: the mask is
+ *                   generated in-kernel from Philox4x32-10(seed, element index),
+ *                   identically in forward and backward.
+ *  R    (N*L, O)    signed sqrt of the pooled sums (un-normalised)
+ *  rowssq (N*L)     per-row sum of R^2 (= sum |pooled|)
+ *  zdrop (N*L,5*O) or NULL: the dropped-out product itself (only MHB needs it)
+ */
+int vqf_mfb_fuse_fwd(const float* P, const float* q, const float* cascade,
+                     const uint8_t* keep, uint64_t seed, float p_drop,
+                     int N, int L, int O, float* R, float* rowssq, float* zdrop,
+                     void* stream);
+
+/* norm[n] = sqrt(sum_l rowssq[n*L+l]);  inv[n] = 1 / max(norm[n], 1e-12)  (F.normalize eps) */
+int vqf_l2_group_norm(const float* rowssq, int N, int L, float* norm, float* inv, void* stream);
+
+/* Y[m,:] = R[m,:] * inv[m / L]   (in place allowed: Y == R) */
+int vqf_scale_rows(const float* R, const float* inv, int M, int L, int W, float* Y, void* stream);
+
+/* rowdot[m] = sum_o Y[m,o] * dY[m,o] */
+int vqf_rowdot(const float* Y, const float* dY, int M, int W, float* rowdot, void* stream);
+
+/* Coefficients of the F.normalize backward per sample:
+ *   dR = coefA[n] * dY - coefB[n] * Y,
+ *   coefA = inv, coefB = inv * sum_l rowdot   (coefB = 0 when norm <= eps: clamped branch) */
+int vqf_l2_norm_bwd_coef(const float* rowdot, const float* norm, const float* inv,
+                         int N, int L, float* coefA, float* coefB, void* stream);
+
+/* Backward of vqf_mfb_fuse_fwd given dY (N*L,O) w.r.t. the NORMALISED output Y
+ * and, optionally, dzdrop (N*L,5*O) w.r.t. the zdrop output (NULL: none):
+ *   dS = (coefA dY - coefB Y) * 0.5 * inv / |Y|     (0 where Y == 0: relu'(0) = 0)
+ *   dz[c] = (dS[c/5] + dzdrop[c]) * keep[c] / (1-p)
+ *   dP[m,c] = dz * q[n,c] (* cascade),  dq[n,c] = sum_l dz * P[m,c] (* cascade)
+ *   dcascade[m,c] = dz * P * q          (if cascade != NULL)
+ *   dbias_P[c] = sum_m dP[m,c]          (if dbiasP != NULL)
+ * ws: at least vqf_mfb_fuse_bwd_ws_bytes(N,L,O). */
+size_t vqf_mfb_fuse_bwd_ws_bytes(int N, int L, int O);
+int vqf_mfb_fuse_bwd(const float* dY, const float* dzdrop, const float* Y, const float* inv,
+                     const float* coefA, const float* coefB,
+                     const float* P, const float* q, const float* cascade,
+                     const uint8_t* keep, uint64_t seed, float p_drop,
+                     int N, int L, int O,
+                     float* dP, float* dq, float* dcascade, float* dbiasP,
+                     void* ws, size_t ws_bytes, void* stream);
+
+/* --------------------------------------------------------------------------
+ * Opt-in profiler: hipEvent pairs around every kernel launch, on the stream
+ * the kernel is launched on.  Off by default (zero overhead).
+ */
+void vqf_prof_enable(int on);
+void vqf_prof_reset(void);
+int vqf_prof_num_kernels(void);
+const char* vqf_prof_kernel_name(int id);
+/* synchronises the recorded events; returns launches and total milliseconds */
+int vqf_prof_get(int id, long long* launches, double* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VQA_FUSION_H */

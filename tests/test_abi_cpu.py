@@ -1,0 +1,87 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds/loads and exports
+every symbol include/vqa_fusion.h declares; host modules keep the reference's
+constructor signatures and state_dict layout; the product path refuses CPU tensors."""
+import os
+import re
+import types
+
+import pytest
+import torch
+
+from cases import MFB_CASES, MHBCOATT_CASES, make_cfg
+from oracle import ref_torch as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def vqa():
+    import vqa_amd
+    vqa_amd.build()
+    return vqa_amd
+
+
+def _header_symbols():
+    txt = open(os.path.join(ROOT, "include", "vqa_fusion.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(vqf_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol(vqa):
+    import ctypes
+    lib = ctypes.CDLL(vqa.lib.LIB_PATH)
+    syms = _header_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(lib, s), "libvqa_fusion.so does not export %s" % s
+
+
+def test_binding_table_covers_the_header(vqa):
+    assert sorted(vqa.lib.SIGNATURES.keys()) == _header_symbols()
+    lib = vqa.lib.load()
+    assert lib.vqf_abi_version() == 1
+    assert b"gfx950" in lib.vqf_build_info()
+    assert lib.vqf_prof_num_kernels() > 10
+    names = [lib.vqf_prof_kernel_name(i) for i in range(lib.vqf_prof_num_kernels())]
+    assert all(n for n in names)
+
+
+def test_workspace_size_queries_need_no_gpu(vqa):
+    lib = vqa.lib.load()
+    assert lib.vqf_colsum_ws_bytes(1000, 512) == 4 * 512 * 4
+    assert lib.vqf_mfb_fuse_bwd_ws_bytes(512, 196, 1000) == 2 * 512 * 4 * 5000 * 4
+    assert lib.vqf_att_logits_bwd_ws_bytes(100352, 1024) > 0
+    assert lib.vqf_colsum_ws_bytes(0, 5) == 0
+
+
+def test_state_dict_layout_matches_reference(vqa):
+    cfg = make_cfg(MFB_CASES[0])
+    assert {k: tuple(v.shape) for k, v in vqa.MFB(cfg).state_dict().items()} == \
+        {k: tuple(v) for k, v in O.mfb_shapes(cfg).items()}
+    cfgm = make_cfg(MFB_CASES[4])
+    assert {k: tuple(v.shape) for k, v in vqa.MFB(cfgm).state_dict().items()} == \
+        {k: tuple(v) for k, v in O.mfb_shapes(cfgm).items()}
+    cfgh = make_cfg(MHBCOATT_CASES[3])
+    assert {k: tuple(v.shape) for k, v in vqa.MHBCoAtt(cfgh).state_dict().items()} == \
+        {k: tuple(v) for k, v in O.mfb_shapes(cfgh, mhb=True).items()}
+    cfgb = types.SimpleNamespace(q_vocab_size=50, a_vocab_size=30, emb_dim=24, hidden_dim=64,
+                                 img_feature_channel=96, img_feature_dim=196, model_name="mhb")
+    assert {k: tuple(v.shape) for k, v in vqa.MHB(cfgb).state_dict().items()} == \
+        {k: tuple(v) for k, v in O.mhb_shapes(cfgb).items()}
+
+
+def test_product_path_has_no_cpu_fallback(vqa):
+    cfg = make_cfg(MFB_CASES[0])
+    m = vqa.MFB(cfg)
+    with pytest.raises(vqa.VqfError):
+        m(torch.zeros(2, cfg.img_feature_dim, cfg.img_feature_channel), torch.ones(2, 7, dtype=torch.long))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "vqa-attention-networks_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert "oracle" not in src.replace("no oracle", ""), os.path.join(dp, f)
+                assert "/root/reference" not in src

@@ -1,0 +1,241 @@
+"""GPU parity tests of every C-ABI entry point against plain torch (fp64 on CPU).
+
+All calls go through ctypes into libvqa_fusion.so (vqa_amd.ops).  Tolerances:
+1e-5 relative for GEMMs (fp32 MFMA == fmaf chain; reference in fp64), 1e-5 for
+the HBM-bound kernels; stated per test.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import vqa_amd
+    vqa_amd.lib.load()
+    return vqa_amd.ops
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    # rounded to fp32 so that the fp64 reference sees exactly the kernel's inputs
+    return ((torch.rand(shape, generator=g, dtype=torch.float64) * 2 - 1) * scale).float().double()
+
+
+def _pos(shape, seed):
+    g = torch.Generator().manual_seed(seed)
+    return (0.1 + 0.9 * torch.rand(shape, generator=g, dtype=torch.float64)).float().double()
+
+
+def _rel(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+GEMM_SHAPES = [(1, 1, 1), (5, 7, 3), (33, 65, 31), (130, 257, 70), (128, 128, 32), (256, 384, 1000),
+               (100, 5000, 64), (3, 2, 4096), (300, 200, 4100)]
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_all_layouts(ops, ta, tb, M, N, K):
+    A = _rand((K, M) if ta else (M, K), 1)
+    B = _rand((K, N) if tb else (N, K), 2)
+    bias = _rand((N,), 3)
+    ref = (A.t() if ta else A) @ (B if tb else B.t()) + bias
+    out = ops.gemm(A.float().cuda(), B.float().cuda(), ta=bool(ta), tb=bool(tb), bias=bias.float().cuda())
+    assert out.shape == (M, N)
+    assert _rel(out, ref) <= 2e-6 * max(1.0, np.sqrt(K) / 8)
+
+
+def test_gemm_relu_accumulate_and_splitk(ops):
+    M, N, K = 640, 512, 8192           # few tiles, deep K -> split-K path
+    A, B = _rand((K, M), 4), _rand((K, N), 5)
+    ref = A.t() @ B
+    out = ops.gemm(A.float().cuda(), B.float().cuda(), ta=True, tb=True)
+    assert _rel(out, ref) <= 1e-5
+    out_ns = ops.gemm(A.float().cuda(), B.float().cuda(), ta=True, tb=True, splitk=False)
+    assert _rel(out_ns, ref) <= 1e-5
+    # relu + accumulate
+    C0 = _rand((M, N), 6)
+    out2 = C0.float().cuda().clone()
+    ops.gemm(A.float().cuda(), B.float().cuda(), ta=True, tb=True, out=out2, accumulate=True, relu=True)
+    assert _rel(out2, torch.relu(ref + C0)) <= 1e-5
+
+
+def test_gemm_unaligned_views(ops):
+    """odd leading dimensions / offsets force the scalar-load path."""
+    M, N, K = 70, 50, 45
+    A = _rand((M, K + 3), 7)[:, 1:K + 1].contiguous()
+    B = _rand((N, K), 8)
+    out = ops.gemm(A.float().cuda(), B.float().cuda())
+    assert _rel(out, A @ B.t()) <= 1e-5
+
+
+def test_batched_gemm(ops):
+    Bn, M, N, K = 5, 22, 196, 64
+    A, B = _rand((Bn, M, K), 9), _rand((Bn, N, K), 10)
+    assert _rel(ops.bgemm(A.float().cuda(), B.float().cuda()), A @ B.transpose(1, 2)) <= 1e-5
+    A2, B2 = _rand((Bn, K, M), 11), _rand((Bn, K, N), 12)
+    assert _rel(ops.bgemm(A2.float().cuda(), B2.float().cuda(), ta=True, tb=True),
+                A2.transpose(1, 2) @ B2) <= 1e-5
+    # K = 14 (tokens) contraction, not a multiple of 4
+    A3, B3 = _rand((Bn, 64, 14), 13), _rand((Bn, 14, 196), 14)
+    assert _rel(ops.bgemm(A3.float().cuda(), B3.float().cuda(), tb=True), A3 @ B3) <= 1e-5
+
+
+def test_colsum_relu_bwd(ops):
+    for M, N in [(1, 5), (300, 1000), (5000, 512), (777, 33)]:
+        x = _rand((M, N), 20)
+        assert _rel(ops.colsum(x.float().cuda()), x.sum(0)) <= 1e-5
+    dx, y = _rand((300, 512), 21), _rand((300, 512), 22)
+    dpre, db = ops.relu_bwd(dx.float().cuda(), y.float().cuda())
+    ref = dx * (y > 0)
+    assert _rel(dpre, ref) == 0.0
+    assert _rel(db, ref.sum(0)) <= 1e-5
+
+
+@pytest.mark.parametrize("M,Hh", [(14, 1024), (7168, 512), (333, 64), (5, 36)])
+def test_att_logits_fwd_bwd(ops, M, Hh):
+    hid = torch.relu(_rand((M, Hh), 30))
+    w2, b2 = _rand((2, Hh), 31, 0.1), _rand((2,), 32)
+    ref = hid @ w2.t() + b2
+    out = ops.att_logits_fwd(hid.float().cuda(), w2.float().cuda(), b2.float().cuda())
+    assert _rel(out, ref) <= 1e-5
+    dl = _rand((M, 2), 33)
+    dpre, dw2, db2, db1 = ops.att_logits_bwd(dl.float().cuda(), hid.float().cuda(), w2.float().cuda())
+    ref_pre = (dl @ w2) * (hid > 0)
+    assert _rel(dpre, ref_pre) <= 1e-5
+    assert _rel(dw2, dl.t() @ hid) <= 1e-5
+    assert _rel(db2, dl.sum(0)) <= 1e-5
+    assert _rel(db1, ref_pre.sum(0)) <= 1e-5
+
+
+@pytest.mark.parametrize("unit", [False, True])
+@pytest.mark.parametrize("N,S,C", [(3, 14, 1024), (2, 196, 2048), (5, 22, 64), (1, 1, 8), (2, 7, 36)])
+def test_glimpse_pool_fwd_bwd(ops, N, S, C, unit):
+    feat = _rand((N, S, C), 40).requires_grad_()
+    logits = _rand((N * S, 2), 41, 3.0).requires_grad_()
+    lg = logits.view(N, S, 2).permute(0, 2, 1)
+    w = torch.ones_like(lg) if unit else torch.softmax(lg, dim=2)
+    pooled_ref = torch.einsum("ngs,nsc->ngc", w, feat).reshape(N, 2 * C)
+    wts, pooled = ops.glimpse_pool_fwd(feat.detach().float().cuda(), logits.detach().float().cuda(), unit)
+    assert _rel(wts, w) <= 1e-5
+    assert _rel(pooled, pooled_ref) <= 1e-5
+    dp = _rand((N, 2 * C), 42)
+    pooled_ref.backward(dp)
+    dlogits, dfeat = ops.glimpse_pool_bwd(dp.float().cuda(), feat.detach().float().cuda(), wts, unit, True)
+    if unit:
+        assert float(dlogits.abs().max()) == 0.0
+    else:
+        assert _rel(dlogits, logits.grad) <= 2e-5
+    assert _rel(dfeat, feat.grad) <= 1e-5
+
+
+def _ssqrt(s):
+    return torch.sqrt(torch.relu(s)) - torch.sqrt(torch.relu(-s))
+
+
+@pytest.mark.parametrize("N,L,O,use_keep,use_casc", [(3, 196, 1000, False, False), (2, 20, 1000, True, False),
+                                                     (4, 1, 1000, True, False), (3, 1, 1000, True, True),
+                                                     (2, 5, 8, True, True), (1, 3, 1000, False, False)])
+def test_mfb_fuse_fwd_bwd(ops, N, L, O, use_keep, use_casc):
+    W5 = 5 * O
+    # |pooled sum| stays >= 0.05: all 5 products of a pooling window share one sign, so the
+    # singular derivative 0.5/sqrt|s| does not amplify fp32 rounding in this kernel-level check
+    P = _pos((N * L, W5), 50).requires_grad_()
+    gsign = torch.sign(_rand((N, O), 56) + 1e-3).repeat_interleave(5, 1)
+    q = (_pos((N, W5), 51) * gsign).requires_grad_()
+    casc = _pos((N * L, W5), 52).requires_grad_() if use_casc else None
+    keep = (torch.rand((N * L, W5), generator=torch.Generator().manual_seed(53)) >= 0.1).to(torch.uint8) \
+        if use_keep else None
+    z = P * q.repeat_interleave(L, 0)
+    if use_casc:
+        z = z * casc
+    if use_keep:
+        z = z * (keep.double() / (1.0 - np.float32(0.1).astype(np.float64)))
+    S = z.view(N * L, O, 5).sum(2)
+    R = _ssqrt(S)
+    Y_ref = torch.nn.functional.normalize(R.view(N, -1)).view(N * L, O)
+    cu = lambda t: None if t is None else t.detach().float().cuda()
+    Y, norm, inv, zdrop = ops.mfb_fuse_fwd(cu(P), cu(q), N, L, O, keep=None if keep is None else keep.cuda(),
+                                           p_drop=0.1 if use_keep else 0.0, cascade=cu(casc),
+                                           want_zdrop=use_casc)
+    assert _rel(Y, Y_ref) <= 1e-5
+    assert _rel(norm, R.view(N, -1).norm(dim=1)) <= 1e-5
+    if use_casc:
+        assert _rel(zdrop, z) <= 1e-5
+    dY = _rand((N * L, O), 54)
+    dzx = _rand((N * L, W5), 55) if use_casc else None
+    loss = (Y_ref * dY).sum() + ((z * dzx).sum() if use_casc else 0.0)
+    loss.backward()
+    dP, dq, dc, db = ops.mfb_fuse_bwd(cu(dY), Y, norm, inv, cu(P), cu(q), N, L, O,
+                                      keep=None if keep is None else keep.cuda(),
+                                      p_drop=0.1 if use_keep else 0.0, cascade=cu(casc), want_dbias=True,
+                                      dzdrop=cu(dzx))
+    assert _rel(dP, P.grad) <= 2e-5
+    assert _rel(dq, q.grad) <= 2e-5
+    assert _rel(db, P.grad.sum(0)) <= 2e-5
+    if use_casc:
+        assert _rel(dc, casc.grad) <= 2e-5
+
+
+def test_mfb_fuse_zero_pool_has_zero_grad(ops):
+    """relu'(0) = 0: a pooled sum that is exactly 0 contributes no gradient (and no NaN)."""
+    N, L, O = 2, 3, 8
+    P = _rand((N * L, 5 * O), 60).float().cuda()
+    q = _rand((N, 5 * O), 61).float().cuda()
+    P[:, :5] = 0.0
+    Y, norm, inv, _ = ops.mfb_fuse_fwd(P, q, N, L, O)
+    assert float(Y[:, 0].abs().max()) == 0.0
+    dP, dq, _, _ = ops.mfb_fuse_bwd(torch.ones_like(Y), Y, norm, inv, P, q, N, L, O)
+    assert torch.isfinite(dP).all() and torch.isfinite(dq).all()
+    assert float(dP[:, :5].abs().max()) == 0.0
+
+
+def test_mfb_fuse_philox_dropout(ops):
+    """in-kernel Philox mask: P(drop) ~ p, same mask in forward and backward, seed-dependent."""
+    N, L, O = 4, 50, 1000
+    P = torch.ones((N * L, 5 * O), device="cuda")
+    q = torch.ones((N, 5 * O), device="cuda")
+    _, _, _, z = ops.mfb_fuse_fwd(P, q, N, L, O, seed=1234, p_drop=0.1, want_zdrop=True)
+    kept = (z != 0)
+    frac = 1.0 - kept.float().mean().item()
+    assert abs(frac - 0.1) < 2e-3, frac
+    assert torch.allclose(z[kept], torch.full_like(z[kept], 1.0 / 0.9), rtol=1e-6)
+    _, _, _, z2 = ops.mfb_fuse_fwd(P, q, N, L, O, seed=1234, p_drop=0.1, want_zdrop=True)
+    assert torch.equal(z, z2)
+    _, _, _, z3 = ops.mfb_fuse_fwd(P, q, N, L, O, seed=1235, p_drop=0.1, want_zdrop=True)
+    assert not torch.equal(z, z3)
+    # backward sees the same mask: dP is zero exactly where the forward dropped
+    Y, norm, inv, _ = ops.mfb_fuse_fwd(P, q, N, L, O, seed=1234, p_drop=0.1)
+    dY = torch.ones_like(Y)
+    dP, _, _, _ = ops.mfb_fuse_bwd(dY, Y, norm, inv, P, q, N, L, O, seed=1234, p_drop=0.1)
+    assert torch.equal(dP != 0, kept) or float(((dP != 0) ^ kept).float().mean()) < 1e-3
+
+
+def test_l2_norm_clamp_branch(ops):
+    """all-zero sample: F.normalize clamps the norm at eps; backward has no projection term."""
+    N, L, O = 2, 2, 8
+    P = _rand((N * L, 5 * O), 70).float().cuda()
+    q = _rand((N, 5 * O), 71).float().cuda()
+    q[1] = 0.0
+    Y, norm, inv, _ = ops.mfb_fuse_fwd(P, q, N, L, O)
+    assert float(norm[1]) == 0.0 and float(Y[L:].abs().max()) == 0.0
+    dP, dq, _, _ = ops.mfb_fuse_bwd(torch.ones_like(Y), Y, norm, inv, P, q, N, L, O)
+    assert torch.isfinite(dP).all() and torch.isfinite(dq).all()
+
+
+def test_errors_are_loud(ops):
+    import vqa_amd
+    with pytest.raises(vqa_amd.VqfError):
+        ops.gemm(torch.zeros(4, 4), torch.zeros(4, 4))                 # CPU tensors: no fallback
+    with pytest.raises(vqa_amd.VqfError):
+        ops.gemm(torch.zeros(4, 4, device="cuda"), torch.zeros(4, 5, device="cuda"))
+    with pytest.raises(vqa_amd.VqfError):
+        ops.mfb_fuse_fwd(torch.zeros(2, 35, device="cuda"), torch.zeros(2, 35, device="cuda"), 2, 1, 7)
+    with pytest.raises(vqa_amd.VqfError):
+        ops.glimpse_pool_fwd(torch.zeros(1, 2000, 4, device="cuda"), torch.zeros(2000, 2, device="cuda"), False)

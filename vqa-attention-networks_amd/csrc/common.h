@@ -1,0 +1,83 @@
+// Internal helpers shared by the .hip translation units (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/vqa_fusion.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// kernel ids for the profiler (keep in sync with prof.hip names[])
+enum VqfKernelId {
+  KID_GEMM_A0B0 = 0, // ta=0,tb=0   (forward projections); id = KID_GEMM_A0B0 + 2*ta + tb
+  KID_GEMM_A0B1,     // ta=0,tb=1   (dgrad)
+  KID_GEMM_A1B0,     // ta=1,tb=0
+  KID_GEMM_A1B1,     // ta=1,tb=1   (wgrad)
+  KID_SPLITK_REDUCE,
+  KID_COLSUM,
+  KID_GROUP_REDUCE,
+  KID_RELU_BWD,
+  KID_ATT_LOGITS_FWD,
+  KID_ATT_LOGITS_BWD,
+  KID_GLIMPSE_FWD,
+  KID_GLIMPSE_BWD,
+  KID_MFB_FUSE_FWD,
+  KID_L2_GROUP_NORM,
+  KID_SCALE_ROWS,
+  KID_ROWDOT,
+  KID_L2_BWD_COEF,
+  KID_MFB_FUSE_BWD,
+  KID_COUNT
+};
+
+extern int g_vqf_prof_on;
+void vqf_prof_begin(int id, hipStream_t s);
+void vqf_prof_end(int id, hipStream_t s);
+
+// Launch with optional event bracketing; evaluates to the launch error code.
+#define VQF_LAUNCH(id, kern, grid, block, shmem, stream, ...)                      \
+  do {                                                                             \
+    if (g_vqf_prof_on) vqf_prof_begin((id), (stream));                             \
+    hipLaunchKernelGGL(kern, grid, block, shmem, stream, __VA_ARGS__);             \
+    if (g_vqf_prof_on) vqf_prof_end((id), (stream));                               \
+  } while (0)
+
+static inline int vqf_last_error() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? VQF_OK : (int)e;
+}
+
+static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// ---- device helpers -------------------------------------------------------
+__device__ __forceinline__ bool aligned16_dev(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Philox4x32-10 (Salmon et al.), counter = (ctr_lo, ctr_hi, 0, 0), key = seed.
+__device__ __forceinline__ uint4 philox4x32_10(uint64_t ctr, uint64_t seed) {
+  uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0u, c3 = 0u;
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return make_uint4(c0, c1, c2, c3);
+}
+// keep iff uniform(0,1) >= p  <=>  u32 >= p * 2^32   (host side; passed to the kernels)
+static inline uint32_t drop_threshold_host(float p) {
+  double t = (double)p * 4294967296.0;
+  return t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+}

@@ -1,0 +1,246 @@
+// MFB fusion stage (HBM-bound): broadcast product, dropout, k=5 sum-pool,
+// signed square root, and the per-row partial of the per-sample L2 norm.
+//
+//   mfb.py:98-106  (L = 196: image projection x question projection)
+//   mfb.py:128-135 (L = 1:   final block)      mhb_coAtt.py:100-108,126-145,192-211
+//
+// One thread owns 4 pooled outputs = 20 consecutive projection columns, i.e.
+// five 16-byte loads from the (N*L, 5000) projection row; a 256-thread
+// workgroup owns one row (1000 pooled outputs -> 250 active lanes), so every
+// HBM access is a fully coalesced 16-B-per-lane stream.  The 5-wide pooling
+// window never crosses a thread (20 = 4*5), so no cross-lane traffic is needed
+// for the pool; the row's sum of squares is a wavefront-shuffle reduction.
+// Dropout masks are never stored: forward and backward regenerate them from
+// Philox4x32-10(seed, element index / 4).
+#include "common.h"
+
+namespace {
+
+constexpr int KP = VQF_POOL_K;      // 5
+constexpr int TPT = 4;              // pooled outputs per thread
+constexpr int CPT = KP * TPT;       // 20 projection columns per thread
+
+__device__ __forceinline__ void load20(const float* __restrict__ p, float (&v)[CPT]) {
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const f32x4 x = *reinterpret_cast<const f32x4*>(p + 4 * i);
+    v[4 * i] = x[0]; v[4 * i + 1] = x[1]; v[4 * i + 2] = x[2]; v[4 * i + 3] = x[3];
+  }
+}
+__device__ __forceinline__ void store20(float* __restrict__ p, const float (&v)[CPT]) {
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    f32x4 x = {v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
+    *reinterpret_cast<f32x4*>(p + 4 * i) = x;
+  }
+}
+
+// scale[i] = keep ? 1/(1-p) : 0 for the 20 elements starting at flat index e0 (e0 % 4 == 0)
+__device__ __forceinline__ void keep_scale20(const uint8_t* __restrict__ keep, uint64_t seed,
+                                             uint32_t thr, float inv_keep, long long e0,
+                                             float (&sc)[CPT]) {
+  if (keep) {
+    const uint32_t* k32 = reinterpret_cast<const uint32_t*>(keep + e0);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const uint32_t w = k32[i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sc[4 * i + j] = ((w >> (8 * j)) & 0xFFu) ? inv_keep : 0.f;
+    }
+  } else if (thr != 0u) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const uint4 r = philox4x32_10((uint64_t)(e0 >> 2) + i, seed);
+      sc[4 * i] = r.x >= thr ? inv_keep : 0.f;
+      sc[4 * i + 1] = r.y >= thr ? inv_keep : 0.f;
+      sc[4 * i + 2] = r.z >= thr ? inv_keep : 0.f;
+      sc[4 * i + 3] = r.w >= thr ? inv_keep : 0.f;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) sc[i] = 1.0f;
+  }
+}
+
+// grid = N*L rows; block = 256
+__global__ void __launch_bounds__(256)
+mfb_fuse_fwd_kernel(const float* __restrict__ P, const float* __restrict__ q,
+                    const float* __restrict__ cascade, const uint8_t* __restrict__ keep,
+                    uint64_t seed, uint32_t thr, float inv_keep, int L, int O,
+                    float* __restrict__ R, float* __restrict__ rowssq, float* __restrict__ zdrop) {
+  __shared__ float red[4];
+  const long long row = blockIdx.x;
+  const int n = (int)(row / L);
+  const int W5 = KP * O;
+  const int tid = threadIdx.x;
+  float ssq = 0.f;
+  for (int t = tid; t < O / TPT; t += 256) {
+    const long long e0 = row * W5 + (long long)CPT * t;
+    float p[CPT], qq[CPT], sc[CPT];
+    load20(P + e0, p);
+    load20(q + (long long)n * W5 + CPT * t, qq);
+    keep_scale20(keep, seed, thr, inv_keep, e0, sc);
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) p[i] *= qq[i];
+    if (cascade) {
+      load20(cascade + e0, qq);
+#pragma unroll
+      for (int i = 0; i < CPT; ++i) p[i] *= qq[i];
+    }
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) p[i] *= sc[i];
+    if (zdrop) store20(zdrop + e0, p);
+    f32x4 r;
+#pragma unroll
+    for (int j = 0; j < TPT; ++j) {
+      const float s = (((p[5 * j] + p[5 * j + 1]) + p[5 * j + 2]) + p[5 * j + 3]) + p[5 * j + 4];
+      const float a = fabsf(s);
+      ssq += a;                                  // (sign(s) sqrt|s|)^2 == |s|
+      const float rt = sqrtf(a);
+      r[j] = s < 0.f ? -rt : rt;                 // sqrt(relu(s)) - sqrt(relu(-s))
+    }
+    *reinterpret_cast<f32x4*>(R + row * O + TPT * t) = r;
+  }
+  ssq = wave_sum(ssq);
+  if ((tid & 63) == 0) red[tid >> 6] = ssq;
+  __syncthreads();
+  if (tid == 0) rowssq[row] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// grid (N, LS); block 256.  Each block walks rows l = ls, ls+LS, ... of sample n.
+template <bool CASC, bool DBIAS>
+__global__ void __launch_bounds__(256)
+mfb_fuse_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ dzdrop,
+                    const float* __restrict__ Y,
+                    const float* __restrict__ inv, const float* __restrict__ coefA,
+                    const float* __restrict__ coefB, const float* __restrict__ P,
+                    const float* __restrict__ q, const float* __restrict__ cascade,
+                    const uint8_t* __restrict__ keep, uint64_t seed, uint32_t thr, float inv_keep,
+                    int L, int O, int LS, float* __restrict__ dP, float* __restrict__ dq_part,
+                    float* __restrict__ dcascade, float* __restrict__ db_part) {
+  const int n = blockIdx.x, ls = blockIdx.y;
+  const int W5 = KP * O;
+  const float ca = coefA[n], cb = coefB[n], hi = 0.5f * inv[n];
+  for (int t = threadIdx.x; t < O / TPT; t += 256) {
+    float qq[CPT], dq[CPT], db[CPT];
+    load20(q + (long long)n * W5 + CPT * t, qq);
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) { dq[i] = 0.f; db[i] = 0.f; }
+    for (int l = ls; l < L; l += LS) {
+      const long long row = (long long)n * L + l;
+      const long long e0 = row * W5 + (long long)CPT * t;
+      const f32x4 dy = *reinterpret_cast<const f32x4*>(dY + row * O + TPT * t);
+      const f32x4 y = *reinterpret_cast<const f32x4*>(Y + row * O + TPT * t);
+      float p[CPT], sc[CPT], cc[CPT];
+      load20(P + e0, p);
+      if (CASC) load20(cascade + e0, cc);
+      keep_scale20(keep, seed, thr, inv_keep, e0, sc);
+      float ds[TPT];
+#pragma unroll
+      for (int j = 0; j < TPT; ++j) {
+        const float ay = fabsf(y[j]);
+        // d sqrt(relu(s)) - sqrt(relu(-s)) = 0.5/|R| for R != 0, and 0 at 0 (relu'(0) = 0)
+        ds[j] = ay > 0.f ? (ca * dy[j] - cb * y[j]) * (hi / ay) : 0.f;
+      }
+      float dp[CPT], dc[CPT], dzx[CPT];
+      if (dzdrop) load20(dzdrop + e0, dzx);
+#pragma unroll
+      for (int i = 0; i < CPT; ++i) {
+        const float dz = (dzdrop ? ds[i / KP] + dzx[i] : ds[i / KP]) * sc[i];
+        if (CASC) {
+          dp[i] = dz * qq[i] * cc[i];
+          dq[i] += dz * p[i] * cc[i];
+          dc[i] = dz * p[i] * qq[i];
+        } else {
+          dp[i] = dz * qq[i];
+          dq[i] += dz * p[i];
+        }
+        if (DBIAS) db[i] += dp[i];
+      }
+      store20(dP + e0, dp);
+      if (CASC) store20(dcascade + e0, dc);
+    }
+    const long long po = ((long long)n * LS + ls) * W5 + CPT * t;
+    store20(dq_part + po, dq);
+    if (DBIAS) store20(db_part + po, db);
+  }
+}
+
+int pick_ls(int N, int L) {
+  // enough blocks to cover 256 CUs x 4, but never more splits than rows
+  int ls = 1;
+  while ((long long)N * ls < 2048 && ls * 2 <= L && ls < 16) ls *= 2;
+  return ls;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vqf_mfb_fuse_fwd(const float* P, const float* q, const float* cascade, const uint8_t* keep,
+                     uint64_t seed, float p_drop, int N, int L, int O, float* R, float* rowssq,
+                     float* zdrop, void* stream) {
+  if (!P || !q || !R || !rowssq || N <= 0 || L <= 0 || O <= 0) return VQF_E_BADARG;
+  if (O % TPT) return VQF_E_UNSUPPORTED;
+  if (p_drop < 0.f || p_drop >= 1.f) return VQF_E_BADARG;
+  if (!aligned16(P) || !aligned16(q) || !aligned16(R) || (cascade && !aligned16(cascade)) ||
+      (zdrop && !aligned16(zdrop)) || (keep && (((uintptr_t)keep) & 3)))
+    return VQF_E_ALIGN;
+  const uint32_t thr = (keep || p_drop == 0.f) ? 0u : drop_threshold_host(p_drop);
+  const float inv_keep = (keep || p_drop > 0.f) ? 1.0f / (1.0f - p_drop) : 1.0f;
+  const long long rows = (long long)N * L;
+  VQF_LAUNCH(KID_MFB_FUSE_FWD, mfb_fuse_fwd_kernel, dim3((unsigned)rows), dim3(256), 0,
+             (hipStream_t)stream, P, q, cascade, keep, seed, thr, inv_keep, L, O, R, rowssq, zdrop);
+  return vqf_last_error();
+}
+
+size_t vqf_mfb_fuse_bwd_ws_bytes(int N, int L, int O) {
+  if (N <= 0 || L <= 0 || O <= 0) return 0;
+  return (size_t)2 * N * pick_ls(N, L) * KP * O * sizeof(float);
+}
+
+int vqf_mfb_fuse_bwd(const float* dY, const float* dzdrop, const float* Y, const float* inv,
+                     const float* coefA,
+                     const float* coefB, const float* P, const float* q, const float* cascade,
+                     const uint8_t* keep, uint64_t seed, float p_drop, int N, int L, int O,
+                     float* dP, float* dq, float* dcascade, float* dbiasP, void* ws,
+                     size_t ws_bytes, void* stream) {
+  if (!dY || !Y || !inv || !coefA || !coefB || !P || !q || !dP || !dq || N <= 0 || L <= 0 || O <= 0)
+    return VQF_E_BADARG;
+  if (O % TPT) return VQF_E_UNSUPPORTED;
+  if ((cascade != nullptr) != (dcascade != nullptr)) return VQF_E_BADARG;
+  if (p_drop < 0.f || p_drop >= 1.f) return VQF_E_BADARG;
+  if (!aligned16(dY) || (dzdrop && !aligned16(dzdrop)) || !aligned16(Y) || !aligned16(P) || !aligned16(q) || !aligned16(dP) ||
+      !aligned16(dq) || (cascade && (!aligned16(cascade) || !aligned16(dcascade))) ||
+      (keep && (((uintptr_t)keep) & 3)))
+    return VQF_E_ALIGN;
+  const int LS = pick_ls(N, L);
+  const int W5 = KP * O;
+  const bool direct = (LS == 1);      // dq partial == dq
+  if (!direct || dbiasP) {
+    if (!ws || ws_bytes < vqf_mfb_fuse_bwd_ws_bytes(N, L, O) || !aligned16(ws)) return VQF_E_WORKSPACE;
+  }
+  float* dq_part = direct ? dq : (float*)ws;
+  float* db_part = (float*)ws + (size_t)N * LS * W5;
+  const uint32_t thr = (keep || p_drop == 0.f) ? 0u : drop_threshold_host(p_drop);
+  const float inv_keep = (keep || p_drop > 0.f) ? 1.0f / (1.0f - p_drop) : 1.0f;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(N, LS);
+#define VQF_BWD(C_, D_)                                                                        \
+  VQF_LAUNCH(KID_MFB_FUSE_BWD, (mfb_fuse_bwd_kernel<C_, D_>), grid, dim3(256), 0, s, dY, dzdrop, Y, inv, \
+             coefA, coefB, P, q, cascade, keep, seed, thr, inv_keep, L, O, LS, dP, dq_part,    \
+             dcascade, db_part)
+  if (cascade) { if (dbiasP) VQF_BWD(true, true); else VQF_BWD(true, false); }
+  else         { if (dbiasP) VQF_BWD(false, true); else VQF_BWD(false, false); }
+#undef VQF_BWD
+  int rc = vqf_last_error();
+  if (rc) return rc;
+  if (!direct) {
+    rc = vqf_group_reduce_f32(dq_part, N, LS, W5, dq, stream);
+    if (rc) return rc;
+  }
+  if (dbiasP) rc = vqf_group_reduce_f32(db_part, 1, N * LS, W5, dbiasP, stream);
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,319 @@
+// fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32), gfx950 only.
+//
+//   C[m,n] (+)= sum_k Aop[m,k] * Bop[n,k] (+ bias[n]) (relu)
+//
+// Replaces the nn.Linear / 1x1 nn.Conv2d forward, dgrad and wgrad GEMMs of the
+// reference path (list in include/vqa_fusion.h).  The dominant instance is the
+// image projection img_conv1d (mfb.py:96): M = N*196, K = 2048, N = 5000.
+//
+// Design (MI355X-first, not a warp-tiling port):
+//   * 256-thread workgroup = 4 wave64, one per SIMD; 2 workgroups per CU.
+//   * 128x128x32 block tile, each wave owns a 64x64 sub-tile = 2x2 MFMA
+//     32x32 accumulators (64 accumulator VGPRs); the fp32 MFMA is 64 cycles per
+//     instruction per SIMD, so 4 independent accumulators per wave keep the
+//     pipe back-to-back and LDS/global traffic is <15 % of the issue slots.
+//   * operands are staged global -> registers -> LDS with the NEXT tile's global
+//     loads issued before the current tile's MFMAs (register prefetch) and two
+//     LDS buffers, so there is one barrier per K-tile.
+//   * "row-major K-contiguous" operands (activations, weights in forward) live
+//     in LDS as [row][32+4] and are read with one ds_read_b128 per 8 k (the 16-B
+//     row pad makes the 16-lane b128 groups conflict-free); "K-major" operands
+//     (both operands of wgrad, the weight in dgrad) live as [k][128] and are read
+//     with conflict-free ds_read_b32.  Both give lane (i, h) the k-indices
+//     {8g+4h+j}, j=0..3, so A and B fragments always agree on k.
+//   * workgroup ids are remapped so that each XCD (private 4 MiB L2) walks a
+//     contiguous range of output tiles: the 40 column tiles that share one
+//     128-row slab of the (N*196, 2048) image tensor hit that XCD's L2.
+//   * split-K (grid.y) with a deterministic slab reduction for the wgrad
+//     shapes (few output tiles, K = N*196).
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32, NTHREADS = 256;
+constexpr int LD_RK = BK + 4;                 // floats; [row][k] image, 16-B pad
+constexpr int OP_FLOATS = BM * LD_RK;         // 4608 floats >= BK*BM (4096)
+constexpr int STAGE_FLOATS = 2 * OP_FLOATS;   // A + B
+constexpr int SMEM_BYTES = 2 * STAGE_FLOATS * 4;   // 73,728 B (double buffered)
+
+struct GemmArgs {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;
+  float* slab;             // split-K partials [splits][M][N] or nullptr
+  int M, N, K, lda, ldb, ldc;
+  int flags;
+  int kchunk;              // K range per grid.y slice (multiple of BK)
+  int tiles_m, tiles_n;
+  int vecA, vecB;          // 16-B vector loads allowed
+  long long sA, sB, sC;    // batch strides (grid.z), 0 when not batched
+};
+
+// ---- global -> register staging ------------------------------------------
+// T == false: operand(row r, k) = p[r*ld + k]   (tile rows x BK, 8 float4 per row)
+// T == true : operand(row r, k) = p[k*ld + r]   (BK k-rows x 128, 32 float4 per k-row)
+template <bool T>
+__device__ __forceinline__ void load_tile(const float* __restrict__ p, int ld, int r0, int R,
+                                          int k0, int kend, bool vec, int tid, f32x4 (&v)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int f = tid + NTHREADS * i;
+    int r, k;
+    if (!T) { r = r0 + (f >> 3); k = k0 + ((f & 7) << 2); }
+    else    { k = k0 + (f >> 5); r = r0 + ((f & 31) << 2); }
+    f32x4 x = {0.f, 0.f, 0.f, 0.f};
+    if (!T) {
+      if (r < R) {
+        const float* q = p + (long long)r * ld + k;
+        if (vec && k + 3 < kend) x = *reinterpret_cast<const f32x4*>(q);
+        else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) if (k + j < kend) x[j] = q[j];
+        }
+      }
+    } else {
+      if (k < kend) {
+        const float* q = p + (long long)k * ld + r;
+        if (vec && r + 3 < R) x = *reinterpret_cast<const f32x4*>(q);
+        else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) if (r + j < R) x[j] = q[j];
+        }
+      }
+    }
+    v[i] = x;
+  }
+}
+
+template <bool T>
+__device__ __forceinline__ void store_tile(float* s, int tid, const f32x4 (&v)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int f = tid + NTHREADS * i;
+    if (!T) *reinterpret_cast<f32x4*>(s + (f >> 3) * LD_RK + ((f & 7) << 2)) = v[i];
+    else    *reinterpret_cast<f32x4*>(s + (f >> 5) * BM + ((f & 31) << 2)) = v[i];
+  }
+}
+
+// fragment of one 32-row sub-tile for k-group g8 (8 consecutive k)
+template <bool T>
+__device__ __forceinline__ f32x4 read_frag(const float* s, int row, int g8, int h) {
+  if (!T) return *reinterpret_cast<const f32x4*>(s + row * LD_RK + g8 * 8 + 4 * h);
+  f32x4 x;
+  const float* q = s + (g8 * 8 + 4 * h) * BM + row;
+  x[0] = q[0]; x[1] = q[BM]; x[2] = q[2 * BM]; x[3] = q[3 * BM];
+  return x;
+}
+
+template <bool TA, bool TB>
+__global__ void __launch_bounds__(NTHREADS, 2) gemm_f32_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int l31 = lane & 31, h = lane >> 5;
+
+  // XCD-aware, bijective tile remap (blocks b and b+8 share an XCD's L2)
+  const int nwg = g.tiles_m * g.tiles_n;
+  const int bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int tm = wg / g.tiles_n, tn = wg - tm * g.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int kbeg = blockIdx.y * g.kchunk;
+  const int kend = min(g.K, kbeg + g.kchunk);
+  const int ntiles = (kend - kbeg + BK - 1) / BK;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const float* gA = g.A + (long long)blockIdx.z * g.sA;
+  const float* gB = g.B + (long long)blockIdx.z * g.sB;
+  f32x4 ra[4], rb[4];
+  load_tile<TA>(gA, g.lda, m0, g.M, kbeg, kend, g.vecA, tid, ra);
+  load_tile<TB>(gB, g.ldb, n0, g.N, kbeg, kend, g.vecB, tid, rb);
+  store_tile<TA>(smem, tid, ra);
+  store_tile<TB>(smem + OP_FLOATS, tid, rb);
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    const float* sA = smem + (t & 1) * STAGE_FLOATS;
+    const float* sB = sA + OP_FLOATS;
+    const bool more = (t + 1) < ntiles;
+    if (more) {
+      const int k0 = kbeg + (t + 1) * BK;
+      load_tile<TA>(gA, g.lda, m0, g.M, k0, kend, g.vecA, tid, ra);
+      load_tile<TB>(gB, g.ldb, n0, g.N, k0, kend, g.vecB, tid, rb);
+    }
+#pragma unroll
+    for (int g8 = 0; g8 < BK / 8; ++g8) {
+      f32x4 af[2], bf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[i] = read_frag<TA>(sA, wr * 64 + i * 32 + l31, g8, h);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bf[j] = read_frag<TB>(sB, wc * 64 + j * 32 + l31, g8, h);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      float* d = smem + ((t + 1) & 1) * STAGE_FLOATS;
+      store_tile<TA>(d, tid, ra);
+      store_tile<TB>(d + OP_FLOATS, tid, rb);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const bool to_slab = g.slab != nullptr;
+  float* out = to_slab ? g.slab + (long long)blockIdx.y * g.M * g.N
+                       : g.C + (long long)blockIdx.z * g.sC;
+  const int ldo = to_slab ? g.N : g.ldc;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + wc * 64 + j * 32 + l31;
+    if (col >= g.N) continue;
+    const float bv = (!to_slab && g.bias) ? g.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < g.M) {
+          float* pc = out + (long long)row * ldo + col;
+          float v = acc[i][j][r] + bv;
+          if (!to_slab) {
+            if (g.flags & VQF_GEMM_ACCUM) v += *pc;
+            if (g.flags & VQF_GEMM_RELU) v = fmaxf(v, 0.f);
+          }
+          *pc = v;
+        }
+      }
+    }
+  }
+}
+
+// C = sum_z slab[z] + bias (+C) (relu);  float4 over flattened (M,N) when possible
+__global__ void splitk_reduce_kernel(const float* __restrict__ slab, int splits, int M, int N,
+                                     float* __restrict__ C, int ldc, const float* __restrict__ bias,
+                                     int flags) {
+  const long long total = (long long)M * N;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int row = (int)(i / N), col = (int)(i - (long long)row * N);
+    float v = 0.f;
+    for (int z = 0; z < splits; ++z) v += slab[(long long)z * total + i];
+    if (bias) v += bias[col];
+    float* pc = C + (long long)row * ldc + col;
+    if (flags & VQF_GEMM_ACCUM) v += *pc;
+    if (flags & VQF_GEMM_RELU) v = fmaxf(v, 0.f);
+    *pc = v;
+  }
+}
+
+template <bool TA, bool TB>
+int launch_gemm(const GemmArgs& g, dim3 grid, hipStream_t s, int kid) {
+  static bool attr_done = false;   // idempotent; a race only repeats the same call
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<TA, TB>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  VQF_LAUNCH(kid, (gemm_f32_kernel<TA, TB>), grid, dim3(NTHREADS), SMEM_BYTES, s, g);
+  return vqf_last_error();
+}
+
+}  // namespace
+
+extern "C" int vqf_gemm_f32(int ta, int tb, int M, int N, int K, const float* A, int lda,
+                            const float* B, int ldb, float* C, int ldc, const float* bias,
+                            int flags, void* ws, size_t ws_bytes, void* stream) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || lda <= 0 || ldb <= 0 || ldc < N)
+    return VQF_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  GemmArgs g;
+  g.A = A; g.B = B; g.C = C; g.bias = bias; g.slab = nullptr;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.flags = flags;
+  g.sA = g.sB = g.sC = 0;
+  g.tiles_m = (M + BM - 1) / BM;
+  g.tiles_n = (N + BN - 1) / BN;
+  g.vecA = aligned16(A) && (lda % 4 == 0);
+  g.vecB = aligned16(B) && (ldb % 4 == 0);
+
+  // split-K: only when the output has too few tiles to fill 256 CUs x 2 and K is deep
+  const long long tiles = (long long)g.tiles_m * g.tiles_n;
+  const int ktiles = (K + BK - 1) / BK;
+  int splits = 1;
+  if (ws && tiles < 1024 && ktiles >= 16) {
+    double best = 1e30;
+    const int slots = 512;
+    for (int sp = 1; sp <= 16; ++sp) {
+      if (ktiles / sp < 8) break;
+      if ((size_t)sp * M * N * sizeof(float) > ws_bytes) break;
+      const double blocks = (double)tiles * sp;
+      const double rounds = (double)((long long)((blocks + slots - 1) / slots));
+      // time ~ rounds * (per-block work ~ 1/sp) ; small penalty per split for the reduce pass
+      const double cost = rounds / sp * (1.0 + 0.01 * sp);
+      if (cost < best - 1e-12) { best = cost; splits = sp; }
+    }
+  }
+  int kt_per = (ktiles + splits - 1) / splits;
+  g.kchunk = kt_per * BK;
+  splits = (K + g.kchunk - 1) / g.kchunk;
+  if (splits > 1) g.slab = (float*)ws;
+
+  dim3 grid((unsigned)tiles, (unsigned)splits);
+  const int kid = KID_GEMM_A0B0 + 2 * (ta ? 1 : 0) + (tb ? 1 : 0);
+  int rc;
+  if (!ta && !tb) rc = launch_gemm<false, false>(g, grid, s, kid);
+  else if (!ta && tb) rc = launch_gemm<false, true>(g, grid, s, kid);
+  else if (ta && !tb) rc = launch_gemm<true, false>(g, grid, s, kid);
+  else rc = launch_gemm<true, true>(g, grid, s, kid);
+  if (rc != VQF_OK) return rc;
+  if (splits > 1) {
+    const long long total = (long long)M * N;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    VQF_LAUNCH(KID_SPLITK_REDUCE, splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s,
+               (const float*)ws, splits, M, N, C, ldc, bias, flags);
+    rc = vqf_last_error();
+  }
+  return rc;
+}
+
+// Batched form (grid.z = batch, no bias, no split-K): the per-sample products of
+// hieCoAtten.py:32,38,41,45,48 (affinity, attention-weighted sums).
+extern "C" int vqf_gemm_f32_batched(int ta, int tb, int batch, int M, int N, int K, const float* A,
+                                    int lda, long long strideA, const float* B, int ldb,
+                                    long long strideB, float* C, int ldc, long long strideC,
+                                    int flags, void* stream) {
+  if (!A || !B || !C || batch <= 0 || batch > 65535 || M <= 0 || N <= 0 || K <= 0 || lda <= 0 ||
+      ldb <= 0 || ldc < N)
+    return VQF_E_BADARG;
+  GemmArgs g;
+  g.A = A; g.B = B; g.C = C; g.bias = nullptr; g.slab = nullptr;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.flags = flags;
+  g.sA = strideA; g.sB = strideB; g.sC = strideC;
+  g.tiles_m = (M + BM - 1) / BM;
+  g.tiles_n = (N + BN - 1) / BN;
+  g.vecA = aligned16(A) && (lda % 4 == 0) && (strideA % 4 == 0);
+  g.vecB = aligned16(B) && (ldb % 4 == 0) && (strideB % 4 == 0);
+  g.kchunk = ((K + BK - 1) / BK) * BK;
+  dim3 grid((unsigned)(g.tiles_m * g.tiles_n), 1, (unsigned)batch);
+  hipStream_t s = (hipStream_t)stream;
+  const int kid = KID_GEMM_A0B0 + 2 * (ta ? 1 : 0) + (tb ? 1 : 0);
+  if (!ta && !tb) return launch_gemm<false, false>(g, grid, s, kid);
+  if (!ta && tb) return launch_gemm<false, true>(g, grid, s, kid);
+  if (ta && !tb) return launch_gemm<true, false>(g, grid, s, kid);
+  return launch_gemm<true, true>(g, grid, s, kid);
+}

@@ -1,0 +1,73 @@
+// Opt-in hipEvent profiler + ABI/version entry points.
+#include "common.h"
+#include <mutex>
+#include <vector>
+
+int g_vqf_prof_on = 0;
+
+namespace {
+struct Pair { hipEvent_t a, b; int id; };
+std::mutex g_mu;
+std::vector<Pair> g_pairs;
+std::vector<hipEvent_t> g_free;
+thread_local hipEvent_t t_start = nullptr;
+
+const char* const kNames[KID_COUNT] = {
+    "gemm_f32_a0b0(fwd)", "gemm_f32_a0b1(dgrad)", "gemm_f32_a1b0", "gemm_f32_a1b1(wgrad)",
+    "splitk_reduce", "colsum", "group_reduce", "relu_bwd",
+    "att_logits_fwd", "att_logits_bwd", "glimpse_pool_fwd", "glimpse_pool_bwd",
+    "mfb_fuse_fwd", "l2_group_norm", "scale_rows", "rowdot", "l2_norm_bwd_coef", "mfb_fuse_bwd"};
+
+hipEvent_t get_event() {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_free.empty()) { hipEvent_t e = g_free.back(); g_free.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+}  // namespace
+
+void vqf_prof_begin(int, hipStream_t s) {
+  t_start = get_event();
+  (void)hipEventRecord(t_start, s);
+}
+void vqf_prof_end(int id, hipStream_t s) {
+  hipEvent_t b = get_event();
+  (void)hipEventRecord(b, s);
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_pairs.push_back({t_start, b, id});
+}
+
+extern "C" {
+int vqf_abi_version(void) { return 1; }
+const char* vqf_build_info(void) {
+  return "libvqa_fusion gfx950 fp32-mfma(v_mfma_f32_32x32x2_f32) tile128x128x32 wave64 philox4x32-10";
+}
+void vqf_prof_enable(int on) { g_vqf_prof_on = on ? 1 : 0; }
+void vqf_prof_reset(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (auto& p : g_pairs) { g_free.push_back(p.a); g_free.push_back(p.b); }
+  g_pairs.clear();
+}
+int vqf_prof_num_kernels(void) { return KID_COUNT; }
+const char* vqf_prof_kernel_name(int id) { return (id >= 0 && id < KID_COUNT) ? kNames[id] : ""; }
+int vqf_prof_get(int id, long long* launches, double* total_ms) {
+  if (id < 0 || id >= KID_COUNT || !launches || !total_ms) return VQF_E_BADARG;
+  std::lock_guard<std::mutex> lk(g_mu);
+  long long n = 0;
+  double ms = 0.0;
+  for (auto& p : g_pairs) {
+    if (p.id != id) continue;
+    hipError_t e = hipEventSynchronize(p.b);
+    if (e != hipSuccess) return (int)e;
+    float t = 0.f;
+    e = hipEventElapsedTime(&t, p.a, p.b);
+    if (e != hipSuccess) return (int)e;
+    ms += t;
+    ++n;
+  }
+  *launches = n;
+  *total_ms = ms;
+  return VQF_OK;
+}
+}

@@ -1,0 +1,197 @@
+// Small HBM-bound helpers: column sums (bias gradients), slab reducers, ReLU
+// backward, row scaling, row dot products and the F.normalize coefficients.
+#include "common.h"
+
+namespace {
+
+constexpr int CS_ROWS = 256;   // rows folded by one colsum block
+
+// partial[b, c] = sum over rows [b*CS_ROWS, ...) of in[r, c];  thread = column
+__global__ void colsum_partial_kernel(const float* __restrict__ in, int M, int N, int ld,
+                                      float* __restrict__ partial) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= N) return;
+  const int r0 = blockIdx.y * CS_ROWS, r1 = min(M, r0 + CS_ROWS);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int r = r0;
+  for (; r + 3 < r1; r += 4) {
+    a0 += in[(long long)r * ld + c];
+    a1 += in[(long long)(r + 1) * ld + c];
+    a2 += in[(long long)(r + 2) * ld + c];
+    a3 += in[(long long)(r + 3) * ld + c];
+  }
+  for (; r < r1; ++r) a0 += in[(long long)r * ld + c];
+  partial[(long long)blockIdx.y * N + c] = (a0 + a1) + (a2 + a3);
+}
+
+// out[g, c] = sum_{j<J} in[(g*J + j), c]
+__global__ void group_reduce_kernel(const float* __restrict__ in, int G, int J, int W,
+                                    float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int g = blockIdx.y;
+  if (c >= W) return;
+  const float* p = in + (long long)g * J * W + c;
+  float a0 = 0.f, a1 = 0.f;
+  int j = 0;
+  for (; j + 1 < J; j += 2) { a0 += p[(long long)j * W]; a1 += p[(long long)(j + 1) * W]; }
+  if (j < J) a0 += p[(long long)j * W];
+  out[(long long)g * W + c] = a0 + a1;
+}
+
+__global__ void relu_bwd_kernel(const float* __restrict__ dX, const float* __restrict__ Y,
+                                long long n, float* __restrict__ dXpre) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    dXpre[i] = Y[i] > 0.f ? dX[i] : 0.f;
+}
+
+// one wave per row: Y[m,:] = R[m,:] * inv[m / L]
+__global__ void scale_rows_kernel(const float* __restrict__ R, const float* __restrict__ inv,
+                                  int M, int L, int W, float* __restrict__ Y) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int lane = threadIdx.x & 63;
+  const float s = inv[row / L];
+  const float* r = R + (long long)row * W;
+  float* y = Y + (long long)row * W;
+  if ((W & 3) == 0 && aligned16_dev(r) && aligned16_dev(y)) {
+    for (int c = lane * 4; c < W; c += 256) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(r + c);
+      v *= s;
+      *reinterpret_cast<f32x4*>(y + c) = v;
+    }
+  } else {
+    for (int c = lane; c < W; c += 64) y[c] = r[c] * s;
+  }
+}
+
+__global__ void rowdot_kernel(const float* __restrict__ Y, const float* __restrict__ dY, int M,
+                              int W, float* __restrict__ out) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int lane = threadIdx.x & 63;
+  const float* a = Y + (long long)row * W;
+  const float* b = dY + (long long)row * W;
+  float acc = 0.f;
+  if ((W & 3) == 0 && aligned16_dev(a) && aligned16_dev(b)) {
+    for (int c = lane * 4; c < W; c += 256) {
+      const f32x4 x = *reinterpret_cast<const f32x4*>(a + c);
+      const f32x4 y = *reinterpret_cast<const f32x4*>(b + c);
+      acc += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
+    }
+  } else {
+    for (int c = lane; c < W; c += 64) acc += a[c] * b[c];
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) out[row] = acc;
+}
+
+// one wave per sample
+__global__ void l2_group_norm_kernel(const float* __restrict__ rowssq, int N, int L,
+                                     float* __restrict__ norm, float* __restrict__ inv) {
+  const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const int lane = threadIdx.x & 63;
+  float a = 0.f;
+  for (int l = lane; l < L; l += 64) a += rowssq[(long long)n * L + l];
+  a = wave_sum(a);
+  if (lane == 0) {
+    const float nr = sqrtf(a);
+    norm[n] = nr;
+    inv[n] = 1.0f / fmaxf(nr, 1e-12f);      // F.normalize eps (mfb.py:105,135)
+  }
+}
+
+__global__ void l2_norm_bwd_coef_kernel(const float* __restrict__ rowdot,
+                                        const float* __restrict__ norm,
+                                        const float* __restrict__ inv, int N, int L,
+                                        float* __restrict__ coefA, float* __restrict__ coefB) {
+  const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const int lane = threadIdx.x & 63;
+  float a = 0.f;
+  for (int l = lane; l < L; l += 64) a += rowdot[(long long)n * L + l];
+  a = wave_sum(a);
+  if (lane == 0) {
+    coefA[n] = inv[n];
+    coefB[n] = norm[n] > 1e-12f ? inv[n] * a : 0.f;   // clamp_min branch has no projection term
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t vqf_colsum_ws_bytes(int M, int N) {
+  if (M <= 0 || N <= 0) return 0;
+  return (size_t)((M + CS_ROWS - 1) / CS_ROWS) * (size_t)N * sizeof(float);
+}
+
+int vqf_colsum_f32(const float* dY, int M, int N, int ldy, float* db, void* ws, size_t ws_bytes,
+                   void* stream) {
+  if (!dY || !db || M <= 0 || N <= 0 || ldy < N) return VQF_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int nb = (M + CS_ROWS - 1) / CS_ROWS;
+  dim3 grid((N + 255) / 256, nb);
+  if (nb == 1) {
+    VQF_LAUNCH(KID_COLSUM, colsum_partial_kernel, grid, dim3(256), 0, s, dY, M, N, ldy, db);
+    return vqf_last_error();
+  }
+  if (!ws || ws_bytes < vqf_colsum_ws_bytes(M, N)) return VQF_E_WORKSPACE;
+  VQF_LAUNCH(KID_COLSUM, colsum_partial_kernel, grid, dim3(256), 0, s, dY, M, N, ldy, (float*)ws);
+  int rc = vqf_last_error();
+  if (rc) return rc;
+  return vqf_group_reduce_f32((const float*)ws, 1, nb, N, db, stream);
+}
+
+int vqf_group_reduce_f32(const float* in, int G, int J, int W, float* out, void* stream) {
+  if (!in || !out || G <= 0 || J <= 0 || W <= 0) return VQF_E_BADARG;
+  dim3 grid((W + 255) / 256, G);
+  VQF_LAUNCH(KID_GROUP_REDUCE, group_reduce_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, G,
+             J, W, out);
+  return vqf_last_error();
+}
+
+int vqf_relu_bwd_f32(const float* dX, const float* Y, int M, int C, float* dXpre, float* dbias,
+                     void* ws, size_t ws_bytes, void* stream) {
+  if (!dX || !Y || !dXpre || M <= 0 || C <= 0) return VQF_E_BADARG;
+  const long long n = (long long)M * C;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  VQF_LAUNCH(KID_RELU_BWD, relu_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dX, Y,
+             n, dXpre);
+  int rc = vqf_last_error();
+  if (rc || !dbias) return rc;
+  return vqf_colsum_f32(dXpre, M, C, C, dbias, ws, ws_bytes, stream);
+}
+
+int vqf_scale_rows(const float* R, const float* inv, int M, int L, int W, float* Y, void* stream) {
+  if (!R || !inv || !Y || M <= 0 || L <= 0 || W <= 0) return VQF_E_BADARG;
+  VQF_LAUNCH(KID_SCALE_ROWS, scale_rows_kernel, dim3((M + 3) / 4), dim3(256), 0,
+             (hipStream_t)stream, R, inv, M, L, W, Y);
+  return vqf_last_error();
+}
+
+int vqf_rowdot(const float* Y, const float* dY, int M, int W, float* rowdot, void* stream) {
+  if (!Y || !dY || !rowdot || M <= 0 || W <= 0) return VQF_E_BADARG;
+  VQF_LAUNCH(KID_ROWDOT, rowdot_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, Y,
+             dY, M, W, rowdot);
+  return vqf_last_error();
+}
+
+int vqf_l2_group_norm(const float* rowssq, int N, int L, float* norm, float* inv, void* stream) {
+  if (!rowssq || !norm || !inv || N <= 0 || L <= 0) return VQF_E_BADARG;
+  VQF_LAUNCH(KID_L2_GROUP_NORM, l2_group_norm_kernel, dim3((N + 3) / 4), dim3(256), 0,
+             (hipStream_t)stream, rowssq, N, L, norm, inv);
+  return vqf_last_error();
+}
+
+int vqf_l2_norm_bwd_coef(const float* rowdot, const float* norm, const float* inv, int N, int L,
+                         float* coefA, float* coefB, void* stream) {
+  if (!rowdot || !norm || !inv || !coefA || !coefB || N <= 0 || L <= 0) return VQF_E_BADARG;
+  VQF_LAUNCH(KID_L2_BWD_COEF, l2_norm_bwd_coef_kernel, dim3((N + 3) / 4), dim3(256), 0,
+             (hipStream_t)stream, rowdot, norm, inv, N, L, coefA, coefB);
+  return vqf_last_error();
+}
+
+}  // extern "C"

@@ -1,0 +1,169 @@
+"""torch.autograd.Function per fused stage of the hot path.
+
+Each Function's forward/backward is a short sequence of C-ABI launches on the
+current HIP stream; no torch arithmetic op touches the big tensors.
+
+  LinearFn     a4, a10      nn.Linear / 1x1 conv          (mfb.py:92,137 ...)
+  AttHeadFn    a3, a7+a8    attention MLP -> 2 logits -> softmax -> glimpse sums
+  ImgFuseFn    a5+a6        image projection + MFB fusion over the 196 regions
+  FinalMfbFn   a9           the (N,5000) x (N,5000) MFB block(s)
+"""
+import torch
+
+from . import ops
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _w2d(w):
+    """(out,in,1,1) conv weight or (out,in) linear weight -> contiguous (out,in) view."""
+    return _c(w.reshape(w.shape[0], -1))
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x @ W^T + b  (optionally relu).  x (M,K), W (N,K)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, relu=False):
+        x = _c(x)
+        w2 = _w2d(w)
+        y = ops.gemm(x, w2, bias=b, relu=relu)
+        ctx.save_for_backward(x, w, y if relu else None)
+        ctx.has_bias = b is not None
+        ctx.relu = relu
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        w2 = _w2d(w)
+        dy = _c(dy)
+        db = None
+        if ctx.relu:
+            dy, db = ops.relu_bwd(dy, y, want_bias=ctx.has_bias)
+        elif ctx.has_bias and ctx.needs_input_grad[2]:
+            db = ops.colsum(dy)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.gemm(dy, w2, tb=True)                       # dX = dY W      (M,K)
+        if ctx.needs_input_grad[1]:
+            dw = ops.gemm(dy, x, ta=True, tb=True).view_as(w)    # dW = dY^T X    (N,K)
+        return dx, dw, db, None
+
+
+class AttHeadFn(torch.autograd.Function):
+    """Attention MLP + glimpse pooling.
+
+    x    (N*S, Cin)  MLP input  (question side: the LSTM states; image side: fusion_normed)
+    feat (N, S, C)   what the glimpses pool (LSTM states / the image tensor)
+    w1,b1 [wm,bm] w2,b2: conv1 (+ "multilayer" conv) + conv2 -> 2 logits
+    unit_softmax: reproduce mfb.py:84,118 (softmax over the singleton axis == 1)
+    returns pooled (N, 2C); the attention weights (N,2,S) are kept on ctx.
+    """
+
+    @staticmethod
+    def forward(ctx, x, feat, w1, b1, wm, bm, w2, b2, unit_softmax):
+        x = _c(x)
+        feat = _c(feat)
+        hid1 = ops.gemm(x, _w2d(w1), bias=b1, relu=True)
+        hid2 = ops.gemm(hid1, _w2d(wm), bias=bm, relu=True) if wm is not None else None
+        last = hid2 if hid2 is not None else hid1
+        logits = ops.att_logits_fwd(last, _w2d(w2), b2)
+        wts, pooled = ops.glimpse_pool_fwd(feat, logits, unit_softmax)
+        ctx.save_for_backward(x, feat, w1, wm, w2, hid1, hid2, wts)
+        ctx.unit = bool(unit_softmax)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        x, feat, w1, wm, w2, hid1, hid2, wts = ctx.saved_tensors
+        dpooled = _c(dpooled)
+        need_dfeat = ctx.needs_input_grad[1]
+        dlogits, dfeat = ops.glimpse_pool_bwd(dpooled, feat, wts, ctx.unit, need_dfeat)
+        last = hid2 if hid2 is not None else hid1
+        dlast_pre, dw2, db2, dblast = ops.att_logits_bwd(dlogits, last, _w2d(w2))
+        dwm = dbm = None
+        if hid2 is not None:
+            dwm = ops.gemm(dlast_pre, hid1, ta=True, tb=True).view_as(wm)
+            dbm = dblast
+            dhid1 = ops.gemm(dlast_pre, _w2d(wm), tb=True)
+            d1_pre, db1 = ops.relu_bwd(dhid1, hid1, want_bias=True)
+        else:
+            d1_pre, db1 = dlast_pre, dblast
+        dw1 = ops.gemm(d1_pre, x, ta=True, tb=True).view_as(w1)
+        dx = ops.gemm(d1_pre, _w2d(w1), tb=True) if ctx.needs_input_grad[0] else None
+        return dx, dfeat, dw1, db1, dwm, dbm, dw2.view_as(w2), db2, None
+
+
+class ImgFuseFn(torch.autograd.Function):
+    """a5+a6: P = img W^T + b;  Y = L2norm_n(ssqrt(pool5(dropout(P * q[n])))).
+
+    img (N,L,D) data (no gradient), wi (5000,D[,1,1]), bi (5000), q (N,5000)
+    -> Y (N*L, 1000), row m = n*L + l   (the reference's fusion_normed is the
+    (N,1000,L,1) permutation of the same values, mfb.py:103-106).
+    """
+
+    @staticmethod
+    def forward(ctx, img, wi, bi, q, keep, seed, p_drop):
+        img = _c(img)
+        q = _c(q)
+        N, L, D = img.shape
+        wi2 = _w2d(wi)
+        O = wi2.shape[0] // ops.POOL_K
+        P = ops.gemm(img.view(N * L, D), wi2, bias=bi)
+        Y, norm, inv, _ = ops.mfb_fuse_fwd(P, q, N, L, O, keep=keep, seed=seed, p_drop=p_drop)
+        ctx.save_for_backward(img, wi, q, P, Y, norm, inv, keep)
+        ctx.seed, ctx.p_drop, ctx.dims = seed, p_drop, (N, L, D, O)
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        img, wi, q, P, Y, norm, inv, keep = ctx.saved_tensors
+        N, L, D, O = ctx.dims
+        dP, dq, _, dbi = ops.mfb_fuse_bwd(_c(dY), Y, norm, inv, P, q, N, L, O, keep=keep, seed=ctx.seed,
+                                          p_drop=ctx.p_drop, want_dbias=True)
+        dwi = ops.gemm(dP, img.view(N * L, D), ta=True, tb=True).view_as(wi)   # wgrad, K = N*L
+        return None, dwi, dbi, dq, None, None, None
+
+
+class FinalMfbFn(torch.autograd.Function):
+    """a9: y = L2norm_row(ssqrt(pool5(dropout((qa Wq^T + bq) * (va Wv^T + bv))))), (N,1000).
+
+    cascade (N,5000) optional third factor and want_zdrop: MHB's high-order block
+    (mhb_coAtt.py:201-211) reuses this stage.
+    """
+
+    @staticmethod
+    def forward(ctx, qa, va, wq, bq, wv, bv, keep, seed, p_drop, cascade=None, want_zdrop=False):
+        qa, va = _c(qa), _c(va)
+        N = qa.shape[0]
+        O = wq.shape[0] // ops.POOL_K
+        qq = ops.gemm(qa, _w2d(wq), bias=bq)
+        vv = ops.gemm(va, _w2d(wv), bias=bv)
+        if cascade is not None:
+            cascade = _c(cascade)
+        y, norm, inv, zdrop = ops.mfb_fuse_fwd(vv, qq, N, 1, O, keep=keep, seed=seed, p_drop=p_drop,
+                                               cascade=cascade, want_zdrop=want_zdrop)
+        ctx.save_for_backward(qa, va, wq, wv, qq, vv, y, norm, inv, keep, cascade)
+        ctx.seed, ctx.p_drop, ctx.dims = seed, p_drop, (N, O)
+        if want_zdrop:
+            return y, zdrop
+        return y
+
+    @staticmethod
+    def backward(ctx, dy, dz=None):
+        qa, va, wq, wv, qq, vv, y, norm, inv, keep, cascade = ctx.saved_tensors
+        N, O = ctx.dims
+        dvv, dqq, dcasc, _ = ops.mfb_fuse_bwd(_c(dy), y, norm, inv, vv, qq, N, 1, O, keep=keep,
+                                              seed=ctx.seed, p_drop=ctx.p_drop, cascade=cascade,
+                                              dzdrop=None if dz is None else _c(dz))
+        wq2, wv2 = _w2d(wq), _w2d(wv)
+        dqa = ops.gemm(dqq, wq2, tb=True) if ctx.needs_input_grad[0] else None
+        dva = ops.gemm(dvv, wv2, tb=True) if ctx.needs_input_grad[1] else None
+        dwq = ops.gemm(dqq, qa, ta=True, tb=True).view_as(wq)
+        dwv = ops.gemm(dvv, va, ta=True, tb=True).view_as(wv)
+        dbq = ops.colsum(dqq)
+        dbv = ops.colsum(dvv)
+        return dqa, dva, dwq, dbq, dwv, dbv, None, None, None, dcasc, None

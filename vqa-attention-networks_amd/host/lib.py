@@ -1,0 +1,114 @@
+"""ctypes binding of libvqa_fusion.so (C ABI declared in include/vqa_fusion.h).
+
+The product path has NO CPU fallback: if the shared library is missing or an
+op is handed a non-GPU tensor, it raises.  `build()` compiles the library
+in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+"""
+import ctypes
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PKG_DIR = os.path.dirname(_HERE)
+CSRC_DIR = os.path.join(PKG_DIR, "csrc")
+LIB_PATH = os.path.join(PKG_DIR, "libvqa_fusion.so")
+HEADER_PATH = os.path.join(os.path.dirname(PKG_DIR), "include", "vqa_fusion.h")
+
+_lock = threading.Lock()
+_lib = None
+
+c_f = ctypes.c_void_p          # device float* (raw pointer)
+c_i = ctypes.c_int
+c_sz = ctypes.c_size_t
+c_u64 = ctypes.c_uint64
+c_p = ctypes.c_void_p
+
+# name -> (restype, argtypes); must list every symbol of include/vqa_fusion.h
+SIGNATURES = {
+    "vqf_abi_version": (c_i, []),
+    "vqf_build_info": (ctypes.c_char_p, []),
+    "vqf_gemm_f32": (c_i, [c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_i, c_f, c_i, c_f, c_i, c_p, c_sz, c_p]),
+    "vqf_gemm_f32_batched": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, ctypes.c_longlong,
+                                   c_f, c_i, ctypes.c_longlong, c_f, c_i, ctypes.c_longlong, c_i, c_p]),
+    "vqf_colsum_ws_bytes": (c_sz, [c_i, c_i]),
+    "vqf_colsum_f32": (c_i, [c_f, c_i, c_i, c_i, c_f, c_p, c_sz, c_p]),
+    "vqf_group_reduce_f32": (c_i, [c_f, c_i, c_i, c_i, c_f, c_p]),
+    "vqf_relu_bwd_f32": (c_i, [c_f, c_f, c_i, c_i, c_f, c_f, c_p, c_sz, c_p]),
+    "vqf_att_logits_fwd": (c_i, [c_f, c_f, c_f, c_i, c_i, c_f, c_p]),
+    "vqf_att_logits_bwd_ws_bytes": (c_sz, [c_i, c_i]),
+    "vqf_att_logits_bwd": (c_i, [c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_f, c_f, c_p, c_sz, c_p]),
+    "vqf_glimpse_pool_fwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_p]),
+    "vqf_glimpse_pool_bwd": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_p]),
+    "vqf_mfb_fuse_fwd": (c_i, [c_f, c_f, c_f, c_p, c_u64, ctypes.c_float, c_i, c_i, c_i, c_f, c_f, c_f, c_p]),
+    "vqf_l2_group_norm": (c_i, [c_f, c_i, c_i, c_f, c_f, c_p]),
+    "vqf_scale_rows": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f, c_p]),
+    "vqf_rowdot": (c_i, [c_f, c_f, c_i, c_i, c_f, c_p]),
+    "vqf_l2_norm_bwd_coef": (c_i, [c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_p]),
+    "vqf_mfb_fuse_bwd_ws_bytes": (c_sz, [c_i, c_i, c_i]),
+    "vqf_mfb_fuse_bwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_u64, ctypes.c_float,
+                               c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_p, c_sz, c_p]),
+    "vqf_prof_enable": (None, [c_i]),
+    "vqf_prof_reset": (None, []),
+    "vqf_prof_num_kernels": (c_i, []),
+    "vqf_prof_kernel_name": (ctypes.c_char_p, [c_i]),
+    "vqf_prof_get": (c_i, [c_i, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_double)]),
+}
+
+_ERR = {-1: "VQF_E_BADARG", -2: "VQF_E_ALIGN", -3: "VQF_E_UNSUPPORTED", -4: "VQF_E_WORKSPACE"}
+
+
+class VqfError(RuntimeError):
+    pass
+
+
+def build(force=False, verbose=False):
+    """Compile csrc/*.hip into libvqa_fusion.so for gfx950 (make -C csrc)."""
+    srcs = [os.path.join(CSRC_DIR, f) for f in os.listdir(CSRC_DIR) if f.endswith((".hip", ".h"))]
+    srcs.append(HEADER_PATH)
+    stale = force or not os.path.exists(LIB_PATH) or any(
+        os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if not stale:
+        return LIB_PATH
+    cmd = ["make", "-C", CSRC_DIR, "-j", str(min(8, os.cpu_count() or 1))]
+    if force:
+        subprocess.run(["make", "-C", CSRC_DIR, "clean"], check=True, capture_output=not verbose)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or r.returncode:
+        print(r.stdout)
+        print(r.stderr)
+    if r.returncode:
+        raise VqfError("hipcc build of libvqa_fusion.so failed (see output above)")
+    return LIB_PATH
+
+
+def load():
+    """Return the loaded library; raise loudly if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise VqfError(
+                "libvqa_fusion.so is missing (%s).  The HIP extension is the product path and "
+                "there is no CPU fallback: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C %s`." % (LIB_PATH, CSRC_DIR))
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)        # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        if lib.vqf_abi_version() != 1:
+            raise VqfError("libvqa_fusion.so ABI version mismatch")
+        _lib = lib
+        return _lib
+
+
+def check(rc, what):
+    if rc == 0:
+        return
+    if rc < 0:
+        raise VqfError("%s: %s" % (what, _ERR.get(rc, "error %d" % rc)))
+    raise VqfError("%s: HIP error %d" % (what, rc))

@@ -1,0 +1,101 @@
+"""MFB-baseline model on the HIP fusion path.
+
+Mirrors the reference interface (mfb.py:6-140): `MFB(cfg)`,
+`forward(img_features, questions, is_training=True) -> logits (N, a_vocab_size)`,
+identical state_dict keys/shapes, so it drops into solver.py / train_models.py.
+The question encoder (embedding, tanh, LSTM, dropout_l; mfb.py:68-70) stays on
+PyTorch-ROCm (MIOpen); everything from the question attention to the logits
+runs in libvqa_fusion.so.
+"""
+import torch
+import torch.nn as nn
+
+from .functions import LinearFn, AttHeadFn, ImgFuseFn, FinalMfbFn
+
+
+class _DropSeeds:
+    """Per-call dropout seeds for the in-kernel Philox masks (train mode)."""
+
+    def __init__(self):
+        self.keep = {}      # optional externally supplied uint8 keep-masks (parity tests)
+
+    def next(self, training, p):
+        if not training or p <= 0.0:
+            return 0, 0.0
+        # one 63-bit seed per call from torch's CPU generator: reproducible under manual_seed
+        return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item()), p
+
+
+class MFB(nn.Module):
+    def __init__(self, cfg):
+        super(MFB, self).__init__()
+        self.cfg = cfg
+        self.word_embedding = nn.Embedding(cfg.q_vocab_size, cfg.emb_dim)
+        self.lstm = nn.LSTM(input_size=cfg.emb_dim, hidden_size=cfg.hidden_dim,
+                            num_layers=cfg.num_layers, batch_first=True)
+        self.dropout_l = nn.Dropout(p=0.3)
+        self.multilayer = cfg.model_name == 'mfb-multilayer'
+        self.ques_att_conv1 = nn.Conv2d(cfg.hidden_dim, 1024, [1, 1])
+        if self.multilayer:
+            self.ques_att_multiconv = nn.Conv2d(1024, 512, [1, 1])
+            self.ques_att_conv2 = nn.Conv2d(512, 2, [1, 1])
+        else:
+            self.ques_att_conv2 = nn.Conv2d(1024, 2, [1, 1])
+        self.ques_proj1 = nn.Linear(2 * cfg.hidden_dim, 5000)
+        self.img_conv1d = nn.Conv2d(cfg.img_feature_channel, 5000, [1, 1])
+        self.dropout_m = nn.Dropout(p=0.1)      # kept for module-tree parity; masks are in-kernel
+        self.co_att_conv1 = nn.Conv2d(1000, 1024, [1, 1])
+        if self.multilayer:
+            self.co_att_multiconv = nn.Conv2d(1024, 512, [1, 1])
+            self.co_att_conv2 = nn.Conv2d(512, 2, [1, 1])
+        else:
+            self.co_att_conv2 = nn.Conv2d(1024, 2, [1, 1])
+        self.ques_proj2 = nn.Linear(2 * cfg.hidden_dim, 5000)
+        self.img_proj2 = nn.Linear(2 * cfg.img_feature_channel, 5000)
+        self.linear_pred = nn.Linear(1000, cfg.a_vocab_size)
+        # reference_compat: mfb.py:84,118 run both softmaxes over a singleton axis (weights == 1)
+        self.unit_softmax = True
+        self._seeds = _DropSeeds()
+
+    # -- helpers -----------------------------------------------------------
+    def _mc(self, name):
+        m = getattr(self, name, None) if self.multilayer else None
+        return (m.weight, m.bias) if m is not None else (None, None)
+
+    def set_keep_masks(self, **masks):
+        """Test hook: explicit uint8 keep-masks 'm1' (N*L,5000), 'm2' (N,5000) instead of Philox."""
+        self._seeds.keep = masks
+
+    def forward(self, img_features, questions, is_training=True):
+        # a2: question encoder (PyTorch-ROCm)                                mfb.py:68-70
+        que_embedded = torch.tanh(self.word_embedding(questions))
+        lstm_o, _ = self.lstm(que_embedded)
+        ques_feature = self.dropout_l(lstm_o).contiguous()                 # (N,T,H)
+        N, T, H = ques_feature.shape
+        L = img_features.shape[1]
+        keep = self._seeds.keep
+
+        # a3: question attention                                             mfb.py:73-89
+        wm, bm = self._mc('ques_att_multiconv')
+        qa = AttHeadFn.apply(ques_feature.view(N * T, H), ques_feature,
+                             self.ques_att_conv1.weight, self.ques_att_conv1.bias, wm, bm,
+                             self.ques_att_conv2.weight, self.ques_att_conv2.bias, self.unit_softmax)
+        # a4: ques_proj1                                                     mfb.py:92-93
+        qp = LinearFn.apply(qa, self.ques_proj1.weight, self.ques_proj1.bias)
+        # a5+a6: image projection + MFB fusion over the regions             mfb.py:95-106
+        seed, p = self._seeds.next(self.training, 0.1)
+        k1 = keep.get('m1')
+        Y = ImgFuseFn.apply(img_features, self.img_conv1d.weight, self.img_conv1d.bias, qp,
+                            k1, seed, 0.1 if k1 is not None else p)
+        # a7+a8: co-attention over the regions                               mfb.py:109-123
+        wm, bm = self._mc('co_att_multiconv')
+        va = AttHeadFn.apply(Y, img_features, self.co_att_conv1.weight, self.co_att_conv1.bias, wm, bm,
+                             self.co_att_conv2.weight, self.co_att_conv2.bias, self.unit_softmax)
+        # a9: final MFB block                                                mfb.py:126-135
+        seed, p = self._seeds.next(self.training, 0.1)
+        k2 = keep.get('m2')
+        y = FinalMfbFn.apply(qa, va, self.ques_proj2.weight, self.ques_proj2.bias,
+                             self.img_proj2.weight, self.img_proj2.bias, k2, seed,
+                             0.1 if k2 is not None else p)
+        # a10: classifier; the reference computes a softmax and discards it  mfb.py:137-140
+        return LinearFn.apply(y, self.linear_pred.weight, self.linear_pred.bias)

@@ -1,0 +1,128 @@
+"""MHBCoAtt and MHB on the HIP fusion path (reference interface: mhb_coAtt.py).
+
+MHBCoAtt keeps the reference's behaviour, including the LSTM that is built
+with batch_first=True but fed (T,N,.) and therefore recurs over the minibatch
+axis (mhb_coAtt.py:27-36,72-74); set `fix_lstm_orientation=True` to opt out.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .functions import LinearFn, AttHeadFn, ImgFuseFn, FinalMfbFn
+from .mfb import _DropSeeds
+
+
+class MHBCoAtt(nn.Module):
+    def __init__(self, cfg):
+        super(MHBCoAtt, self).__init__()
+        self.cfg = cfg
+        self.word_embedding = nn.Embedding(cfg.q_vocab_size, cfg.emb_dim)
+        lstm_in = cfg.emb_dim * 2 if cfg.glove else cfg.emb_dim
+        self.lstm = nn.LSTM(input_size=lstm_in, hidden_size=cfg.hidden_dim,
+                            num_layers=cfg.num_layers, batch_first=True)
+        self.dropout_l = nn.Dropout(p=0.3)
+        self.ques_att_conv1 = nn.Conv2d(cfg.hidden_dim, 512, [1, 1])
+        self.ques_att_conv2 = nn.Conv2d(512, 2, [1, 1])
+        self.ques_proj1 = nn.Linear(2 * cfg.hidden_dim, 5000)
+        self.img_conv1d = nn.Conv2d(cfg.img_feature_channel, 5000, [1, 1])
+        self.dropout_m = nn.Dropout(p=0.1)
+        self.co_att_conv1 = nn.Conv2d(1000, 512, [1, 1])
+        self.co_att_conv2 = nn.Conv2d(512, 2, [1, 1])
+        self.ques_proj2 = nn.Linear(2 * cfg.hidden_dim, 5000)
+        self.ques_proj3 = nn.Linear(2 * cfg.hidden_dim, 5000)
+        self.img_proj2 = nn.Linear(2 * cfg.img_feature_channel, 5000)
+        self.img_proj3 = nn.Linear(2 * cfg.img_feature_channel, 5000)
+        self.linear_pred = nn.Linear(2000, cfg.a_vocab_size)
+        self.fix_lstm_orientation = False
+        self._seeds = _DropSeeds()
+
+    def set_keep_masks(self, **masks):
+        self._seeds.keep = masks
+
+    def forward(self, img_features, questions, glove_matrix=None, is_training=True):
+        N, L, D = img_features.shape
+        keep = self._seeds.keep
+        que_embedded = torch.tanh(self.word_embedding(questions))            # (N,T,E)
+        if self.cfg.glove:
+            assert glove_matrix is not None, 'glove should not be NoneType.'
+            que_embedded = torch.cat((que_embedded, glove_matrix), dim=2)
+        if self.fix_lstm_orientation:
+            lstm_o, _ = self.lstm(que_embedded)                              # (N,T,H)
+            ques_feature = self.dropout_l(lstm_o).contiguous()
+        else:
+            lstm_o, _ = self.lstm(que_embedded.permute(1, 0, 2))             # (T,N,H), recurs over N
+            ques_feature = self.dropout_l(lstm_o).permute(1, 0, 2).contiguous()   # (N,T,H)
+        T, H = ques_feature.shape[1], ques_feature.shape[2]
+
+        qa = AttHeadFn.apply(ques_feature.view(N * T, H), ques_feature,
+                             self.ques_att_conv1.weight, self.ques_att_conv1.bias, None, None,
+                             self.ques_att_conv2.weight, self.ques_att_conv2.bias, False)
+        qp = LinearFn.apply(qa, self.ques_proj1.weight, self.ques_proj1.bias)
+        seed, p = self._seeds.next(self.training, 0.1)
+        k1 = keep.get('m1')
+        Y = ImgFuseFn.apply(img_features, self.img_conv1d.weight, self.img_conv1d.bias, qp,
+                            k1, seed, 0.1 if k1 is not None else p)
+        va = AttHeadFn.apply(Y, img_features, self.co_att_conv1.weight, self.co_att_conv1.bias, None, None,
+                             self.co_att_conv2.weight, self.co_att_conv2.bias, False)
+        ys = []
+        for tag, qpj, ipj in (('m2', self.ques_proj2, self.img_proj2), ('m3', self.ques_proj3, self.img_proj3)):
+            seed, p = self._seeds.next(self.training, 0.1)
+            kk = keep.get(tag)
+            ys.append(FinalMfbFn.apply(qa, va, qpj.weight, qpj.bias, ipj.weight, ipj.bias, kk, seed,
+                                       0.1 if kk is not None else p))
+        att_normed_23 = torch.cat(ys, 1)                                     # (N,2000)  :147
+        logits = LinearFn.apply(att_normed_23, self.linear_pred.weight, self.linear_pred.bias)
+        return F.log_softmax(logits, dim=1)                                  # :149 (implicit dim=1)
+
+
+class MHB(nn.Module):
+    """Mean-pooled image x last valid LSTM state, two cascaded MFB blocks (mhb_coAtt.py:153-217).
+
+    The reference class cannot run as shipped (hard .cuda() at :176 is harmless
+    here, but :214 names an undefined `mhb_22`); this follows the evident
+    intent `mhb_12` (:213).
+    """
+
+    def __init__(self, cfg):
+        super(MHB, self).__init__()
+        self.model_name = cfg.model_name
+        self.cfg = cfg
+        self.mean_pool = nn.AvgPool2d((14, 14))
+        self.Embedding = nn.Embedding(cfg.q_vocab_size, cfg.emb_dim)
+        self.LSTM = nn.LSTM(input_size=cfg.emb_dim, hidden_size=cfg.hidden_dim, num_layers=1,
+                            batch_first=False)
+        self.linear_q_1 = nn.Linear(cfg.hidden_dim, 5000)
+        self.linear_q_2 = nn.Linear(cfg.hidden_dim, 5000)
+        self.linear_i_1 = nn.Linear(cfg.img_feature_channel, 5000)
+        self.linear_i_2 = nn.Linear(cfg.img_feature_channel, 5000)
+        self.lstm_dropout = nn.Dropout(0.3)
+        self.mfb_dropout = nn.Dropout(0.1)
+        self.linear_out = nn.Linear(2000, cfg.a_vocab_size)
+        self._seeds = _DropSeeds()
+
+    def set_keep_masks(self, **masks):
+        self._seeds.keep = masks
+
+    def forward(self, img_feature, questions, q_length):
+        batch_size, max_len = questions.size()
+        keep = self._seeds.keep
+        # AvgPool2d(14,14) over the (N,C,14,14) view == mean over the 196 regions   :178-180
+        i_mean = img_feature.reshape(batch_size, -1, self.cfg.img_feature_channel).mean(1)
+        q_embedded = self.Embedding(questions).permute(1, 0, 2)              # (T,N,E)  :181-182
+        lstm_outs, _ = self.LSTM(q_embedded)                                 # (T,N,H)
+        idx = (q_length.to(torch.long) - 1).to(lstm_outs.device)
+        lstm_out = lstm_outs[idx, torch.arange(batch_size, device=lstm_outs.device)]   # :185-186
+        lstm_out = self.lstm_dropout(lstm_out)
+        seed, p = self._seeds.next(self.training, 0.1)
+        k1 = keep.get('m1')
+        mhb_1, z1 = FinalMfbFn.apply(lstm_out, i_mean, self.linear_q_1.weight, self.linear_q_1.bias,
+                                     self.linear_i_1.weight, self.linear_i_1.bias, k1, seed,
+                                     0.1 if k1 is not None else p, None, True)      # :190-199
+        seed, p = self._seeds.next(self.training, 0.1)
+        k2 = keep.get('m2')
+        mhb_2 = FinalMfbFn.apply(lstm_out, i_mean, self.linear_q_2.weight, self.linear_q_2.bias,
+                                 self.linear_i_2.weight, self.linear_i_2.bias, k2, seed,
+                                 0.1 if k2 is not None else p, z1, False)            # :201-211
+        mhb_12 = torch.cat((mhb_1, mhb_2), 1)
+        logits = LinearFn.apply(mhb_12, self.linear_out.weight, self.linear_out.bias)
+        return F.log_softmax(logits, dim=1)

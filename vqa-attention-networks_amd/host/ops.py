@@ -1,0 +1,248 @@
+"""Tensor-level wrappers over the C ABI (raw device pointers + current stream).
+
+PyTorch is plumbing here: it owns device memory (caching allocator) and the
+HIP stream; all arithmetic happens in libvqa_fusion.so.  There is no CPU
+fallback -- a CPU tensor raises.
+"""
+import ctypes
+import torch
+
+from . import lib as _l
+
+GEMM_RELU = 1
+GEMM_ACCUM = 2
+POOL_K = 5
+
+
+def _lib():
+    return _l.load()
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _l.VqfError("vqa fusion ops need GPU tensors (HIP extension is the only path; "
+                              "no CPU fallback)")
+        if t.dtype != torch.float32:
+            raise _l.VqfError("fp32 tensor expected, got %s" % t.dtype)
+        if not t.is_contiguous():
+            raise _l.VqfError("contiguous tensor expected")
+
+
+class _Workspace:
+    """Grow-only scratch buffer per device (split-K slabs, partial sums)."""
+
+    def __init__(self):
+        self.bufs = {}
+
+    def get(self, device, nbytes):
+        nbytes = max(int(nbytes), 256)
+        b = self.bufs.get(device)
+        if b is None or b.numel() < nbytes:
+            b = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
+            self.bufs[device] = b
+        return b
+
+
+_ws = _Workspace()
+SPLITK_WS_BYTES = 192 << 20
+
+
+def workspace(device, nbytes):
+    return _ws.get(device, nbytes)
+
+
+# ---------------------------------------------------------------------------
+def gemm(a, b, ta=False, tb=False, bias=None, relu=False, out=None, accumulate=False,
+         M=None, N=None, K=None, splitk=True):
+    """C[M,N] = Aop @ Bop^T (+bias) ; a/b are 2-D contiguous.
+
+    ta=False: a is (M,K); ta=True: a is (K,M).   tb=False: b is (N,K); tb=True: b is (K,N).
+    """
+    _chk(a, b, bias, out)
+    if M is None:
+        M = a.shape[1] if ta else a.shape[0]
+    if K is None:
+        K = a.shape[0] if ta else a.shape[1]
+    if N is None:
+        N = b.shape[1] if tb else b.shape[0]
+    kb = b.shape[0] if tb else b.shape[1]
+    if kb != K:
+        raise _l.VqfError("gemm: inner dimensions differ (%d vs %d)" % (K, kb))
+    if out is None:
+        if accumulate:
+            raise _l.VqfError("gemm: accumulate needs out")
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    flags = (GEMM_RELU if relu else 0) | (GEMM_ACCUM if accumulate else 0)
+    ws = workspace(a.device, SPLITK_WS_BYTES) if splitk else None
+    rc = _lib().vqf_gemm_f32(int(ta), int(tb), M, N, K, _ptr(a), a.stride(0), _ptr(b), b.stride(0),
+                             _ptr(out), out.stride(0), _ptr(bias), flags,
+                             _ptr(ws), ws.numel() if ws is not None else 0, _stream())
+    _l.check(rc, "vqf_gemm_f32")
+    return out
+
+
+def bgemm(a, b, ta=False, tb=False, out=None, accumulate=False):
+    """Batched: a (B,M,K)|(B,K,M), b (B,N,K)|(B,K,N) -> (B,M,N)."""
+    _chk(a, b, out)
+    Bn = a.shape[0]
+    M = a.shape[2] if ta else a.shape[1]
+    K = a.shape[1] if ta else a.shape[2]
+    N = b.shape[2] if tb else b.shape[1]
+    kb = b.shape[1] if tb else b.shape[2]
+    if kb != K or b.shape[0] != Bn:
+        raise _l.VqfError("bgemm: shape mismatch")
+    if out is None:
+        out = torch.empty((Bn, M, N), dtype=torch.float32, device=a.device)
+    rc = _lib().vqf_gemm_f32_batched(int(ta), int(tb), Bn, M, N, K, _ptr(a), a.stride(1), a.stride(0),
+                                     _ptr(b), b.stride(1), b.stride(0), _ptr(out), out.stride(1),
+                                     out.stride(0), GEMM_ACCUM if accumulate else 0, _stream())
+    _l.check(rc, "vqf_gemm_f32_batched")
+    return out
+
+
+def colsum(x):
+    _chk(x)
+    M, N = x.shape
+    out = torch.empty(N, dtype=torch.float32, device=x.device)
+    need = _lib().vqf_colsum_ws_bytes(M, N)
+    ws = workspace(x.device, need)
+    _l.check(_lib().vqf_colsum_f32(_ptr(x), M, N, x.stride(0), _ptr(out), _ptr(ws), ws.numel(), _stream()),
+             "vqf_colsum_f32")
+    return out
+
+
+def relu_bwd(dx, y, want_bias=True):
+    _chk(dx, y)
+    M, C = y.shape
+    dpre = torch.empty_like(y)
+    db = torch.empty(C, dtype=torch.float32, device=y.device) if want_bias else None
+    ws = workspace(y.device, _lib().vqf_colsum_ws_bytes(M, C))
+    _l.check(_lib().vqf_relu_bwd_f32(_ptr(dx), _ptr(y), M, C, _ptr(dpre), _ptr(db), _ptr(ws), ws.numel(),
+                                     _stream()), "vqf_relu_bwd_f32")
+    return dpre, db
+
+
+def att_logits_fwd(hid, w2, b2):
+    _chk(hid, w2, b2)
+    M, Hh = hid.shape
+    out = torch.empty((M, 2), dtype=torch.float32, device=hid.device)
+    _l.check(_lib().vqf_att_logits_fwd(_ptr(hid), _ptr(w2), _ptr(b2), M, Hh, _ptr(out), _stream()),
+             "vqf_att_logits_fwd")
+    return out
+
+
+def att_logits_bwd(dlogits, hid, w2):
+    _chk(dlogits, hid, w2)
+    M, Hh = hid.shape
+    dpre = torch.empty_like(hid)
+    dw2 = torch.empty((2, Hh), dtype=torch.float32, device=hid.device)
+    db2 = torch.empty(2, dtype=torch.float32, device=hid.device)
+    db1 = torch.empty(Hh, dtype=torch.float32, device=hid.device)
+    ws = workspace(hid.device, _lib().vqf_att_logits_bwd_ws_bytes(M, Hh))
+    _l.check(_lib().vqf_att_logits_bwd(_ptr(dlogits), _ptr(hid), _ptr(w2), M, Hh, _ptr(dpre), _ptr(dw2),
+                                       _ptr(db2), _ptr(db1), _ptr(ws), ws.numel(), _stream()),
+             "vqf_att_logits_bwd")
+    return dpre, dw2, db2, db1
+
+
+def glimpse_pool_fwd(feat, logits, unit_softmax):
+    _chk(feat, logits)
+    N, S, C = feat.shape
+    wts = torch.empty((N, 2, S), dtype=torch.float32, device=feat.device)
+    pooled = torch.empty((N, 2 * C), dtype=torch.float32, device=feat.device)
+    _l.check(_lib().vqf_glimpse_pool_fwd(_ptr(feat), _ptr(logits), N, S, C, int(bool(unit_softmax)),
+                                         _ptr(wts), _ptr(pooled), _stream()), "vqf_glimpse_pool_fwd")
+    return wts, pooled
+
+
+def glimpse_pool_bwd(dpooled, feat, wts, unit_softmax, want_dfeat):
+    _chk(dpooled, feat, wts)
+    N, S, C = feat.shape
+    dlogits = torch.empty((N * S, 2), dtype=torch.float32, device=feat.device)
+    dfeat = torch.empty_like(feat) if want_dfeat else None
+    _l.check(_lib().vqf_glimpse_pool_bwd(_ptr(dpooled), _ptr(feat), _ptr(wts), N, S, C,
+                                         int(bool(unit_softmax)), _ptr(dlogits), _ptr(dfeat), _stream()),
+             "vqf_glimpse_pool_bwd")
+    return dlogits, dfeat
+
+
+def _keep_ptr(keep):
+    if keep is None:
+        return ctypes.c_void_p(0)
+    if not keep.is_cuda or keep.dtype != torch.uint8 or not keep.is_contiguous():
+        raise _l.VqfError("keep mask must be a contiguous uint8 GPU tensor")
+    return ctypes.c_void_p(keep.data_ptr())
+
+
+def mfb_fuse_fwd(P, q, N, L, O, keep=None, seed=0, p_drop=0.0, cascade=None, want_zdrop=False):
+    """-> (Y normalised (N*L,O), norm (N), inv (N), zdrop or None)."""
+    _chk(P, q, cascade)
+    dev = P.device
+    R = torch.empty((N * L, O), dtype=torch.float32, device=dev)
+    rowssq = torch.empty(N * L, dtype=torch.float32, device=dev)
+    zdrop = torch.empty_like(P) if want_zdrop else None
+    _l.check(_lib().vqf_mfb_fuse_fwd(_ptr(P), _ptr(q), _ptr(cascade), _keep_ptr(keep), int(seed),
+                                     float(p_drop), N, L, O, _ptr(R), _ptr(rowssq), _ptr(zdrop), _stream()),
+             "vqf_mfb_fuse_fwd")
+    norm = torch.empty(N, dtype=torch.float32, device=dev)
+    inv = torch.empty(N, dtype=torch.float32, device=dev)
+    _l.check(_lib().vqf_l2_group_norm(_ptr(rowssq), N, L, _ptr(norm), _ptr(inv), _stream()),
+             "vqf_l2_group_norm")
+    _l.check(_lib().vqf_scale_rows(_ptr(R), _ptr(inv), N * L, L, O, _ptr(R), _stream()), "vqf_scale_rows")
+    return R, norm, inv, zdrop
+
+
+def mfb_fuse_bwd(dY, Y, norm, inv, P, q, N, L, O, keep=None, seed=0, p_drop=0.0, cascade=None,
+                 want_dbias=False, dzdrop=None):
+    """-> (dP (N*L,5O), dq (N,5O), dcascade or None, dbiasP or None)."""
+    _chk(dY, Y, norm, inv, P, q, cascade, dzdrop)
+    dev = P.device
+    rowdot = torch.empty(N * L, dtype=torch.float32, device=dev)
+    _l.check(_lib().vqf_rowdot(_ptr(Y), _ptr(dY), N * L, O, _ptr(rowdot), _stream()), "vqf_rowdot")
+    cA = torch.empty(N, dtype=torch.float32, device=dev)
+    cB = torch.empty(N, dtype=torch.float32, device=dev)
+    _l.check(_lib().vqf_l2_norm_bwd_coef(_ptr(rowdot), _ptr(norm), _ptr(inv), N, L, _ptr(cA), _ptr(cB),
+                                         _stream()), "vqf_l2_norm_bwd_coef")
+    dP = torch.empty_like(P)
+    dq = torch.empty((N, POOL_K * O), dtype=torch.float32, device=dev)
+    dc = torch.empty_like(P) if cascade is not None else None
+    db = torch.empty(POOL_K * O, dtype=torch.float32, device=dev) if want_dbias else None
+    ws = workspace(dev, _lib().vqf_mfb_fuse_bwd_ws_bytes(N, L, O))
+    _l.check(_lib().vqf_mfb_fuse_bwd(_ptr(dY), _ptr(dzdrop), _ptr(Y), _ptr(inv), _ptr(cA), _ptr(cB), _ptr(P), _ptr(q),
+                                     _ptr(cascade), _keep_ptr(keep), int(seed), float(p_drop), N, L, O,
+                                     _ptr(dP), _ptr(dq), _ptr(dc), _ptr(db), _ptr(ws), ws.numel(), _stream()),
+             "vqf_mfb_fuse_bwd")
+    return dP, dq, dc, db
+
+
+# ---------------------------------------------------------------------------
+def prof_enable(on=True):
+    _lib().vqf_prof_enable(int(on))
+
+
+def prof_reset():
+    _lib().vqf_prof_reset()
+
+
+def prof_report():
+    """{kernel name: (launches, total_ms)} for kernels launched since the last reset."""
+    lib = _lib()
+    out = {}
+    for i in range(lib.vqf_prof_num_kernels()):
+        n = ctypes.c_longlong(0)
+        ms = ctypes.c_double(0.0)
+        _l.check(lib.vqf_prof_get(i, ctypes.byref(n), ctypes.byref(ms)), "vqf_prof_get")
+        if n.value:
+            out[lib.vqf_prof_kernel_name(i).decode()] = (n.value, ms.value)
+    return out
