@@ -80,17 +80,18 @@ def load_recipe(model, salt):
     model.load_state_dict(new)
 
 
-def grad_digest(model, out):
-    """per-parameter: is-None flag, l2 norm, abs-sum, 16 sampled entries."""
+def grad_digest(model, out, tag=""):
+    """per-parameter: is-None flag, l2 norm, abs-sum, 16 sampled entries.
+    tag="64": digests of the reference run in float64 (model.double())."""
     for k, p in model.named_parameters():
         if p.grad is None:
             out["gnone/" + k] = np.array(1, dtype=np.int64)
             continue
         g = p.grad.detach().reshape(-1).double().numpy()
-        out["gnorm/" + k] = np.array(np.sqrt((g * g).sum()))
-        out["gabs/" + k] = np.array(np.abs(g).sum())
+        out["g%snorm/" % tag + k] = np.array(np.sqrt((g * g).sum()))
+        out["g%sabs/" % tag + k] = np.array(np.abs(g).sum())
         idx = sample_indices(k, g.size, 16)
-        out["gsamp/" + k] = g[idx].astype(np.float32)
+        out["g%ssamp/" % tag + k] = g[idx].astype(np.float64 if tag else np.float32)
 
 
 def tensor_digest(prefix, t, out, full_limit=4096):
@@ -148,6 +149,21 @@ def run_mfb_like(case, mhb):
     tensor_digest("co_att_feature", store["img_proj2.in"], out)
     tensor_digest("att_normed", store["linear_pred.in"], out)
     grad_digest(model, out)
+    # the same reference modules in float64: conditioning-free gradients (see tests/test_oracle_golden.py)
+    model.double()
+    model.zero_grad()
+    for p_ in model.parameters():
+        p_.grad = None
+    if mhb:
+        o64 = model.forward(img.double(), q, glove_matrix=None if glove is None else glove.double())
+        l64 = torch.nn.KLDivLoss()(o64, soft.double())
+    else:
+        o64 = model.forward(img.double(), q)
+        l64 = torch.nn.CrossEntropyLoss()(o64, ans)
+    l64.backward()
+    out["out64"] = o64.detach().numpy()
+    out["loss64"] = np.array(l64.item())
+    grad_digest(model, out, tag="64")
     return out
 
 

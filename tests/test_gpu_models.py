@@ -3,8 +3,11 @@
   (2) the CPU oracle on the same seeded inputs (incl. train mode with explicit
       dropout masks and the full-size batch through per-sample independence).
 
-Tolerances: forward 1e-4 relative (north_star); gradients 3e-3 on digests (the
-signed-sqrt derivative is singular at 0 -- see tests/test_oracle_golden.py).
+Tolerances: forward 1e-4 relative (north_star).  Gradients: golden_util.grad_parity --
+the HIP gradient must be as close to the exact (fp64) gradient as the CPU fp32
+path is (<= 4x its fp32-vs-fp64 distance, floor 2e-4), because the signed-sqrt
+derivative is singular at 0 and ANY two fp32 summation orders differ by up to
+~1e-2 there; plus a loose 2e-2 check straight against the reference's fp32 digests.
 """
 import numpy as np
 import pytest
@@ -12,13 +15,32 @@ import torch
 
 import recipe
 from cases import MFB_CASES, MHBCOATT_CASES, make_cfg
-from golden_util import load_golden, recipe_sd, mfb_inputs, rel_err, check_grads
+from golden_util import load_golden, recipe_sd, mfb_inputs, rel_err, check_grads, grad_parity
 from oracle import ref_torch as O
 
 pytestmark = pytest.mark.gpu
 
 OUT_TOL = 1e-4
-GRAD_TOL = 3e-3
+GRAD_TOL = 2e-2      # direct digest check vs the reference's fp32 gradients (sanity only)
+
+
+def _oracle_pair(case, mhb, img, q, glove, target, drop=None, cfg=None):
+    """oracle gradients in fp32 and fp64 on the same inputs -> (out32, g32, g64)."""
+    cfg = cfg or make_cfg(case)
+    res = []
+    for dt in (torch.float32, torch.float64):
+        sd = {k: v.to(dt).requires_grad_(True)
+              for k, v in recipe_sd(O.mfb_shapes(cfg, mhb=mhb), case["salt"]).items()}
+        gl = None if glove is None else glove.cpu().to(dt)
+        if mhb:
+            out = O.mhbcoatt_forward(sd, cfg, img.cpu().to(dt), q.cpu(), glove=gl, drop=drop)
+            loss = O.kldiv_loss(out, target.cpu().to(dt))
+        else:
+            out = O.mfb_forward(sd, cfg, img.cpu().to(dt), q.cpu(), drop=drop)
+            loss = O.ce_loss(out, target.cpu())
+        loss.backward()
+        res.append((out.detach(), {k: v.grad for k, v in sd.items()}))
+    return res[0][0], res[0][1], res[1][1]
 
 
 def _vqa():
@@ -33,6 +55,16 @@ def _load(model, salt):
     return model.cuda()
 
 
+def _no_dropout_train(model):
+    """MIOpen's (like cuDNN's) LSTM backward only runs in training mode, so the eval-mode goldens
+    are reproduced in train() with every dropout rate set to 0."""
+    model.train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    return model
+
+
 def _named_grads(model):
     return {k: p.grad for k, p in model.named_parameters()}
 
@@ -42,13 +74,15 @@ def test_mfb_matches_reference_golden(case):
     vqa = _vqa()
     gold = load_golden("mfb_" + case["name"])
     cfg, img, q, _, hard, _ = mfb_inputs(case, "cuda")
-    model = _load(vqa.MFB(cfg), case["salt"]).eval()
+    model = _no_dropout_train(_load(vqa.MFB(cfg), case["salt"]))
     logits = model.forward(img, q)
     assert rel_err(logits.detach().cpu().numpy(), gold["out"]) <= OUT_TOL
     loss = torch.nn.CrossEntropyLoss()(logits, hard)
     assert abs(loss.item() - float(gold["loss"])) <= OUT_TOL * max(1.0, float(gold["loss"]))
     loss.backward()
     check_grads(_named_grads(model), gold, GRAD_TOL)
+    _, g32, g64 = _oracle_pair(case, False, img, q, None, hard)
+    grad_parity(_named_grads(model), g32, g64)
 
 
 @pytest.mark.parametrize("case", [pytest.param(c, id=c["name"]) for c in MHBCOATT_CASES])
@@ -56,13 +90,15 @@ def test_mhbcoatt_matches_reference_golden(case):
     vqa = _vqa()
     gold = load_golden("mhbcoatt_" + case["name"])
     cfg, img, q, glove, _, soft = mfb_inputs(case, "cuda")
-    model = _load(vqa.MHBCoAtt(cfg), case["salt"]).eval()
+    model = _no_dropout_train(_load(vqa.MHBCoAtt(cfg), case["salt"]))
     out = model.forward(img, q, glove_matrix=glove)
     assert rel_err(out.detach().cpu().numpy(), gold["out"]) <= OUT_TOL
     loss = torch.nn.KLDivLoss()(out, soft)
     assert abs(loss.item() - float(gold["loss"])) <= 2e-4 * max(1e-3, abs(float(gold["loss"])))
     loss.backward()
     check_grads(_named_grads(model), gold, GRAD_TOL)
+    _, g32, g64 = _oracle_pair(case, True, img, q, glove, soft)
+    grad_parity(_named_grads(model), g32, g64)
 
 
 def _oracle_grads(fn, sd, loss_fn):
@@ -104,16 +140,10 @@ def test_train_mode_with_explicit_dropout_masks(mhb):
     loss = torch.nn.KLDivLoss()(out, soft) if mhb else torch.nn.CrossEntropyLoss()(out, hard)
     loss.backward()
 
-    sd = recipe_sd(O.mfb_shapes(cfg, mhb=mhb), case["salt"], requires_grad=True)
     drop = dict(m1=m1.view(N, L, 5000), m2=m2, m3=m3)
-    if mhb:
-        o_out, ogr = _oracle_grads(lambda s: O.mhbcoatt_forward(s, cfg, img.cpu(), q.cpu(), drop=drop), sd,
-                                   lambda o: O.kldiv_loss(o, soft.cpu()))
-    else:
-        o_out, ogr = _oracle_grads(lambda s: O.mfb_forward(s, cfg, img.cpu(), q.cpu(), drop=drop), sd,
-                                   lambda o: O.ce_loss(o, hard.cpu()))
+    o_out, g32, g64 = _oracle_pair(case, mhb, img, q, glove, soft if mhb else hard, drop=drop)
     assert rel_err(out.detach().cpu().numpy(), o_out.numpy()) <= OUT_TOL
-    _cmp_grads(model, ogr, 5e-3)
+    grad_parity(_named_grads(model), g32, g64)
 
 
 def test_train_mode_philox_is_seeded_and_differentiable():
@@ -137,7 +167,7 @@ def test_mfb_unit_softmax_switch_gives_live_attention():
     vqa = _vqa()
     case = MFB_CASES[2]
     cfg, img, q, _, hard, _ = mfb_inputs(case, "cuda")
-    model = _load(vqa.MFB(cfg), case["salt"]).eval()
+    model = _no_dropout_train(_load(vqa.MFB(cfg), case["salt"]))
     compat = model.forward(img, q)
     model.unit_softmax = False
     live = model.forward(img, q)
@@ -175,14 +205,12 @@ def test_full_dims_gradients_vs_oracle_n16():
     case = dict(name="n16", salt=78, N=16, model_name="mhb_coAtt", glove=False,
                 H=1024, E=300, D=2048, L=196, V=1000, A=1000, T=14)
     cfg, img, q, glove, hard, soft = mfb_inputs(case, "cuda")
-    model = _load(vqa.MHBCoAtt(cfg), case["salt"]).eval()
+    model = _no_dropout_train(_load(vqa.MHBCoAtt(cfg), case["salt"]))
     out = model.forward(img, q)
     torch.nn.KLDivLoss()(out, soft).backward()
-    sd = recipe_sd(O.mfb_shapes(cfg, mhb=True), case["salt"], requires_grad=True)
-    o_out, ogr = _oracle_grads(lambda s: O.mhbcoatt_forward(s, cfg, img.cpu(), q.cpu()), sd,
-                               lambda o: O.kldiv_loss(o, soft.cpu()))
+    o_out, g32, g64 = _oracle_pair(case, True, img, q, None, soft)
     assert rel_err(out.detach().cpu().numpy(), o_out.numpy()) <= OUT_TOL
-    _cmp_grads(model, ogr, 5e-3)
+    grad_parity(_named_grads(model), g32, g64)
 
 
 def test_mhb_module_vs_oracle():
@@ -192,17 +220,21 @@ def test_mhb_module_vs_oracle():
     cfg = types.SimpleNamespace(q_vocab_size=50, a_vocab_size=30, emb_dim=24, hidden_dim=64, num_layers=1,
                                 img_feature_channel=96, img_feature_dim=196, model_name="mhb", glove=False)
     N, T = 5, 7
-    model = _load(vqa.MHB(cfg), 61).eval()
+    model = _no_dropout_train(_load(vqa.MHB(cfg), 61))
     img = torch.from_numpy(recipe.img_features(N, 196, 96, 61))
     qn = recipe.question_tokens(N, T, 50, 61)
     q, ql = torch.from_numpy(qn), torch.from_numpy(recipe.question_lengths(qn))
     soft = torch.from_numpy(recipe.soft_answers(N, 30, 61))
     out = model.forward(img.cuda(), q.cuda(), ql.cuda())
     torch.nn.KLDivLoss()(out, soft.cuda()).backward()
-    sd = recipe_sd(O.mhb_shapes(cfg), 61, requires_grad=True)
-    o_out, ogr = _oracle_grads(lambda s: O.mhb_forward(s, cfg, img, q, ql), sd, lambda o: O.kldiv_loss(o, soft))
-    assert rel_err(out.detach().cpu().numpy(), o_out.numpy()) <= OUT_TOL
-    _cmp_grads(model, ogr, 5e-3)
+    res = []
+    for dt in (torch.float32, torch.float64):
+        sd = {k: v.to(dt).requires_grad_(True) for k, v in recipe_sd(O.mhb_shapes(cfg), 61).items()}
+        o = O.mhb_forward(sd, cfg, img.to(dt), q, ql)
+        O.kldiv_loss(o, soft.to(dt)).backward()
+        res.append((o.detach(), {k: v.grad for k, v in sd.items()}))
+    assert rel_err(out.detach().cpu().numpy(), res[0][0].numpy()) <= OUT_TOL
+    grad_parity(_named_grads(model), res[0][1], res[1][1])
 
 
 def test_state_dict_keys_match_reference_layout():

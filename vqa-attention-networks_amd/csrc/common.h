@@ -37,6 +37,7 @@ void vqf_prof_end(int id, hipStream_t s);
 // Launch with optional event bracketing; evaluates to the launch error code.
 #define VQF_LAUNCH(id, kern, grid, block, shmem, stream, ...)                      \
   do {                                                                             \
+    (void)hipGetLastError(); /* drop stale errors of unrelated earlier calls */    \
     if (g_vqf_prof_on) vqf_prof_begin((id), (stream));                             \
     hipLaunchKernelGGL(kern, grid, block, shmem, stream, __VA_ARGS__);             \
     if (g_vqf_prof_on) vqf_prof_end((id), (stream));                               \

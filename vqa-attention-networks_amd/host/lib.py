@@ -95,6 +95,10 @@ def load():
                 "libvqa_fusion.so is missing (%s).  The HIP extension is the product path and "
                 "there is no CPU fallback: run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C %s`." % (LIB_PATH, CSRC_DIR))
+        # torch first: PyTorch-ROCm bundles its own libamdhip64 (same SONAME); loading ours
+        # before it would put two HIP runtimes in the process (kernels would then be launched
+        # on a runtime that has not opened torch's device/streams -> hipErrorNoDevice).
+        import torch  # noqa: F401
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)        # AttributeError if the symbol is not exported

@@ -43,7 +43,7 @@ class MFB(nn.Module):
             self.ques_att_conv2 = nn.Conv2d(1024, 2, [1, 1])
         self.ques_proj1 = nn.Linear(2 * cfg.hidden_dim, 5000)
         self.img_conv1d = nn.Conv2d(cfg.img_feature_channel, 5000, [1, 1])
-        self.dropout_m = nn.Dropout(p=0.1)      # kept for module-tree parity; masks are in-kernel
+        self.dropout_m = nn.Dropout(p=0.1)      # its .p is the rate of the in-kernel Philox masks
         self.co_att_conv1 = nn.Conv2d(1000, 1024, [1, 1])
         if self.multilayer:
             self.co_att_multiconv = nn.Conv2d(1024, 512, [1, 1])
@@ -83,19 +83,20 @@ class MFB(nn.Module):
         # a4: ques_proj1                                                     mfb.py:92-93
         qp = LinearFn.apply(qa, self.ques_proj1.weight, self.ques_proj1.bias)
         # a5+a6: image projection + MFB fusion over the regions             mfb.py:95-106
-        seed, p = self._seeds.next(self.training, 0.1)
+        pm = self.dropout_m.p
+        seed, p = self._seeds.next(self.training, pm)
         k1 = keep.get('m1')
         Y = ImgFuseFn.apply(img_features, self.img_conv1d.weight, self.img_conv1d.bias, qp,
-                            k1, seed, 0.1 if k1 is not None else p)
+                            k1, seed, pm if k1 is not None else p)
         # a7+a8: co-attention over the regions                               mfb.py:109-123
         wm, bm = self._mc('co_att_multiconv')
         va = AttHeadFn.apply(Y, img_features, self.co_att_conv1.weight, self.co_att_conv1.bias, wm, bm,
                              self.co_att_conv2.weight, self.co_att_conv2.bias, self.unit_softmax)
         # a9: final MFB block                                                mfb.py:126-135
-        seed, p = self._seeds.next(self.training, 0.1)
+        seed, p = self._seeds.next(self.training, pm)
         k2 = keep.get('m2')
         y = FinalMfbFn.apply(qa, va, self.ques_proj2.weight, self.ques_proj2.bias,
                              self.img_proj2.weight, self.img_proj2.bias, k2, seed,
-                             0.1 if k2 is not None else p)
+                             pm if k2 is not None else p)
         # a10: classifier; the reference computes a softmax and discards it  mfb.py:137-140
         return LinearFn.apply(y, self.linear_pred.weight, self.linear_pred.bias)

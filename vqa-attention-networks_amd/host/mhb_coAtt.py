@@ -58,18 +58,19 @@ class MHBCoAtt(nn.Module):
                              self.ques_att_conv1.weight, self.ques_att_conv1.bias, None, None,
                              self.ques_att_conv2.weight, self.ques_att_conv2.bias, False)
         qp = LinearFn.apply(qa, self.ques_proj1.weight, self.ques_proj1.bias)
-        seed, p = self._seeds.next(self.training, 0.1)
+        pm = self.dropout_m.p
+        seed, p = self._seeds.next(self.training, pm)
         k1 = keep.get('m1')
         Y = ImgFuseFn.apply(img_features, self.img_conv1d.weight, self.img_conv1d.bias, qp,
-                            k1, seed, 0.1 if k1 is not None else p)
+                            k1, seed, pm if k1 is not None else p)
         va = AttHeadFn.apply(Y, img_features, self.co_att_conv1.weight, self.co_att_conv1.bias, None, None,
                              self.co_att_conv2.weight, self.co_att_conv2.bias, False)
         ys = []
         for tag, qpj, ipj in (('m2', self.ques_proj2, self.img_proj2), ('m3', self.ques_proj3, self.img_proj3)):
-            seed, p = self._seeds.next(self.training, 0.1)
+            seed, p = self._seeds.next(self.training, pm)
             kk = keep.get(tag)
             ys.append(FinalMfbFn.apply(qa, va, qpj.weight, qpj.bias, ipj.weight, ipj.bias, kk, seed,
-                                       0.1 if kk is not None else p))
+                                       pm if kk is not None else p))
         att_normed_23 = torch.cat(ys, 1)                                     # (N,2000)  :147
         logits = LinearFn.apply(att_normed_23, self.linear_pred.weight, self.linear_pred.bias)
         return F.log_softmax(logits, dim=1)                                  # :149 (implicit dim=1)
@@ -113,16 +114,17 @@ class MHB(nn.Module):
         idx = (q_length.to(torch.long) - 1).to(lstm_outs.device)
         lstm_out = lstm_outs[idx, torch.arange(batch_size, device=lstm_outs.device)]   # :185-186
         lstm_out = self.lstm_dropout(lstm_out)
-        seed, p = self._seeds.next(self.training, 0.1)
+        pm = self.mfb_dropout.p
+        seed, p = self._seeds.next(self.training, pm)
         k1 = keep.get('m1')
         mhb_1, z1 = FinalMfbFn.apply(lstm_out, i_mean, self.linear_q_1.weight, self.linear_q_1.bias,
                                      self.linear_i_1.weight, self.linear_i_1.bias, k1, seed,
-                                     0.1 if k1 is not None else p, None, True)      # :190-199
-        seed, p = self._seeds.next(self.training, 0.1)
+                                     pm if k1 is not None else p, None, True)       # :190-199
+        seed, p = self._seeds.next(self.training, pm)
         k2 = keep.get('m2')
         mhb_2 = FinalMfbFn.apply(lstm_out, i_mean, self.linear_q_2.weight, self.linear_q_2.bias,
                                  self.linear_i_2.weight, self.linear_i_2.bias, k2, seed,
-                                 0.1 if k2 is not None else p, z1, False)            # :201-211
+                                 pm if k2 is not None else p, z1, False)             # :201-211
         mhb_12 = torch.cat((mhb_1, mhb_2), 1)
         logits = LinearFn.apply(mhb_12, self.linear_out.weight, self.linear_out.bias)
         return F.log_softmax(logits, dim=1)
