@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""Headline benchmark: QA-pairs/s of one MFB-baseline training step (forward +
+loss + backward + gradient all-reduce + Adam step), batch 512 per GPU, fp32,
+on 1..8 MI355X (one process per GPU, RCCL over xGMI), beside the CPU baseline.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement).  Synthetic
+inputs per BASELINE.md section 3: img = relu(N(0,1)) (B,196,2048), questions
+uniform [1,1000) (B,14), labels uniform [0,1000); weights: manual_seed(0),
+module default init, xavier_uniform_ on every non-bias parameter
+(train_models.py:54-56).  Train mode (dropout active), device-resident inputs.
+
+mode "faithful": every op the reference's autograd executes is executed here
+too -- including the image-projection GEMM and its weight-gradient GEMM whose
+results cannot reach the logits/gradients in MFB-baseline because mfb.py:84,118
+take their softmax over a singleton axis.  roofline.achieved
+counts only FLOPs actually executed by the measured kernel.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 matrix peak (= vector peak)
+HBM_PEAK_GBS = 8000.0
+
+
+def full_cfg(model_name="mfb"):
+    return types.SimpleNamespace(q_vocab_size=1000, a_vocab_size=1000, emb_dim=300, hidden_dim=1024,
+                                 num_layers=1, model_name=model_name, glove=False,
+                                 img_feature_channel=2048, img_feature_dim=196)
+
+
+def synth_batch(B, rank, device):
+    g = torch.Generator().manual_seed(1234 + 1000 * rank)
+    img = torch.relu(torch.randn((B, 196, 2048), generator=g))
+    q = torch.randint(1, 1000, (B, 14), generator=torch.Generator().manual_seed(1235 + 1000 * rank))
+    a = torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(1236 + 1000 * rank))
+    return img.to(device), q.to(device), a.to(device)
+
+
+def init_like_reference(model):
+    torch.manual_seed(0)
+    for name, p in model.named_parameters():
+        if name.find('bias') == -1:
+            torch.nn.init.xavier_uniform_(p)          # train_models.py:54-56
+
+
+def host_cores():
+    """CPU cores this process may actually use: cgroup quota (cpu.max) capped by the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(budget_s=20.0):
+    """The oracle (CPU restatement, PyTorch CPU ops) on the host cores: same step contents.
+
+    Bounded sample: one probe step at B=16 sizes the sample so that 1 warm-up + 2 timed steps
+    take about `budget_s` seconds (B in [16,128]); per-sample CPU cost is flat in B."""
+    from oracle import ref_torch as O
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    cfg = full_cfg()
+    torch.manual_seed(0)
+    sd = {}
+    for k, shp in O.mfb_shapes(cfg).items():
+        t = torch.empty(shp)
+        if k.find('bias') == -1 and t.dim() >= 2:
+            torch.nn.init.xavier_uniform_(t)
+        else:
+            t.uniform_(-0.05, 0.05)
+        sd[k] = t.requires_grad_(True)
+    opt = torch.optim.Adam(list(sd.values()), lr=7e-4)
+    gen = torch.Generator().manual_seed(99)
+
+    def one_step(img, q, a):
+        Bs = img.shape[0]
+        drop = dict(l=(torch.rand((Bs, 14, 1024), generator=gen) >= 0.3),
+                    m1=(torch.rand((Bs, 196, 5000), generator=gen) >= 0.1),
+                    m2=(torch.rand((Bs, 5000), generator=gen) >= 0.1))
+        t0 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        logits = O.mfb_forward(sd, cfg, img, q, drop=drop)
+        loss = O.ce_loss(logits, a)
+        loss.backward()
+        opt.step()
+        return time.perf_counter() - t0
+
+    img, q, a = synth_batch(128, 0, "cpu")
+    one_step(img[:16], q[:16], a[:16])                      # page-in / thread-pool warm-up
+    probe = one_step(img[:16], q[:16], a[:16])
+    per_sample = probe / 16.0
+    Bs = int(max(16, min(128, (budget_s / 3.0) / max(per_sample, 1e-6))))
+    Bs -= Bs % 8
+    times = [one_step(img[:Bs], q[:Bs], a[:Bs]) for _ in range(3)]
+    t = sorted(times[1:])[0] if len(times) == 2 else sorted(times[1:])[len(times[1:]) // 2]
+    try:
+        model = [l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        model = "unknown"
+    return {"value": round(Bs / t, 3), "unit": "QA-pairs/s", "cores": cores, "kind": "port",
+            "sample": "oracle MFB train step (fwd+loss+bwd+Adam, dropout masks supplied), B=%d, "
+                      "1 warm-up + 2 timed steps, median %.2f s/step, %d threads; CPU: %s"
+                      % (Bs, t, cores, model)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=512, help="QA pairs per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--model", default="mfb", choices=["mfb", "mhb_coAtt"])
+    args = ap.parse_args()
+
+    import vqa_amd
+    from importlib import import_module
+    parallel = import_module("vqa-attention-networks_amd.host.parallel")
+    ops = vqa_amd.ops
+    vqa_amd.lib.load()
+
+    rank, world, local = parallel.init_distributed()
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    B = args.batch
+    cfg = full_cfg(args.model)
+    model = (vqa_amd.MFB if args.model == "mfb" else vqa_amd.MHBCoAtt)(cfg)
+    init_like_reference(model)
+    model = model.to(dev).train()
+    reducer = parallel.GradientAllReducer(model)        # broadcasts rank 0's weights; no-op at world 1
+    try:
+        opt = torch.optim.Adam(model.parameters(), lr=7e-4, fused=True)
+    except Exception:
+        opt = torch.optim.Adam(model.parameters(), lr=7e-4)
+    img, q, a = synth_batch(B, rank, dev)
+    soft = torch.softmax(torch.randn((B, 1000), generator=torch.Generator().manual_seed(1236 + rank)), 1).to(dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = model.forward(img, q)
+        loss = F.cross_entropy(out, a) if args.model == "mfb" else F.kl_div(out, soft, reduction="mean")
+        loss.backward()
+        reducer.finish()
+        opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ops.prof_reset()
+    ops.prof_enable(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    ops.prof_enable(False)
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = B * world * args.steps / elapsed
+
+    # ---- roofline of the dominant kernel: the image-projection GEMM (mfb.py:96) --------------
+    M, N, K = B * 196, 5000, 2048
+    n_f, ms_f = ops.prof_gemm(0, 0, M, N, K)               # forward projection
+    n_w, ms_w = ops.prof_gemm(1, 1, N, K, M)               # its weight gradient (same FLOPs)
+    flops = 2.0 * M * N * K
+    roofline = None
+    if n_f:
+        ach = flops / (ms_f / n_f * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "gemm_f32_a0b0 img_conv1d forward (M=%d,N=%d,K=%d)" % (M, N, K),
+                    "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "avg_launch_ms": round(ms_f / n_f, 4), "launches": n_f,
+                    "flops_per_launch": flops}
+        if n_w:
+            achw = flops / (ms_w / n_w * 1e-3) / 1e12
+            roofline["wgrad"] = {"kernel": "gemm_f32_a1b1 img_conv1d wgrad (split-K)", "achieved": round(achw, 2),
+                                 "frac": round(achw / FP32_MFMA_PEAK_TFLOPS, 4),
+                                 "avg_launch_ms": round(ms_w / n_w, 4), "launches": n_w}
+    kernels = {k: {"launches_per_step": round(n / args.steps, 2), "ms_per_step": round(ms / args.steps, 4)}
+               for k, (n, ms) in sorted(ops.prof_report().items(), key=lambda kv: -kv[1][1])}
+
+    if rank == 0:
+        out = {
+            "metric": "QA-pairs/sec fwd+bwd, MFB-baseline batch 512",
+            "value": round(value, 2), "unit": "QA-pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "MFB-baseline train step (fwd+loss+bwd+grad all-reduce+Adam), "
+                                   "batch %d per GPU, 196x2048 image grid, 14 tokens, fp32, mode=faithful"
+                                   % B if args.model == "mfb" else "MHBCoAtt train step, batch %d per GPU" % B,
+                       "global_batch": B * world, "parallelism": "dp%d" % world,
+                       "grad_allreduce_bytes": reducer.gradient_bytes()},
+            "loss": round(float(loss.item()), 5),
+            "roofline": roofline,
+            "kernels_ms_per_step": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+            out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

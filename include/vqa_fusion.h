@@ -192,6 +192,8 @@ int vqf_prof_num_kernels(void);
 const char* vqf_prof_kernel_name(int id);
 /* synchronises the recorded events; returns launches and total milliseconds */
 int vqf_prof_get(int id, long long* launches, double* total_ms);
+/* same, restricted to launches whose shape tag matches (GEMMs tag M,N,K; -1 = any) */
+int vqf_prof_get_shape(int id, int d0, int d1, int d2, long long* launches, double* total_ms);
 
 #ifdef __cplusplus
 }

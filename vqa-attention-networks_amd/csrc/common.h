@@ -33,6 +33,7 @@ enum VqfKernelId {
 extern int g_vqf_prof_on;
 void vqf_prof_begin(int id, hipStream_t s);
 void vqf_prof_end(int id, hipStream_t s);
+void vqf_prof_dims(int d0, int d1, int d2);   // shape tag attached to the next launches of this thread
 
 // Launch with optional event bracketing; evaluates to the launch error code.
 #define VQF_LAUNCH(id, kern, grid, block, shmem, stream, ...)                      \

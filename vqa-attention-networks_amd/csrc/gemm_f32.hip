@@ -274,6 +274,7 @@ extern "C" int vqf_gemm_f32(int ta, int tb, int M, int N, int K, const float* A,
 
   dim3 grid((unsigned)tiles, (unsigned)splits);
   const int kid = KID_GEMM_A0B0 + 2 * (ta ? 1 : 0) + (tb ? 1 : 0);
+  if (g_vqf_prof_on) vqf_prof_dims(M, N, K);
   int rc;
   if (!ta && !tb) rc = launch_gemm<false, false>(g, grid, s, kid);
   else if (!ta && tb) rc = launch_gemm<false, true>(g, grid, s, kid);

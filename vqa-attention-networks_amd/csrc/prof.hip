@@ -6,11 +6,12 @@
 int g_vqf_prof_on = 0;
 
 namespace {
-struct Pair { hipEvent_t a, b; int id; };
+struct Pair { hipEvent_t a, b; int id; int d[3]; };
 std::mutex g_mu;
 std::vector<Pair> g_pairs;
 std::vector<hipEvent_t> g_free;
 thread_local hipEvent_t t_start = nullptr;
+thread_local int t_dims[3] = {0, 0, 0};
 
 const char* const kNames[KID_COUNT] = {
     "gemm_f32_a0b0(fwd)", "gemm_f32_a0b1(dgrad)", "gemm_f32_a1b0", "gemm_f32_a1b1(wgrad)",
@@ -35,8 +36,9 @@ void vqf_prof_end(int id, hipStream_t s) {
   hipEvent_t b = get_event();
   (void)hipEventRecord(b, s);
   std::lock_guard<std::mutex> lk(g_mu);
-  g_pairs.push_back({t_start, b, id});
+  g_pairs.push_back({t_start, b, id, {t_dims[0], t_dims[1], t_dims[2]}});
 }
+void vqf_prof_dims(int d0, int d1, int d2) { t_dims[0] = d0; t_dims[1] = d1; t_dims[2] = d2; }
 
 extern "C" {
 int vqf_abi_version(void) { return 1; }
@@ -52,12 +54,16 @@ void vqf_prof_reset(void) {
 int vqf_prof_num_kernels(void) { return KID_COUNT; }
 const char* vqf_prof_kernel_name(int id) { return (id >= 0 && id < KID_COUNT) ? kNames[id] : ""; }
 int vqf_prof_get(int id, long long* launches, double* total_ms) {
+  return vqf_prof_get_shape(id, -1, -1, -1, launches, total_ms);
+}
+int vqf_prof_get_shape(int id, int d0, int d1, int d2, long long* launches, double* total_ms) {
   if (id < 0 || id >= KID_COUNT || !launches || !total_ms) return VQF_E_BADARG;
   std::lock_guard<std::mutex> lk(g_mu);
   long long n = 0;
   double ms = 0.0;
   for (auto& p : g_pairs) {
     if (p.id != id) continue;
+    if ((d0 >= 0 && p.d[0] != d0) || (d1 >= 0 && p.d[1] != d1) || (d2 >= 0 && p.d[2] != d2)) continue;
     hipError_t e = hipEventSynchronize(p.b);
     if (e != hipSuccess) return (int)e;
     float t = 0.f;

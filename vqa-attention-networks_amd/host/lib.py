@@ -53,6 +53,8 @@ SIGNATURES = {
     "vqf_prof_num_kernels": (c_i, []),
     "vqf_prof_kernel_name": (ctypes.c_char_p, [c_i]),
     "vqf_prof_get": (c_i, [c_i, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_double)]),
+    "vqf_prof_get_shape": (c_i, [c_i, c_i, c_i, c_i, ctypes.POINTER(ctypes.c_longlong),
+                                 ctypes.POINTER(ctypes.c_double)]),
 }
 
 _ERR = {-1: "VQF_E_BADARG", -2: "VQF_E_ALIGN", -3: "VQF_E_UNSUPPORTED", -4: "VQF_E_WORKSPACE"}

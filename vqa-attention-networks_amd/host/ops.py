@@ -246,3 +246,13 @@ def prof_report():
         if n.value:
             out[lib.vqf_prof_kernel_name(i).decode()] = (n.value, ms.value)
     return out
+
+
+def prof_gemm(ta, tb, M, N, K):
+    """(launches, total_ms) of the GEMM launches with this layout and shape since the last reset."""
+    lib = _lib()
+    n = ctypes.c_longlong(0)
+    ms = ctypes.c_double(0.0)
+    _l.check(lib.vqf_prof_get_shape(2 * int(bool(ta)) + int(bool(tb)), M, N, K, ctypes.byref(n),
+                                    ctypes.byref(ms)), "vqf_prof_get_shape")
+    return n.value, ms.value
