@@ -132,6 +132,8 @@ def main():
     ap.add_argument("--batch", type=int, default=512, help="QA pairs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--model", default="mfb", choices=["mfb", "mhb_coAtt"])
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); "
+                    "'gloo' lets several ranks share one GPU for rehearsals")
     args = ap.parse_args()
 
     import vqa_amd
@@ -140,11 +142,12 @@ def main():
     ops = vqa_amd.ops
     vqa_amd.lib.load()
 
-    rank, world, local = parallel.init_distributed()
+    rank, world, local = parallel.init_distributed(args.backend)
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 

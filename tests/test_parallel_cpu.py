@@ -1,0 +1,106 @@
+"""world_size-2 gloo tests (CPU) of the data-parallel layer used by bench.py --gpus N:
+shard_rows partitioning, initial broadcast, bucketed overlapped all-reduce == gradient of
+the concatenated batch."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make_model():
+    torch.manual_seed(3)
+    m = torch.nn.Sequential(torch.nn.Linear(12, 40), torch.nn.Tanh(), torch.nn.Linear(40, 7))
+    m.unused = torch.nn.Parameter(torch.ones(5))          # never receives a gradient
+    return m
+
+
+def _worker(rank, world, port, bucket_bytes, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from importlib import import_module
+    par = import_module("vqa-attention-networks_amd.host.parallel")
+    r, w, _ = par.init_distributed(backend="gloo")
+    assert (r, w) == (rank, world)
+    model = _make_model()
+    if rank != 0:                                        # replicas start different; broadcast fixes it
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(1.0)
+    red = par.GradientAllReducer(model, bucket_bytes=bucket_bytes)
+    g = torch.Generator().manual_seed(11)
+    X = torch.randn(16, 12, generator=g)
+    Y = torch.randint(0, 7, (16,), generator=g)
+    lo, hi = par.shard_rows(16, rank, world)
+    outs = []
+    for step in range(2):                                # two steps: buckets must re-arm
+        model.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.cross_entropy(model(X[lo:hi]), Y[lo:hi])
+        loss.backward()
+        red.finish()
+        outs.append([None if p.grad is None else p.grad.clone() for p in model.parameters()])
+    q.put((rank, [p.detach().clone() for p in model.parameters()], outs, len(red.buckets)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bucket_bytes", [64 << 20, 256])
+def test_allreduce_equals_full_batch_gradient(bucket_bytes):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, bucket_bytes, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        rank, params, outs, nb = q.get(timeout=120)
+        res[rank] = (params, outs, nb)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    if bucket_bytes == 256:
+        assert res[0][2] > 1                              # several buckets exercised
+    # reference: single process, full batch, rank-0 initial weights
+    model = _make_model()
+    g = torch.Generator().manual_seed(11)
+    X = torch.randn(16, 12, generator=g)
+    Y = torch.randint(0, 7, (16,), generator=g)
+    torch.nn.functional.cross_entropy(model(X), Y).backward()
+    ref = [p.grad for p in model.parameters()]
+    for rank in range(world):
+        params, outs, _ = res[rank]
+        for a, b in zip(params, model.parameters()):
+            assert torch.equal(a, b.detach())             # broadcast made the replicas identical
+        for step in range(2):
+            for gavg, gref in zip(outs[step], ref):
+                if gref is None:
+                    assert gavg is None or float(gavg.abs().max()) == 0.0
+                else:
+                    assert torch.allclose(gavg, gref, rtol=1e-5, atol=1e-7)
+
+
+def test_shard_rows_partitions_the_batch():
+    from importlib import import_module
+    sys.path.insert(0, ROOT)
+    par = import_module("vqa-attention-networks_amd.host.parallel")
+    for n, w in [(4096, 8), (10, 3), (7, 8), (512, 1)]:
+        spans = [par.shard_rows(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+        assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+    assert par.shard_rows(4096, 3, 8) == (1536, 2048)

@@ -29,6 +29,7 @@ def init_distributed(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
+            local = local % max(torch.cuda.device_count(), 1)
             torch.cuda.set_device(local)
             dist.init_process_group(backend, rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local))
