@@ -86,6 +86,41 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ p, int ld, i
   }
 }
 
+// ---- fast path: per-thread source pointers computed ONCE, rows clamped into range -------------
+// A row beyond the matrix edge only feeds accumulators whose outputs are never stored, so the
+// loader clamps its row index instead of guarding (no branches / exec masking in the K loop).
+// Requires 16-B aligned base, ld % 4 == 0 and, for the K-major layout, R % 4 == 0.
+// Global address space (1) is spelled out: pointers kept in arrays otherwise decay to generic
+// and hipcc emits flat_load, which also counts on lgkmcnt -- every LDS wait would then wait for
+// the prefetch of the NEXT tile as well.
+typedef const float __attribute__((address_space(1))) gfloat;
+typedef const f32x4 __attribute__((address_space(1))) gf32x4;
+
+template <bool T>
+__device__ __forceinline__ void init_ptrs(const float* __restrict__ p0, int ld, int r0, int R, int k0,
+                                          int tid, gfloat* (&q)[4]) {
+  gfloat* p = (gfloat*)p0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int f = tid + NTHREADS * i;
+    if (!T) {
+      const int r = min(r0 + (f >> 3), R - 1);
+      q[i] = p + (long long)r * ld + (k0 + ((f & 7) << 2));
+    } else {
+      const int r = min(r0 + ((f & 31) << 2), R - 4);
+      q[i] = p + (long long)(k0 + (f >> 5)) * ld + r;
+    }
+  }
+}
+template <bool T>
+__device__ __forceinline__ void load_fast(gfloat* (&q)[4], int ld, f32x4 (&v)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[i] = *(gf32x4*)q[i];
+    q[i] += T ? (long long)BK * ld : BK;
+  }
+}
+
 template <bool T>
 __device__ __forceinline__ void store_tile(float* s, int tid, const f32x4 (&v)[4]) {
 #pragma unroll
@@ -106,23 +141,123 @@ __device__ __forceinline__ f32x4 read_frag(const float* s, int row, int g8, int 
   return x;
 }
 
-template <bool TA, bool TB>
+// K loop of one 128x128 output tile.  EDGE = false: all four 32x32 sub-tiles of this wave are
+// inside the matrix (the common case, no predication anywhere in the loop).  EDGE = true: tile on
+// the matrix border; sub-tiles that are entirely outside are skipped (N = 5000 = 39*128 + 8).
+template <bool TA, bool TB, bool FAST, bool EDGE>
+__device__ __forceinline__ void gemm_mainloop(const GemmArgs& g, float* smem, const float* gA,
+                                              const float* gB, int m0, int n0, int kbeg, int kend,
+                                              int tid, int wr, int wc, int l31, int h,
+                                              f32x16 (&acc)[2][2]) {
+  const int ntiles = (kend - kbeg + BK - 1) / BK;
+  const int nfull = (kend - kbeg) / BK;            // tiles that need no K guard
+  bool v10 = true, v01 = true;                     // sub-tile (1,0) / (0,1) inside?  (EDGE only)
+  if (EDGE) {
+    v10 = (m0 + wr * 64 + 32) < g.M;
+    v01 = (n0 + wc * 64 + 32) < g.N;
+  }
+  gfloat* pa[4];
+  gfloat* pb[4];
+  f32x4 ra[4], rb[4];
+  if (FAST) {
+    init_ptrs<TA>(gA, g.lda, m0, g.M, kbeg, tid, pa);
+    init_ptrs<TB>(gB, g.ldb, n0, g.N, kbeg, tid, pb);
+  }
+  if (FAST && nfull > 0) {
+    load_fast<TA>(pa, g.lda, ra);
+    load_fast<TB>(pb, g.ldb, rb);
+  } else {
+    load_tile<TA>(gA, g.lda, m0, g.M, kbeg, kend, g.vecA, tid, ra);
+    load_tile<TB>(gB, g.ldb, n0, g.N, kbeg, kend, g.vecB, tid, rb);
+  }
+  store_tile<TA>(smem, tid, ra);
+  store_tile<TB>(smem + OP_FLOATS, tid, rb);
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    const float* sA = smem + (t & 1) * STAGE_FLOATS;
+    const float* sB = sA + OP_FLOATS;
+    const bool more = (t + 1) < ntiles;
+    if (more) {                                    // prefetch tile t+1 into registers
+      if (FAST && (t + 1) < nfull) {
+        load_fast<TA>(pa, g.lda, ra);
+        load_fast<TB>(pb, g.ldb, rb);
+      } else {
+        const int k0 = kbeg + (t + 1) * BK;
+        load_tile<TA>(gA, g.lda, m0, g.M, k0, kend, g.vecA, tid, ra);
+        load_tile<TB>(gB, g.ldb, n0, g.N, k0, kend, g.vecB, tid, rb);
+      }
+    }
+#pragma unroll
+    for (int g8 = 0; g8 < BK / 8; ++g8) {
+      if (!EDGE) {
+        f32x4 af[2], bf[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[i] = read_frag<TA>(sA, wr * 64 + i * 32 + l31, g8, h);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bf[j] = read_frag<TB>(sB, wc * 64 + j * 32 + l31, g8, h);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
+      } else {
+        const f32x4 a0 = read_frag<TA>(sA, wr * 64 + l31, g8, h);
+        const f32x4 b0 = read_frag<TB>(sB, wc * 64 + l31, g8, h);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[kk], b0[kk], acc[0][0], 0, 0, 0);
+        if (v10) {
+          const f32x4 a1 = read_frag<TA>(sA, wr * 64 + 32 + l31, g8, h);
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk)
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[kk], b0[kk], acc[1][0], 0, 0, 0);
+        }
+        if (v01) {
+          const f32x4 b1 = read_frag<TB>(sB, wc * 64 + 32 + l31, g8, h);
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk)
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[kk], b1[kk], acc[0][1], 0, 0, 0);
+        }
+      }
+    }
+    if (more) {
+      float* d = smem + ((t + 1) & 1) * STAGE_FLOATS;
+      store_tile<TA>(d, tid, ra);
+      store_tile<TB>(d + OP_FLOATS, tid, rb);
+    }
+    __syncthreads();
+  }
+}
+
+template <bool TA, bool TB, bool FAST>
 __global__ void __launch_bounds__(NTHREADS, 2) gemm_f32_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform (scalar branches)
   const int wr = wave >> 1, wc = wave & 1;
   const int l31 = lane & 31, h = lane >> 5;
 
-  // XCD-aware, bijective tile remap (blocks b and b+8 share an XCD's L2)
+  // Tile order.  (1) XCD-aware bijective remap: blocks b and b+8 share an XCD (private 4 MiB L2),
+  // so each XCD walks a contiguous range of the linear tile order.  (2) The linear order is grouped:
+  // GROUP_M row-tiles x all column-tiles per group, walked row-tile-fastest, so the ~64 blocks
+  // resident on one XCD cover ~8x8 tiles and share 8 A slabs + 8 B slabs in that L2.
   const int nwg = g.tiles_m * g.tiles_n;
   const int bid = blockIdx.x;
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
   const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int tm = wg / g.tiles_n, tn = wg - tm * g.tiles_n;
+  constexpr int GROUP_M = 8;
+  const int per_group = GROUP_M * g.tiles_n;
+  const int gid = wg / per_group;
+  const int first_m = gid * GROUP_M;
+  const int gsz = min(g.tiles_m - first_m, GROUP_M);
+  const int in_g = wg - gid * per_group;
+  const int tm = first_m + in_g % gsz, tn = in_g / gsz;
   const int m0 = tm * BM, n0 = tn * BN;
   const int kbeg = blockIdx.y * g.kchunk;
   const int kend = min(g.K, kbeg + g.kchunk);
-  const int ntiles = (kend - kbeg + BK - 1) / BK;
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -134,44 +269,11 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_f32_kernel(GemmArgs g) {
 
   const float* gA = g.A + (long long)blockIdx.z * g.sA;
   const float* gB = g.B + (long long)blockIdx.z * g.sB;
-  f32x4 ra[4], rb[4];
-  load_tile<TA>(gA, g.lda, m0, g.M, kbeg, kend, g.vecA, tid, ra);
-  load_tile<TB>(gB, g.ldb, n0, g.N, kbeg, kend, g.vecB, tid, rb);
-  store_tile<TA>(smem, tid, ra);
-  store_tile<TB>(smem + OP_FLOATS, tid, rb);
-  __syncthreads();
-
-  for (int t = 0; t < ntiles; ++t) {
-    const float* sA = smem + (t & 1) * STAGE_FLOATS;
-    const float* sB = sA + OP_FLOATS;
-    const bool more = (t + 1) < ntiles;
-    if (more) {
-      const int k0 = kbeg + (t + 1) * BK;
-      load_tile<TA>(gA, g.lda, m0, g.M, k0, kend, g.vecA, tid, ra);
-      load_tile<TB>(gB, g.ldb, n0, g.N, k0, kend, g.vecB, tid, rb);
-    }
-#pragma unroll
-    for (int g8 = 0; g8 < BK / 8; ++g8) {
-      f32x4 af[2], bf[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) af[i] = read_frag<TA>(sA, wr * 64 + i * 32 + l31, g8, h);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) bf[j] = read_frag<TB>(sB, wc * 64 + j * 32 + l31, g8, h);
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
-    }
-    if (more) {
-      float* d = smem + ((t + 1) & 1) * STAGE_FLOATS;
-      store_tile<TA>(d, tid, ra);
-      store_tile<TB>(d + OP_FLOATS, tid, rb);
-    }
-    __syncthreads();
-  }
+  const bool all_valid = (m0 + wr * 64 + 32) < g.M && (n0 + wc * 64 + 32) < g.N;   // wave-uniform
+  if (all_valid)
+    gemm_mainloop<TA, TB, FAST, false>(g, smem, gA, gB, m0, n0, kbeg, kend, tid, wr, wc, l31, h, acc);
+  else
+    gemm_mainloop<TA, TB, FAST, true>(g, smem, gA, gB, m0, n0, kbeg, kend, tid, wr, wc, l31, h, acc);
 
   // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const bool to_slab = g.slab != nullptr;
@@ -220,17 +322,27 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int splits,
   }
 }
 
-template <bool TA, bool TB>
-int launch_gemm(const GemmArgs& g, dim3 grid, hipStream_t s, int kid) {
+template <bool TA, bool TB, bool FAST>
+int launch_gemm_impl(const GemmArgs& g, dim3 grid, hipStream_t s, int kid) {
   static bool attr_done = false;   // idempotent; a race only repeats the same call
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<TA, TB>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<TA, TB, FAST>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  VQF_LAUNCH(kid, (gemm_f32_kernel<TA, TB>), grid, dim3(NTHREADS), SMEM_BYTES, s, g);
+  VQF_LAUNCH(kid, (gemm_f32_kernel<TA, TB, FAST>), grid, dim3(NTHREADS), SMEM_BYTES, s, g);
   return vqf_last_error();
+}
+
+template <bool TA, bool TB>
+int launch_gemm(const GemmArgs& g, dim3 grid, hipStream_t s, int kid) {
+  // fast (clamped, unguarded) loaders need vector-aligned operands; K-major operands also need
+  // the row extent to be a multiple of 4 and at least 4
+  const bool okA = g.vecA && (!TA || (g.M % 4 == 0 && g.M >= 4));
+  const bool okB = g.vecB && (!TB || (g.N % 4 == 0 && g.N >= 4));
+  if (okA && okB) return launch_gemm_impl<TA, TB, true>(g, grid, s, kid);
+  return launch_gemm_impl<TA, TB, false>(g, grid, s, kid);
 }
 
 }  // namespace
