@@ -102,31 +102,34 @@ int vqf_relu_bwd_f32(const float* dX, const float* Y, int M, int C, float* dXpre
  * Image side    (S = L):  mfb.py:114-123 / mhb_coAtt.py:113-121
  */
 
-/* logits[m,g] = hid[m,:] . w2[g,:] + b2[g],  g in {0,1}; hid is (M,Hh). */
+/* logits[m,g] = hid[m,:] . w2[g,:] + b2[g],  g < G (G = 2 glimpses: mfb.py / mhb_coAtt.py;
+ * G = 1: hieCoAtten.py:40,47 fc_Whv/fc_Whq, modules.py:60 Attention_1.fc); hid is (M,Hh),
+ * w2 (G,Hh), logits (M,G). */
 int vqf_att_logits_fwd(const float* hid, const float* w2, const float* b2,
-                       int M, int Hh, float* logits, void* stream);
+                       int M, int Hh, int G, float* logits, void* stream);
 
-/* Backward of the two-logit head THROUGH the preceding ReLU:
- *   dhid_pre[m,j] = (dl[m,0] w2[0,j] + dl[m,1] w2[1,j]) * (hid[m,j] > 0)
+/* Backward of the G-logit head; relu_mask != 0: THROUGH the ReLU that produced hid:
+ *   dhid_pre[m,j] = (sum_g dl[m,g] w2[g,j]) * (hid[m,j] > 0  or 1)
  *   dw2[g,j] = sum_m dl[m,g] hid[m,j];  db2[g] = sum_m dl[m,g]
  *   dbias1[j] = sum_m dhid_pre[m,j]          (bias grad of the layer before)
  * ws: at least vqf_att_logits_bwd_ws_bytes(M,Hh). */
 size_t vqf_att_logits_bwd_ws_bytes(int M, int Hh);
 int vqf_att_logits_bwd(const float* dlogits, const float* hid, const float* w2,
-                       int M, int Hh, float* dhid_pre, float* dw2, float* db2,
-                       float* dbias1, void* ws, size_t ws_bytes, void* stream);
+                       int M, int Hh, int G, int relu_mask, float* dhid_pre, float* dw2,
+                       float* db2, float* dbias1, void* ws, size_t ws_bytes, void* stream);
 
 /* wts[n,g,:] = softmax_s(logits[n,:,g])   (unit_softmax != 0: wts == 1, the
  * mfb.py:84,118 singleton-axis softmax);  pooled[n, g*C + c] = sum_s wts[n,g,s] feat[n,s,c].
- * feat (N,S,C), logits (N*S,2), wts (N,2,S), pooled (N,2C).  S <= 1024. */
-int vqf_glimpse_pool_fwd(const float* feat, const float* logits, int N, int S, int C,
+ * feat (N,S,C), logits (N*S,G), wts (N,G,S), pooled (N,G*C).  S <= 1024, G in {1,2}. */
+int vqf_glimpse_pool_fwd(const float* feat, const float* logits, int N, int S, int C, int G,
                          int unit_softmax, float* wts, float* pooled, void* stream);
 
-/* Given dpooled (N,2C): dlogits (N*S,2) through the softmax (all zeros when
- * unit_softmax), and, if dfeat != NULL, dfeat[n,s,c] = sum_g wts[n,g,s] dpooled[n,gC+c]
- * (overwrites; the question side needs it, the image is data). */
-int vqf_glimpse_pool_bwd(const float* dpooled, const float* feat, const float* wts,
-                         int N, int S, int C, int unit_softmax,
+/* Given dpooled (N,G*C) and, optionally, dwts_extra (N,G,S) = gradient arriving through the
+ * returned attention weights (hieCoAtten.py:55 returns av/aq; networks.py:64-66 feeds them to
+ * fc): dlogits (N*S,G) through the softmax (all zeros when unit_softmax), and, if dfeat != NULL,
+ * dfeat[n,s,c] = sum_g wts[n,g,s] dpooled[n,gC+c] (overwrites; the image is data). */
+int vqf_glimpse_pool_bwd(const float* dpooled, const float* dwts_extra, const float* feat,
+                         const float* wts, int N, int S, int C, int G, int unit_softmax,
                          float* dlogits, float* dfeat, void* stream);
 
 /* --------------------------------------------------------------------------
@@ -181,6 +184,24 @@ int vqf_mfb_fuse_bwd(const float* dY, const float* dzdrop, const float* Y, const
                      int N, int L, int O,
                      float* dP, float* dq, float* dcascade, float* dbiasP,
                      void* ws, size_t ws_bytes, void* stream);
+
+/* --------------------------------------------------------------------------
+ * Element-wise stages of HieCoAtten / AttentionNet.  n % 4 == 0, 16-byte aligned pointers.
+ * keep: uint8 keep-mask or NULL (then Philox4x32-10(seed, index/4), as in vqf_mfb_fuse_*).
+ */
+/* y = x * keep / (1-p)      F.dropout, hieCoAtten.py:26,28; networks.py:22,24,55,57.
+ * Its own backward: call it with x = dy and the same keep/seed. */
+int vqf_dropout_f32(const float* x, const uint8_t* keep, uint64_t seed, float p_drop,
+                    long long n, float* y, void* stream);
+/* y = dropout(tanh(a + b))  (b may be NULL)   hieCoAtten.py:32-33,38-39,45-46 */
+int vqf_tanh_dropout_fwd(const float* a, const float* b, const uint8_t* keep, uint64_t seed,
+                         float p_drop, long long n, float* y, void* stream);
+/* dx = dy * keep/(1-p) * (1 - tanh^2), tanh recovered from the saved output y */
+int vqf_tanh_dropout_bwd(const float* dy, const float* y, const uint8_t* keep, uint64_t seed,
+                         float p_drop, long long n, float* dx, void* stream);
+/* softmax over the last axis of (R,W) and its backward   modules.py:91-92 */
+int vqf_softmax_rows_fwd(const float* x, int R, int W, float* y, void* stream);
+int vqf_softmax_rows_bwd(const float* dy, const float* y, int R, int W, float* dx, void* stream);
 
 /* --------------------------------------------------------------------------
  * Opt-in profiler: hipEvent pairs around every kernel launch, on the stream

@@ -30,6 +30,7 @@ def _make_model():
 
 def _worker(rank, world, port, bucket_bytes, q):
     sys.path.insert(0, ROOT)
+    torch.set_num_threads(1)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
                       WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     from importlib import import_module
@@ -58,21 +59,36 @@ def _worker(rank, world, port, bucket_bytes, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("bucket_bytes", [64 << 20, 256])
-def test_allreduce_equals_full_batch_gradient(bucket_bytes):
-    world, port = 2, _free_port()
+def _run_world(world, bucket_bytes):
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, bucket_bytes, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = {}
-    for _ in range(world):
-        rank, params, outs, nb = q.get(timeout=120)
-        res[rank] = (params, outs, nb)
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    try:
+        for _ in range(world):
+            rank, params, outs, nb = q.get(timeout=300)
+            res[rank] = (params, outs, nb)
+        for p in procs:
+            p.join(timeout=120)
+            if p.exitcode != 0:
+                return None
+    except Exception:
+        return None
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+    return res
+
+
+@pytest.mark.parametrize("bucket_bytes", [64 << 20, 256])
+def test_allreduce_equals_full_batch_gradient(bucket_bytes):
+    world = 2
+    res = _run_world(world, bucket_bytes) or _run_world(world, bucket_bytes)   # one retry: rendezvous port race
+    assert res is not None, "2-rank gloo run failed twice"
     if bucket_bytes == 256:
         assert res[0][2] > 1                              # several buckets exercised
     # reference: single process, full batch, rank-0 initial weights

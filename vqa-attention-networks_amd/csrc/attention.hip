@@ -1,23 +1,24 @@
 // Attention heads of the co-attention ladder (HBM-bound, wave64 reductions).
 //
-//   question side (S = T tokens):  mfb.py:81-89   / mhb_coAtt.py:83-91
-//   image side    (S = 196 regions, C = 2048): mfb.py:114-123 / mhb_coAtt.py:113-121
+//   question side (S = T tokens):  mfb.py:81-89   / mhb_coAtt.py:83-91          (G = 2 glimpses)
+//   image side    (S = 196 regions, C = 2048): mfb.py:114-123 / mhb_coAtt.py:113-121   (G = 2)
+//   HieCoAtten av/aq (hieCoAtten.py:40-42,47-49) and Attention_1 (modules.py:60-65)     (G = 1)
 //
-// att_logits_*   : hidden (M,Hh) -> 2 logits per row, and its backward through
-//                  the preceding ReLU (one pass over the hidden activations).
-// glimpse_pool_* : softmax over the S positions of a sample (or the reference's
-//                  singleton-axis softmax == 1, mfb.py:84,118) and the two
-//                  glimpse-weighted sums over the (N,S,C) feature tensor.  The
-//                  image tensor is streamed exactly once per pass with 16-byte
-//                  coalesced loads along C; softmax rows (S <= 1024) live in LDS
-//                  and are reduced with wavefront shuffles.
+// att_logits_*   : hidden (M,Hh) -> G logits per row, and its backward, optionally through the
+//                  preceding ReLU (one pass over the hidden activations).
+// glimpse_pool_* : softmax over the S positions of a sample (or the reference's singleton-axis
+//                  softmax == 1, mfb.py:84,118) and the G glimpse-weighted sums over the (N,S,C)
+//                  feature tensor.  The image tensor is streamed exactly once per pass with 16-byte
+//                  coalesced loads along C; softmax rows (S <= 1024) live in LDS and are reduced
+//                  with wavefront shuffles.
 #include "common.h"
 
 namespace {
 
 constexpr int MAXS = 1024;
 
-// ---- logits[m,g] = hid[m,:] . w2[g,:] + b2[g]; one wave per row ------------
+// ---- logits[m,g] = hid[m,:] . w[g,:] + b[g]; one wave per row ------------------------------
+template <int G>
 __global__ void att_logits_fwd_kernel(const float* __restrict__ hid, const float* __restrict__ w2,
                                       const float* __restrict__ b2, int M, int Hh,
                                       float* __restrict__ logits) {
@@ -25,113 +26,122 @@ __global__ void att_logits_fwd_kernel(const float* __restrict__ hid, const float
   if (row >= M) return;
   const int lane = threadIdx.x & 63;
   const float* h = hid + (long long)row * Hh;
-  float a0 = 0.f, a1 = 0.f;
+  float a[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) a[g] = 0.f;
   if ((Hh & 3) == 0 && aligned16_dev(h) && aligned16_dev(w2)) {
     for (int c = lane * 4; c < Hh; c += 256) {
       const f32x4 x = *reinterpret_cast<const f32x4*>(h + c);
-      const f32x4 u = *reinterpret_cast<const f32x4*>(w2 + c);
-      const f32x4 v = *reinterpret_cast<const f32x4*>(w2 + Hh + c);
-      a0 += x[0] * u[0] + x[1] * u[1] + x[2] * u[2] + x[3] * u[3];
-      a1 += x[0] * v[0] + x[1] * v[1] + x[2] * v[2] + x[3] * v[3];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const f32x4 u = *reinterpret_cast<const f32x4*>(w2 + g * Hh + c);
+        a[g] += x[0] * u[0] + x[1] * u[1] + x[2] * u[2] + x[3] * u[3];
+      }
     }
   } else {
-    for (int c = lane; c < Hh; c += 64) { a0 += h[c] * w2[c]; a1 += h[c] * w2[Hh + c]; }
+    for (int c = lane; c < Hh; c += 64)
+#pragma unroll
+      for (int g = 0; g < G; ++g) a[g] += h[c] * w2[g * Hh + c];
   }
-  a0 = wave_sum(a0);
-  a1 = wave_sum(a1);
-  if (lane == 0) {
-    logits[2 * (long long)row] = a0 + b2[0];
-    logits[2 * (long long)row + 1] = a1 + b2[1];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    a[g] = wave_sum(a[g]);
+    if (lane == 0) logits[(long long)G * row + g] = a[g] + b2[g];
   }
 }
 
-// ---- backward of the 2-logit head through the ReLU -------------------------
-// block = 256 threads, thread = 4 consecutive hidden columns (per 1024-column
-// chunk); a block folds LB_ROWS rows and writes one partial slab row:
-//   part[b][0..Hh)      sum_m dl[m,0] * hid[m,j]
-//   part[b][Hh..2Hh)    sum_m dl[m,1] * hid[m,j]
-//   part[b][2Hh..3Hh)   sum_m dhid_pre[m,j]
-//   part[b][3Hh..3Hh+2) sum_m dl[m,g]
+// ---- backward of the G-logit head, optionally through the ReLU in front of it ----------------
+// block = 256 threads, thread = 4 consecutive hidden columns (per 1024-column chunk); a block folds
+// LB_ROWS rows and writes one partial slab row of width (G+1)*Hh + 4:
+//   part[b][g*Hh + j]      sum_m dl[m,g] * hid[m,j]            (g < G)
+//   part[b][G*Hh + j]      sum_m dhid_pre[m,j]
+//   part[b][(G+1)*Hh + g]  sum_m dl[m,g]
 constexpr int LB_ROWS = 128;
 
+template <int G, bool RELU>
 __global__ void att_logits_bwd_kernel(const float* __restrict__ dl, const float* __restrict__ hid,
                                       const float* __restrict__ w2, int M, int Hh,
                                       float* __restrict__ dhid_pre, float* __restrict__ part) {
   const int r0 = blockIdx.x * LB_ROWS, r1 = min(M, r0 + LB_ROWS);
-  const int pw = 3 * Hh + 4;
+  const int pw = (G + 1) * Hh + 4;
   float* prow = part + (long long)blockIdx.x * pw;
   const bool vec = ((Hh & 3) == 0) && aligned16_dev(hid) && aligned16_dev(dhid_pre);
   for (int c = threadIdx.x * 4; c < Hh; c += 1024) {
     const int nc = min(4, Hh - c);
-    float u[4], v[4], s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0};
+    float u[G][4], s[G][4], sb[4] = {0, 0, 0, 0};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      u[j] = j < nc ? w2[c + j] : 0.f;
-      v[j] = j < nc ? w2[Hh + c + j] : 0.f;
-    }
-    if (vec) {
-      for (int r = r0; r < r1; ++r) {
-        const float d0 = dl[2 * (long long)r], d1 = dl[2 * (long long)r + 1];
-        const f32x4 x = *reinterpret_cast<const f32x4*>(hid + (long long)r * Hh + c);
-        f32x4 gp;
+    for (int g = 0; g < G; ++g)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          gp[j] = x[j] > 0.f ? (d0 * u[j] + d1 * v[j]) : 0.f;
-          s0[j] += d0 * x[j];
-          s1[j] += d1 * x[j];
-          sb[j] += gp[j];
-        }
-        *reinterpret_cast<f32x4*>(dhid_pre + (long long)r * Hh + c) = gp;
+      for (int j = 0; j < 4; ++j) {
+        u[g][j] = j < nc ? w2[g * Hh + c + j] : 0.f;
+        s[g][j] = 0.f;
       }
-    } else {
-      for (int r = r0; r < r1; ++r) {
-        const float d0 = dl[2 * (long long)r], d1 = dl[2 * (long long)r + 1];
-        const float* h = hid + (long long)r * Hh + c;
-        float* o = dhid_pre + (long long)r * Hh + c;
+    for (int r = r0; r < r1; ++r) {
+      float d[G];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (j < nc) {
-            const float x = h[j];
-            const float gpre = x > 0.f ? (d0 * u[j] + d1 * v[j]) : 0.f;
-            o[j] = gpre;
-            s0[j] += d0 * x;
-            s1[j] += d1 * x;
-            sb[j] += gpre;
-          }
-        }
+      for (int g = 0; g < G; ++g) d[g] = dl[(long long)G * r + g];
+      float x[4] = {0, 0, 0, 0}, gp[4];
+      const float* hp = hid + (long long)r * Hh + c;
+      if (vec) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(hp);
+        x[0] = xv[0]; x[1] = xv[1]; x[2] = xv[2]; x[3] = xv[3];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (j < nc) x[j] = hp[j];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < G; ++g) { t += d[g] * u[g][j]; s[g][j] += d[g] * x[j]; }
+        gp[j] = (!RELU || x[j] > 0.f) ? t : 0.f;
+        sb[j] += gp[j];
+      }
+      float* o = dhid_pre + (long long)r * Hh + c;
+      if (vec) {
+        f32x4 gv = {gp[0], gp[1], gp[2], gp[3]};
+        *reinterpret_cast<f32x4*>(o) = gv;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (j < nc) o[j] = gp[j];
       }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      if (j < nc) { prow[c + j] = s0[j]; prow[Hh + c + j] = s1[j]; prow[2 * Hh + c + j] = sb[j]; }
+      if (j < nc) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) prow[g * Hh + c + j] = s[g][j];
+        prow[G * Hh + c + j] = sb[j];
+      }
   }
-  if (threadIdx.x < 2) {
+  if (threadIdx.x < G) {
     float a = 0.f;
-    for (int r = r0; r < r1; ++r) a += dl[2 * (long long)r + threadIdx.x];
-    prow[3 * Hh + threadIdx.x] = a;
+    for (int r = r0; r < r1; ++r) a += dl[(long long)G * r + threadIdx.x];
+    prow[(G + 1) * Hh + threadIdx.x] = a;
   }
 }
 
-// ---- softmax over S + two glimpse sums -------------------------------------
+// ---- softmax over S + G glimpse sums ---------------------------------------------------------
 // grid (ceil(C/1024), N); thread = 4 consecutive channels
+template <int G>
 __global__ void glimpse_pool_fwd_kernel(const float* __restrict__ feat,
                                         const float* __restrict__ logits, int N, int S, int C,
                                         int unit, float* __restrict__ wts,
                                         float* __restrict__ pooled) {
-  __shared__ float w[2][MAXS];
+  __shared__ float w[G][MAXS];
   const int n = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (wave < 2) {
+  if (wave < G) {
     const int g = wave;
-    const float* lg = logits + (long long)n * S * 2 + g;
+    const float* lg = logits + (long long)n * S * G + g;
     if (unit) {
       for (int s = lane; s < S; s += 64) w[g][s] = 1.0f;
     } else {
       float mx = -INFINITY;
-      for (int s = lane; s < S; s += 64) mx = fmaxf(mx, lg[2 * s]);
+      for (int s = lane; s < S; s += 64) mx = fmaxf(mx, lg[G * s]);
       mx = wave_max(mx);
       float sum = 0.f;
-      for (int s = lane; s < S; s += 64) { const float e = expf(lg[2 * s] - mx); w[g][s] = e; sum += e; }
+      for (int s = lane; s < S; s += 64) { const float e = expf(lg[G * s] - mx); w[g][s] = e; sum += e; }
       sum = wave_sum(sum);
       const float rs = 1.0f / sum;
       for (int s = lane; s < S; s += 64) w[g][s] *= rs;
@@ -139,14 +149,16 @@ __global__ void glimpse_pool_fwd_kernel(const float* __restrict__ feat,
   }
   __syncthreads();
   if (blockIdx.x == 0 && wts)
-    for (int i = tid; i < 2 * S; i += blockDim.x)
-      wts[(long long)n * 2 * S + i] = w[i / S][i % S];
+    for (int i = tid; i < G * S; i += blockDim.x)
+      wts[(long long)n * G * S + i] = w[i / S][i % S];
 
   const int c = (blockIdx.x * blockDim.x + tid) * 4;
   if (c >= C) return;
   const float* f = feat + (long long)n * S * C + c;
-  const bool vec = ((C & 3) == 0) && aligned16_dev(feat);
-  f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+  const bool vec = ((C & 3) == 0) && aligned16_dev(feat) && aligned16_dev(pooled);
+  f32x4 a[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) a[g] = f32x4{0, 0, 0, 0};
   if (vec) {
     int s = 0;
     for (; s + 3 < S; s += 4) {
@@ -154,73 +166,88 @@ __global__ void glimpse_pool_fwd_kernel(const float* __restrict__ feat,
       const f32x4 x1 = *reinterpret_cast<const f32x4*>(f + (long long)(s + 1) * C);
       const f32x4 x2 = *reinterpret_cast<const f32x4*>(f + (long long)(s + 2) * C);
       const f32x4 x3 = *reinterpret_cast<const f32x4*>(f + (long long)(s + 3) * C);
-      a0 += x0 * w[0][s]; a1 += x0 * w[1][s];
-      a0 += x1 * w[0][s + 1]; a1 += x1 * w[1][s + 1];
-      a0 += x2 * w[0][s + 2]; a1 += x2 * w[1][s + 2];
-      a0 += x3 * w[0][s + 3]; a1 += x3 * w[1][s + 3];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        a[g] += x0 * w[g][s];
+        a[g] += x1 * w[g][s + 1];
+        a[g] += x2 * w[g][s + 2];
+        a[g] += x3 * w[g][s + 3];
+      }
     }
     for (; s < S; ++s) {
       const f32x4 x = *reinterpret_cast<const f32x4*>(f + (long long)s * C);
-      a0 += x * w[0][s]; a1 += x * w[1][s];
+#pragma unroll
+      for (int g = 0; g < G; ++g) a[g] += x * w[g][s];
     }
-    *reinterpret_cast<f32x4*>(pooled + (long long)n * 2 * C + c) = a0;
-    *reinterpret_cast<f32x4*>(pooled + (long long)n * 2 * C + C + c) = a1;
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+      *reinterpret_cast<f32x4*>(pooled + (long long)n * G * C + g * C + c) = a[g];
   } else {
     const int nc = min(4, C - c);
     for (int s = 0; s < S; ++s)
       for (int j = 0; j < nc; ++j) {
         const float x = f[(long long)s * C + j];
-        a0[j] += x * w[0][s]; a1[j] += x * w[1][s];
+#pragma unroll
+        for (int g = 0; g < G; ++g) a[g][j] += x * w[g][s];
       }
-    for (int j = 0; j < nc; ++j) {
-      pooled[(long long)n * 2 * C + c + j] = a0[j];
-      pooled[(long long)n * 2 * C + C + c + j] = a1[j];
-    }
+    for (int j = 0; j < nc; ++j)
+#pragma unroll
+      for (int g = 0; g < G; ++g) pooled[(long long)n * G * C + g * C + c + j] = a[g][j];
   }
 }
 
-// block per sample; wave per position s (strided); then the softmax backward
+// block per sample; wave per position s (strided); then the softmax backward.
+// dwts_extra (N,G,S) or null: gradient arriving through the returned attention weights.
+template <int G>
 __global__ void glimpse_pool_bwd_kernel(const float* __restrict__ dpooled,
+                                        const float* __restrict__ dwts_extra,
                                         const float* __restrict__ feat,
                                         const float* __restrict__ wts, int N, int S, int C, int unit,
                                         float* __restrict__ dlogits, float* __restrict__ dfeat) {
-  __shared__ float dw[2][MAXS];
-  __shared__ float ws[2][MAXS];
+  __shared__ float dw[G][MAXS];
+  __shared__ float ws[G][MAXS];
   const int n = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = blockDim.x >> 6;
-  for (int i = tid; i < 2 * S; i += blockDim.x) ws[i / S][i % S] = wts[(long long)n * 2 * S + i];
+  for (int i = tid; i < G * S; i += blockDim.x) ws[i / S][i % S] = wts[(long long)n * G * S + i];
   __syncthreads();
-  const float* dp0 = dpooled + (long long)n * 2 * C;
-  const float* dp1 = dp0 + C;
+  const float* dp = dpooled + (long long)n * G * C;
   const bool vec = ((C & 3) == 0) && aligned16_dev(feat) && aligned16_dev(dpooled) &&
                    (dfeat == nullptr || aligned16_dev(dfeat));
   for (int s = wave; s < S; s += nwave) {
     const float* f = feat + ((long long)n * S + s) * C;
     float* df = dfeat ? dfeat + ((long long)n * S + s) * C : nullptr;
-    const float w0 = ws[0][s], w1 = ws[1][s];
-    float a0 = 0.f, a1 = 0.f;
+    float a[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) a[g] = 0.f;
     if (vec) {
       for (int c = lane * 4; c < C; c += 256) {
         const f32x4 x = *reinterpret_cast<const f32x4*>(f + c);
-        const f32x4 p = *reinterpret_cast<const f32x4*>(dp0 + c);
-        const f32x4 q = *reinterpret_cast<const f32x4*>(dp1 + c);
-        a0 += x[0] * p[0] + x[1] * p[1] + x[2] * p[2] + x[3] * p[3];
-        a1 += x[0] * q[0] + x[1] * q[1] + x[2] * q[2] + x[3] * q[3];
-        if (df) *reinterpret_cast<f32x4*>(df + c) = p * w0 + q * w1;
+        f32x4 o = {0, 0, 0, 0};
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const f32x4 p = *reinterpret_cast<const f32x4*>(dp + g * C + c);
+          a[g] += x[0] * p[0] + x[1] * p[1] + x[2] * p[2] + x[3] * p[3];
+          o += p * ws[g][s];
+        }
+        if (df) *reinterpret_cast<f32x4*>(df + c) = o;
       }
     } else {
       for (int c = lane; c < C; c += 64) {
         const float x = f[c];
-        a0 += x * dp0[c]; a1 += x * dp1[c];
-        if (df) df[c] = w0 * dp0[c] + w1 * dp1[c];
+        float o = 0.f;
+#pragma unroll
+        for (int g = 0; g < G; ++g) { a[g] += x * dp[g * C + c]; o += ws[g][s] * dp[g * C + c]; }
+        if (df) df[c] = o;
       }
     }
-    a0 = wave_sum(a0);
-    a1 = wave_sum(a1);
-    if (lane == 0) { dw[0][s] = a0; dw[1][s] = a1; }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      a[g] = wave_sum(a[g]);
+      if (lane == 0) dw[g][s] = a[g] + (dwts_extra ? dwts_extra[((long long)n * G + g) * S + s] : 0.f);
+    }
   }
   __syncthreads();
-  if (wave < 2) {
+  if (wave < G) {
     const int g = wave;
     float dot = 0.f;
     if (!unit) {
@@ -230,7 +257,7 @@ __global__ void glimpse_pool_bwd_kernel(const float* __restrict__ dpooled,
     for (int s = lane; s < S; s += 64) {
       // softmax over a singleton axis: y == 1 and dy - sum(dy*y) == 0 exactly
       const float d = unit ? 0.f : ws[g][s] * (dw[g][s] - dot);
-      dlogits[((long long)n * S + s) * 2 + g] = d;
+      dlogits[((long long)n * S + s) * G + g] = d;
     }
   }
 }
@@ -239,63 +266,84 @@ __global__ void glimpse_pool_bwd_kernel(const float* __restrict__ dpooled,
 
 extern "C" {
 
-int vqf_att_logits_fwd(const float* hid, const float* w2, const float* b2, int M, int Hh,
+int vqf_att_logits_fwd(const float* hid, const float* w2, const float* b2, int M, int Hh, int G,
                        float* logits, void* stream) {
   if (!hid || !w2 || !b2 || !logits || M <= 0 || Hh <= 0) return VQF_E_BADARG;
-  VQF_LAUNCH(KID_ATT_LOGITS_FWD, att_logits_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0,
-             (hipStream_t)stream, hid, w2, b2, M, Hh, logits);
+  if (G != 1 && G != 2) return VQF_E_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  if (G == 2)
+    VQF_LAUNCH(KID_ATT_LOGITS_FWD, att_logits_fwd_kernel<2>, dim3((M + 3) / 4), dim3(256), 0, s, hid,
+               w2, b2, M, Hh, logits);
+  else
+    VQF_LAUNCH(KID_ATT_LOGITS_FWD, att_logits_fwd_kernel<1>, dim3((M + 3) / 4), dim3(256), 0, s, hid,
+               w2, b2, M, Hh, logits);
   return vqf_last_error();
 }
 
 size_t vqf_att_logits_bwd_ws_bytes(int M, int Hh) {
   if (M <= 0 || Hh <= 0) return 0;
-  return (size_t)((M + LB_ROWS - 1) / LB_ROWS) * (size_t)(3 * Hh + 4) * sizeof(float) +
-         (size_t)(3 * Hh + 4) * sizeof(float);
+  return (size_t)((M + LB_ROWS - 1) / LB_ROWS + 1) * (size_t)(3 * Hh + 4) * sizeof(float);
 }
 
-int vqf_att_logits_bwd(const float* dlogits, const float* hid, const float* w2, int M, int Hh,
-                       float* dhid_pre, float* dw2, float* db2, float* dbias1, void* ws,
-                       size_t ws_bytes, void* stream) {
+int vqf_att_logits_bwd(const float* dlogits, const float* hid, const float* w2, int M, int Hh, int G,
+                       int relu_mask, float* dhid_pre, float* dw2, float* db2, float* dbias1,
+                       void* ws, size_t ws_bytes, void* stream) {
   if (!dlogits || !hid || !w2 || !dhid_pre || !dw2 || !db2 || M <= 0 || Hh <= 0)
     return VQF_E_BADARG;
+  if (G != 1 && G != 2) return VQF_E_UNSUPPORTED;
   if (!ws || ws_bytes < vqf_att_logits_bwd_ws_bytes(M, Hh)) return VQF_E_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   const int nb = (M + LB_ROWS - 1) / LB_ROWS;
-  const int pw = 3 * Hh + 4;
+  const int pw = (G + 1) * Hh + 4;
   float* part = (float*)ws;
   float* red = part + (size_t)nb * pw;     // reduced row [pw]
-  VQF_LAUNCH(KID_ATT_LOGITS_BWD, att_logits_bwd_kernel, dim3(nb), dim3(256), 0, s, dlogits, hid,
-             w2, M, Hh, dhid_pre, part);
+#define VQF_LB(G_, R_)                                                                           \
+  VQF_LAUNCH(KID_ATT_LOGITS_BWD, (att_logits_bwd_kernel<G_, R_>), dim3(nb), dim3(256), 0, s,     \
+             dlogits, hid, w2, M, Hh, dhid_pre, part)
+  if (G == 2) { if (relu_mask) VQF_LB(2, true); else VQF_LB(2, false); }
+  else        { if (relu_mask) VQF_LB(1, true); else VQF_LB(1, false); }
+#undef VQF_LB
   int rc = vqf_last_error();
   if (rc) return rc;
   rc = vqf_group_reduce_f32(part, 1, nb, pw, red, stream);
   if (rc) return rc;
-  hipError_t e = hipMemcpyAsync(dw2, red, (size_t)2 * Hh * sizeof(float), hipMemcpyDeviceToDevice, s);
+  hipError_t e = hipMemcpyAsync(dw2, red, (size_t)G * Hh * sizeof(float), hipMemcpyDeviceToDevice, s);
   if (e != hipSuccess) return (int)e;
   if (dbias1) {
-    e = hipMemcpyAsync(dbias1, red + 2 * Hh, (size_t)Hh * sizeof(float), hipMemcpyDeviceToDevice, s);
+    e = hipMemcpyAsync(dbias1, red + G * Hh, (size_t)Hh * sizeof(float), hipMemcpyDeviceToDevice, s);
     if (e != hipSuccess) return (int)e;
   }
-  e = hipMemcpyAsync(db2, red + 3 * Hh, 2 * sizeof(float), hipMemcpyDeviceToDevice, s);
+  e = hipMemcpyAsync(db2, red + (G + 1) * Hh, G * sizeof(float), hipMemcpyDeviceToDevice, s);
   return e == hipSuccess ? VQF_OK : (int)e;
 }
 
-int vqf_glimpse_pool_fwd(const float* feat, const float* logits, int N, int S, int C,
+int vqf_glimpse_pool_fwd(const float* feat, const float* logits, int N, int S, int C, int G,
                          int unit_softmax, float* wts, float* pooled, void* stream) {
   if (!feat || !logits || !pooled || N <= 0 || S <= 0 || C <= 0) return VQF_E_BADARG;
-  if (S > MAXS) return VQF_E_UNSUPPORTED;
+  if (S > MAXS || (G != 1 && G != 2) || N > 65535) return VQF_E_UNSUPPORTED;
   dim3 grid((C + 1023) / 1024, N);
-  VQF_LAUNCH(KID_GLIMPSE_FWD, glimpse_pool_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream,
-             feat, logits, N, S, C, unit_softmax, wts, pooled);
+  hipStream_t s = (hipStream_t)stream;
+  if (G == 2)
+    VQF_LAUNCH(KID_GLIMPSE_FWD, glimpse_pool_fwd_kernel<2>, grid, dim3(256), 0, s, feat, logits, N, S,
+               C, unit_softmax, wts, pooled);
+  else
+    VQF_LAUNCH(KID_GLIMPSE_FWD, glimpse_pool_fwd_kernel<1>, grid, dim3(256), 0, s, feat, logits, N, S,
+               C, unit_softmax, wts, pooled);
   return vqf_last_error();
 }
 
-int vqf_glimpse_pool_bwd(const float* dpooled, const float* feat, const float* wts, int N, int S,
-                         int C, int unit_softmax, float* dlogits, float* dfeat, void* stream) {
+int vqf_glimpse_pool_bwd(const float* dpooled, const float* dwts_extra, const float* feat,
+                         const float* wts, int N, int S, int C, int G, int unit_softmax,
+                         float* dlogits, float* dfeat, void* stream) {
   if (!dpooled || !feat || !wts || !dlogits || N <= 0 || S <= 0 || C <= 0) return VQF_E_BADARG;
-  if (S > MAXS) return VQF_E_UNSUPPORTED;
-  VQF_LAUNCH(KID_GLIMPSE_BWD, glimpse_pool_bwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream,
-             dpooled, feat, wts, N, S, C, unit_softmax, dlogits, dfeat);
+  if (S > MAXS || (G != 1 && G != 2)) return VQF_E_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  if (G == 2)
+    VQF_LAUNCH(KID_GLIMPSE_BWD, glimpse_pool_bwd_kernel<2>, dim3(N), dim3(256), 0, s, dpooled,
+               dwts_extra, feat, wts, N, S, C, unit_softmax, dlogits, dfeat);
+  else
+    VQF_LAUNCH(KID_GLIMPSE_BWD, glimpse_pool_bwd_kernel<1>, dim3(N), dim3(256), 0, s, dpooled,
+               dwts_extra, feat, wts, N, S, C, unit_softmax, dlogits, dfeat);
   return vqf_last_error();
 }
 

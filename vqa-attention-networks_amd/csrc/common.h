@@ -27,6 +27,11 @@ enum VqfKernelId {
   KID_ROWDOT,
   KID_L2_BWD_COEF,
   KID_MFB_FUSE_BWD,
+  KID_DROPOUT,
+  KID_TANH_DROP_FWD,
+  KID_TANH_DROP_BWD,
+  KID_SOFTMAX_FWD,
+  KID_SOFTMAX_BWD,
   KID_COUNT
 };
 

@@ -1,0 +1,152 @@
+// Element-wise stages of HieCoAtten / AttentionNet (HBM-bound, 16-byte accesses):
+//   dropout                      hieCoAtten.py:26,28   networks.py:22,24,55,57   (F.dropout, p=0.5)
+//   y = dropout(tanh(a [+ b]))   hieCoAtten.py:32-33,38-39,45-46
+//   row softmax over the last axis   modules.py:91-92 (Attention_2)
+// Dropout masks are Philox4x32-10(seed, element index / 4), regenerated in the backward, or an
+// explicit uint8 keep-mask (parity tests).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ void keep4(const uint8_t* __restrict__ keep, uint64_t seed, uint32_t thr,
+                                      float inv_keep, long long i4, float (&sc)[4]) {
+  if (keep) {
+    const uint32_t w = *reinterpret_cast<const uint32_t*>(keep + 4 * i4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sc[j] = ((w >> (8 * j)) & 0xFFu) ? inv_keep : 0.f;
+  } else if (thr != 0u) {
+    const uint4 r = philox4x32_10((uint64_t)i4, seed);
+    sc[0] = r.x >= thr ? inv_keep : 0.f;
+    sc[1] = r.y >= thr ? inv_keep : 0.f;
+    sc[2] = r.z >= thr ? inv_keep : 0.f;
+    sc[3] = r.w >= thr ? inv_keep : 0.f;
+  } else {
+    sc[0] = sc[1] = sc[2] = sc[3] = 1.0f;
+  }
+}
+
+// MODE 0: y = x * sc                      (dropout forward; also its backward with x = dy)
+// MODE 1: y = tanh(a + b) * sc            (b may be null)
+// MODE 2: dx = dy * sc * (1 - t^2), t = y / sc   (backward of MODE 1 given its output y)
+template <int MODE>
+__global__ void ew_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                          const uint8_t* __restrict__ keep, uint64_t seed, uint32_t thr,
+                          float inv_keep, long long n4, float* __restrict__ out) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float sc[4];
+    keep4(keep, seed, thr, inv_keep, i, sc);
+    f32x4 x = *reinterpret_cast<const f32x4*>(a + 4 * i);
+    f32x4 y;
+    if (MODE == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) y[j] = x[j] * sc[j];
+    } else if (MODE == 1) {
+      if (b) x += *reinterpret_cast<const f32x4*>(b + 4 * i);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) y[j] = tanhf(x[j]) * sc[j];
+    } else {
+      const f32x4 yy = *reinterpret_cast<const f32x4*>(b + 4 * i);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float t = sc[j] > 0.f ? yy[j] / sc[j] : 0.f;
+        y[j] = x[j] * sc[j] * (1.0f - t * t);
+      }
+    }
+    *reinterpret_cast<f32x4*>(out + 4 * i) = y;
+  }
+}
+
+// one wave per row
+__global__ void softmax_rows_fwd_kernel(const float* __restrict__ x, int R, int W, float* __restrict__ y) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const int lane = threadIdx.x & 63;
+  const float* p = x + (long long)row * W;
+  float* q = y + (long long)row * W;
+  float mx = -INFINITY;
+  for (int c = lane; c < W; c += 64) mx = fmaxf(mx, p[c]);
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int c = lane; c < W; c += 64) { const float e = expf(p[c] - mx); q[c] = e; sum += e; }
+  sum = wave_sum(sum);
+  const float rs = 1.0f / sum;
+  for (int c = lane; c < W; c += 64) q[c] *= rs;
+}
+
+__global__ void softmax_rows_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, int R,
+                                        int W, float* __restrict__ dx) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const int lane = threadIdx.x & 63;
+  const float* g = dy + (long long)row * W;
+  const float* p = y + (long long)row * W;
+  float dot = 0.f;
+  for (int c = lane; c < W; c += 64) dot += g[c] * p[c];
+  dot = wave_sum(dot);
+  for (int c = lane; c < W; c += 64) dx[(long long)row * W + c] = p[c] * (g[c] - dot);
+}
+
+int ew_args_ok(const void* a, const void* out, const uint8_t* keep, float p, long long n) {
+  if (!a || !out || n <= 0) return VQF_E_BADARG;
+  if (n % 4) return VQF_E_UNSUPPORTED;
+  if (p < 0.f || p >= 1.f) return VQF_E_BADARG;
+  if (!aligned16(a) || !aligned16(out) || (keep && (((uintptr_t)keep) & 3))) return VQF_E_ALIGN;
+  return VQF_OK;
+}
+
+template <int MODE>
+int ew_launch(int kid, const float* a, const float* b, const uint8_t* keep, uint64_t seed, float p,
+              long long n, float* out, void* stream) {
+  const uint32_t thr = (keep || p == 0.f) ? 0u : drop_threshold_host(p);
+  const float inv_keep = (keep || p > 0.f) ? 1.0f / (1.0f - p) : 1.0f;
+  const long long n4 = n / 4;
+  long long blocks = (n4 + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  VQF_LAUNCH(kid, ew_kernel<MODE>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, b, keep,
+             seed, thr, inv_keep, n4, out);
+  return vqf_last_error();
+}
+
+}  // namespace
+
+extern "C" {
+
+int vqf_dropout_f32(const float* x, const uint8_t* keep, uint64_t seed, float p_drop, long long n,
+                    float* y, void* stream) {
+  int rc = ew_args_ok(x, y, keep, p_drop, n);
+  if (rc) return rc;
+  return ew_launch<0>(KID_DROPOUT, x, nullptr, keep, seed, p_drop, n, y, stream);
+}
+
+int vqf_tanh_dropout_fwd(const float* a, const float* b, const uint8_t* keep, uint64_t seed,
+                         float p_drop, long long n, float* y, void* stream) {
+  int rc = ew_args_ok(a, y, keep, p_drop, n);
+  if (rc) return rc;
+  if (b && !aligned16(b)) return VQF_E_ALIGN;
+  return ew_launch<1>(KID_TANH_DROP_FWD, a, b, keep, seed, p_drop, n, y, stream);
+}
+
+int vqf_tanh_dropout_bwd(const float* dy, const float* y, const uint8_t* keep, uint64_t seed,
+                         float p_drop, long long n, float* dx, void* stream) {
+  int rc = ew_args_ok(dy, dx, keep, p_drop, n);
+  if (rc) return rc;
+  if (!y || !aligned16(y)) return VQF_E_BADARG;
+  return ew_launch<2>(KID_TANH_DROP_BWD, dy, y, keep, seed, p_drop, n, dx, stream);
+}
+
+int vqf_softmax_rows_fwd(const float* x, int R, int W, float* y, void* stream) {
+  if (!x || !y || R <= 0 || W <= 0) return VQF_E_BADARG;
+  VQF_LAUNCH(KID_SOFTMAX_FWD, softmax_rows_fwd_kernel, dim3((R + 3) / 4), dim3(256), 0,
+             (hipStream_t)stream, x, R, W, y);
+  return vqf_last_error();
+}
+
+int vqf_softmax_rows_bwd(const float* dy, const float* y, int R, int W, float* dx, void* stream) {
+  if (!dy || !y || !dx || R <= 0 || W <= 0) return VQF_E_BADARG;
+  VQF_LAUNCH(KID_SOFTMAX_BWD, softmax_rows_bwd_kernel, dim3((R + 3) / 4), dim3(256), 0,
+             (hipStream_t)stream, dy, y, R, W, dx);
+  return vqf_last_error();
+}
+
+}  // extern "C"

@@ -17,7 +17,8 @@ const char* const kNames[KID_COUNT] = {
     "gemm_f32_a0b0(fwd)", "gemm_f32_a0b1(dgrad)", "gemm_f32_a1b0", "gemm_f32_a1b1(wgrad)",
     "splitk_reduce", "colsum", "group_reduce", "relu_bwd",
     "att_logits_fwd", "att_logits_bwd", "glimpse_pool_fwd", "glimpse_pool_bwd",
-    "mfb_fuse_fwd", "l2_group_norm", "scale_rows", "rowdot", "l2_norm_bwd_coef", "mfb_fuse_bwd"};
+    "mfb_fuse_fwd", "l2_group_norm", "scale_rows", "rowdot", "l2_norm_bwd_coef", "mfb_fuse_bwd",
+    "dropout", "tanh_dropout_fwd", "tanh_dropout_bwd", "softmax_rows_fwd", "softmax_rows_bwd"};
 
 hipEvent_t get_event() {
   std::lock_guard<std::mutex> lk(g_mu);

@@ -83,7 +83,7 @@ class AttHeadFn(torch.autograd.Function):
         need_dfeat = ctx.needs_input_grad[1]
         dlogits, dfeat = ops.glimpse_pool_bwd(dpooled, feat, wts, ctx.unit, need_dfeat)
         last = hid2 if hid2 is not None else hid1
-        dlast_pre, dw2, db2, dblast = ops.att_logits_bwd(dlogits, last, _w2d(w2))
+        dlast_pre, dw2, db2, dblast = ops.att_logits_bwd(dlogits, last, _w2d(w2), relu_mask=True)
         dwm = dbm = None
         if hid2 is not None:
             dwm = ops.gemm(dlast_pre, hid1, ta=True, tb=True).view_as(wm)
@@ -167,3 +167,110 @@ class FinalMfbFn(torch.autograd.Function):
         dbq = ops.colsum(dqq)
         dbv = ops.colsum(dvv)
         return dqa, dva, dwq, dbq, dwv, dbv, None, None, None, dcasc, None
+
+
+# ---------------------------------------------------------------------------------------------
+# stages used by HieCoAtten (hieCoAtten.py) and modules.py / networks.py
+# ---------------------------------------------------------------------------------------------
+class DropoutFn(torch.autograd.Function):
+    """F.dropout with an in-kernel Philox mask (or an explicit uint8 keep-mask)."""
+
+    @staticmethod
+    def forward(ctx, x, keep, seed, p_drop):
+        x = _c(x)
+        ctx.keep, ctx.seed, ctx.p = keep, seed, p_drop
+        return ops.dropout(x, keep=keep, seed=seed, p_drop=p_drop)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.dropout(_c(dy), keep=ctx.keep, seed=ctx.seed, p_drop=ctx.p), None, None, None
+
+
+class TanhDropFn(torch.autograd.Function):
+    """y = dropout(tanh(a [+ b]))   (hieCoAtten.py:32-33,38-39,45-46)."""
+
+    @staticmethod
+    def forward(ctx, a, b, keep, seed, p_drop):
+        a = _c(a)
+        b = None if b is None else _c(b)
+        y = ops.tanh_dropout_fwd(a, b, keep=keep, seed=seed, p_drop=p_drop)
+        ctx.save_for_backward(y)
+        ctx.keep, ctx.seed, ctx.p, ctx.has_b = keep, seed, p_drop, b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dx = ops.tanh_dropout_bwd(_c(dy), y, keep=ctx.keep, seed=ctx.seed, p_drop=ctx.p)
+        return dx, (dx if ctx.has_b else None), None, None, None
+
+
+class BmmFn(torch.autograd.Function):
+    """Batched C_b = Aop_b @ Bop_b^T on the fp32 MFMA GEMM.
+
+    ta=False: a is (B,M,K), ta=True: a is (B,K,M); tb=False: b is (B,N,K), tb=True: b is (B,K,N).
+    """
+
+    @staticmethod
+    def forward(ctx, a, b, ta, tb):
+        a, b = _c(a), _c(b)
+        ctx.save_for_backward(a, b)
+        ctx.ta, ctx.tb = ta, tb
+        return ops.bgemm(a, b, ta=ta, tb=tb)
+
+    @staticmethod
+    def backward(ctx, dc):
+        a, b = ctx.saved_tensors
+        dc = _c(dc)
+        ta, tb = ctx.ta, ctx.tb
+        da = db = None
+        if ctx.needs_input_grad[0]:
+            if not ta:      # dA (B,M,K) = dC (M,N) x Bop (N,K)
+                da = ops.bgemm(dc, b, ta=False, tb=not tb)
+            else:           # dA (B,K,M) = Bop^T (K,N) x dC^T (N,M)
+                da = ops.bgemm(b, dc, ta=not tb, tb=False)
+        if ctx.needs_input_grad[1]:
+            if not tb:      # dB (B,N,K) = dC^T (N,M) x Aop (M,K)
+                db = ops.bgemm(dc, a, ta=True, tb=not ta)
+            else:           # dB (B,K,N) = Aop^T (K,M) x dC (M,N)
+                db = ops.bgemm(a, dc, ta=not ta, tb=True)
+        return da, db, None, None
+
+
+class AttPoolFn(torch.autograd.Function):
+    """logits = x W^T + b (G rows, no hidden layer), softmax over the S positions of a sample,
+    pooled[n] = sum_s wts[n,g,s] feat[n,s,:].  Returns (pooled (N,G*C), wts (N,G,S)), both
+    differentiable (hieCoAtten.py:40-42,47-49 and :55; modules.py:60-65; networks.py:64-66).
+    x (N*S, Cin), feat (N,S,C), w (G,Cin), b (G)."""
+
+    @staticmethod
+    def forward(ctx, x, feat, w, b):
+        x, feat = _c(x), _c(feat)
+        w2 = _w2d(w)
+        logits = ops.att_logits_fwd(x, w2, b)
+        wts, pooled = ops.glimpse_pool_fwd(feat, logits, False)
+        ctx.save_for_backward(x, feat, w, wts)
+        return pooled, wts
+
+    @staticmethod
+    def backward(ctx, dpooled, dwts):
+        x, feat, w, wts = ctx.saved_tensors
+        dlogits, dfeat = ops.glimpse_pool_bwd(_c(dpooled), feat, wts, False, ctx.needs_input_grad[1],
+                                              dwts=None if dwts is None else _c(dwts))
+        dx, dw, db, _ = ops.att_logits_bwd(dlogits, x, _w2d(w), relu_mask=False)
+        return (dx if ctx.needs_input_grad[0] else None), dfeat, dw.view_as(w), db
+
+
+class SoftmaxRowsFn(torch.autograd.Function):
+    """softmax over the last axis of a 2-D tensor (modules.py:91-92)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        y = ops.softmax_rows_fwd(_c(x))
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return ops.softmax_rows_bwd(_c(dy), y)

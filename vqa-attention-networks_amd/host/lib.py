@@ -35,11 +35,16 @@ SIGNATURES = {
     "vqf_colsum_f32": (c_i, [c_f, c_i, c_i, c_i, c_f, c_p, c_sz, c_p]),
     "vqf_group_reduce_f32": (c_i, [c_f, c_i, c_i, c_i, c_f, c_p]),
     "vqf_relu_bwd_f32": (c_i, [c_f, c_f, c_i, c_i, c_f, c_f, c_p, c_sz, c_p]),
-    "vqf_att_logits_fwd": (c_i, [c_f, c_f, c_f, c_i, c_i, c_f, c_p]),
+    "vqf_att_logits_fwd": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_p]),
     "vqf_att_logits_bwd_ws_bytes": (c_sz, [c_i, c_i]),
-    "vqf_att_logits_bwd": (c_i, [c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_f, c_f, c_p, c_sz, c_p]),
-    "vqf_glimpse_pool_fwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_p]),
-    "vqf_glimpse_pool_bwd": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_p]),
+    "vqf_att_logits_bwd": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_p, c_sz, c_p]),
+    "vqf_glimpse_pool_fwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_p]),
+    "vqf_glimpse_pool_bwd": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_p]),
+    "vqf_dropout_f32": (c_i, [c_f, c_p, c_u64, ctypes.c_float, ctypes.c_longlong, c_f, c_p]),
+    "vqf_tanh_dropout_fwd": (c_i, [c_f, c_f, c_p, c_u64, ctypes.c_float, ctypes.c_longlong, c_f, c_p]),
+    "vqf_tanh_dropout_bwd": (c_i, [c_f, c_f, c_p, c_u64, ctypes.c_float, ctypes.c_longlong, c_f, c_p]),
+    "vqf_softmax_rows_fwd": (c_i, [c_f, c_i, c_i, c_f, c_p]),
+    "vqf_softmax_rows_bwd": (c_i, [c_f, c_f, c_i, c_i, c_f, c_p]),
     "vqf_mfb_fuse_fwd": (c_i, [c_f, c_f, c_f, c_p, c_u64, ctypes.c_float, c_i, c_i, c_i, c_f, c_f, c_f, c_p]),
     "vqf_l2_group_norm": (c_i, [c_f, c_i, c_i, c_f, c_f, c_p]),
     "vqf_scale_rows": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f, c_p]),

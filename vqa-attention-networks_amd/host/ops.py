@@ -134,47 +134,93 @@ def relu_bwd(dx, y, want_bias=True):
 
 
 def att_logits_fwd(hid, w2, b2):
+    """logits (M,G) = hid (M,Hh) @ w2 (G,Hh)^T + b2; G in {1,2}."""
     _chk(hid, w2, b2)
     M, Hh = hid.shape
-    out = torch.empty((M, 2), dtype=torch.float32, device=hid.device)
-    _l.check(_lib().vqf_att_logits_fwd(_ptr(hid), _ptr(w2), _ptr(b2), M, Hh, _ptr(out), _stream()),
+    G = w2.shape[0]
+    out = torch.empty((M, G), dtype=torch.float32, device=hid.device)
+    _l.check(_lib().vqf_att_logits_fwd(_ptr(hid), _ptr(w2), _ptr(b2), M, Hh, G, _ptr(out), _stream()),
              "vqf_att_logits_fwd")
     return out
 
 
-def att_logits_bwd(dlogits, hid, w2):
+def att_logits_bwd(dlogits, hid, w2, relu_mask=True):
     _chk(dlogits, hid, w2)
     M, Hh = hid.shape
+    G = w2.shape[0]
     dpre = torch.empty_like(hid)
-    dw2 = torch.empty((2, Hh), dtype=torch.float32, device=hid.device)
-    db2 = torch.empty(2, dtype=torch.float32, device=hid.device)
+    dw2 = torch.empty((G, Hh), dtype=torch.float32, device=hid.device)
+    db2 = torch.empty(G, dtype=torch.float32, device=hid.device)
     db1 = torch.empty(Hh, dtype=torch.float32, device=hid.device)
     ws = workspace(hid.device, _lib().vqf_att_logits_bwd_ws_bytes(M, Hh))
-    _l.check(_lib().vqf_att_logits_bwd(_ptr(dlogits), _ptr(hid), _ptr(w2), M, Hh, _ptr(dpre), _ptr(dw2),
-                                       _ptr(db2), _ptr(db1), _ptr(ws), ws.numel(), _stream()),
-             "vqf_att_logits_bwd")
+    _l.check(_lib().vqf_att_logits_bwd(_ptr(dlogits), _ptr(hid), _ptr(w2), M, Hh, G, int(bool(relu_mask)),
+                                       _ptr(dpre), _ptr(dw2), _ptr(db2), _ptr(db1), _ptr(ws), ws.numel(),
+                                       _stream()), "vqf_att_logits_bwd")
     return dpre, dw2, db2, db1
 
 
 def glimpse_pool_fwd(feat, logits, unit_softmax):
+    """feat (N,S,C), logits (N*S,G) -> wts (N,G,S), pooled (N,G*C)."""
     _chk(feat, logits)
     N, S, C = feat.shape
-    wts = torch.empty((N, 2, S), dtype=torch.float32, device=feat.device)
-    pooled = torch.empty((N, 2 * C), dtype=torch.float32, device=feat.device)
-    _l.check(_lib().vqf_glimpse_pool_fwd(_ptr(feat), _ptr(logits), N, S, C, int(bool(unit_softmax)),
+    G = logits.shape[1]
+    wts = torch.empty((N, G, S), dtype=torch.float32, device=feat.device)
+    pooled = torch.empty((N, G * C), dtype=torch.float32, device=feat.device)
+    _l.check(_lib().vqf_glimpse_pool_fwd(_ptr(feat), _ptr(logits), N, S, C, G, int(bool(unit_softmax)),
                                          _ptr(wts), _ptr(pooled), _stream()), "vqf_glimpse_pool_fwd")
     return wts, pooled
 
 
-def glimpse_pool_bwd(dpooled, feat, wts, unit_softmax, want_dfeat):
-    _chk(dpooled, feat, wts)
+def glimpse_pool_bwd(dpooled, feat, wts, unit_softmax, want_dfeat, dwts=None):
+    _chk(dpooled, feat, wts, dwts)
     N, S, C = feat.shape
-    dlogits = torch.empty((N * S, 2), dtype=torch.float32, device=feat.device)
+    G = wts.shape[1]
+    dlogits = torch.empty((N * S, G), dtype=torch.float32, device=feat.device)
     dfeat = torch.empty_like(feat) if want_dfeat else None
-    _l.check(_lib().vqf_glimpse_pool_bwd(_ptr(dpooled), _ptr(feat), _ptr(wts), N, S, C,
+    _l.check(_lib().vqf_glimpse_pool_bwd(_ptr(dpooled), _ptr(dwts), _ptr(feat), _ptr(wts), N, S, C, G,
                                          int(bool(unit_softmax)), _ptr(dlogits), _ptr(dfeat), _stream()),
              "vqf_glimpse_pool_bwd")
     return dlogits, dfeat
+
+
+def dropout(x, keep=None, seed=0, p_drop=0.5):
+    _chk(x)
+    y = torch.empty_like(x)
+    _l.check(_lib().vqf_dropout_f32(_ptr(x), _keep_ptr(keep), int(seed), float(p_drop), x.numel(), _ptr(y),
+                                    _stream()), "vqf_dropout_f32")
+    return y
+
+
+def tanh_dropout_fwd(a, b=None, keep=None, seed=0, p_drop=0.5):
+    _chk(a, b)
+    y = torch.empty_like(a)
+    _l.check(_lib().vqf_tanh_dropout_fwd(_ptr(a), _ptr(b), _keep_ptr(keep), int(seed), float(p_drop),
+                                         a.numel(), _ptr(y), _stream()), "vqf_tanh_dropout_fwd")
+    return y
+
+
+def tanh_dropout_bwd(dy, y, keep=None, seed=0, p_drop=0.5):
+    _chk(dy, y)
+    dx = torch.empty_like(y)
+    _l.check(_lib().vqf_tanh_dropout_bwd(_ptr(dy), _ptr(y), _keep_ptr(keep), int(seed), float(p_drop),
+                                         y.numel(), _ptr(dx), _stream()), "vqf_tanh_dropout_bwd")
+    return dx
+
+
+def softmax_rows_fwd(x):
+    _chk(x)
+    R, W = x.shape
+    y = torch.empty_like(x)
+    _l.check(_lib().vqf_softmax_rows_fwd(_ptr(x), R, W, _ptr(y), _stream()), "vqf_softmax_rows_fwd")
+    return y
+
+
+def softmax_rows_bwd(dy, y):
+    _chk(dy, y)
+    R, W = y.shape
+    dx = torch.empty_like(y)
+    _l.check(_lib().vqf_softmax_rows_bwd(_ptr(dy), _ptr(y), R, W, _ptr(dx), _stream()), "vqf_softmax_rows_bwd")
+    return dx
 
 
 def _keep_ptr(keep):
