@@ -7,8 +7,8 @@
 // image projection img_conv1d (mfb.py:96): M = N*196, K = 2048, N = 5000.
 //
 // Design (MI355X-first, not a warp-tiling port):
-//   * 256-thread workgroup = 4 wave64, one per SIMD; 2 workgroups per CU.
-//   * 128x128x32 block tile, each wave owns a 64x64 sub-tile = 2x2 MFMA
+//   * 256-thread workgroup = 4 wave64, one per SIMD; 4 workgroups per CU (127 VGPRs, 40 KB LDS).
+//   * 128x128x16 block tile, each wave owns a 64x64 sub-tile = 2x2 MFMA
 //     32x32 accumulators (64 accumulator VGPRs); the fp32 MFMA is 64 cycles per
 //     instruction per SIMD, so 4 independent accumulators per wave keep the
 //     pipe back-to-back and LDS/global traffic is <15 % of the issue slots.
@@ -16,7 +16,7 @@
 //     loads issued before the current tile's MFMAs (register prefetch) and two
 //     LDS buffers, so there is one barrier per K-tile.
 //   * "row-major K-contiguous" operands (activations, weights in forward) live
-//     in LDS as [row][32+4] and are read with one ds_read_b128 per 8 k (the 16-B
+//     in LDS as [row][BK+4] and are read with one ds_read_b128 per 8 k (the 16-B
 //     row pad makes the 16-lane b128 groups conflict-free); "K-major" operands
 //     (both operands of wgrad, the weight in dgrad) live as [k][128] and are read
 //     with conflict-free ds_read_b32.  Both give lane (i, h) the k-indices
@@ -30,11 +30,24 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32, NTHREADS = 256;
+// Measured on MI355X (img_conv1d forward, M=100352 N=5000 K=2048): BK=32 / 2 workgroups per CU
+// 128.9 TF; BK=16 / 3 per CU 132.3 TF; BK=16 / 4 per CU 133.7 TF.  The shallower K-tile halves the
+// LDS footprint (40,960 B) so that four workgroups (4 waves per SIMD) share a CU and cover each
+// other's barrier / LDS-refill bubbles.
+#ifndef VQF_GEMM_BK
+#define VQF_GEMM_BK 16
+#endif
+#ifndef VQF_GEMM_WAVES_PER_SIMD
+#define VQF_GEMM_WAVES_PER_SIMD 4
+#endif
+constexpr int BM = 128, BN = 128, BK = VQF_GEMM_BK, NTHREADS = 256;
 constexpr int LD_RK = BK + 4;                 // floats; [row][k] image, 16-B pad
-constexpr int OP_FLOATS = BM * LD_RK;         // 4608 floats >= BK*BM (4096)
+constexpr int OP_FLOATS = BM * LD_RK;         // >= BK*BM
 constexpr int STAGE_FLOATS = 2 * OP_FLOATS;   // A + B
-constexpr int SMEM_BYTES = 2 * STAGE_FLOATS * 4;   // 73,728 B (double buffered)
+constexpr int SMEM_BYTES = 2 * STAGE_FLOATS * 4;   // 73,728 B at BK=32 (double buffered)
+constexpr int K4 = BK / 4;                    // float4 per tile row (K-contiguous layout)
+constexpr int NLD = BM * BK / 4 / NTHREADS;   // float4 loads per thread per operand per tile
+static_assert(BK % 8 == 0 && NLD >= 1, "BK must be a multiple of 8");
 
 struct GemmArgs {
   const float* A;
@@ -55,12 +68,12 @@ struct GemmArgs {
 // T == true : operand(row r, k) = p[k*ld + r]   (BK k-rows x 128, 32 float4 per k-row)
 template <bool T>
 __device__ __forceinline__ void load_tile(const float* __restrict__ p, int ld, int r0, int R,
-                                          int k0, int kend, bool vec, int tid, f32x4 (&v)[4]) {
+                                          int k0, int kend, bool vec, int tid, f32x4 (&v)[NLD]) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NLD; ++i) {
     const int f = tid + NTHREADS * i;
     int r, k;
-    if (!T) { r = r0 + (f >> 3); k = k0 + ((f & 7) << 2); }
+    if (!T) { r = r0 + f / K4; k = k0 + ((f % K4) << 2); }
     else    { k = k0 + (f >> 5); r = r0 + ((f & 31) << 2); }
     f32x4 x = {0.f, 0.f, 0.f, 0.f};
     if (!T) {
@@ -98,14 +111,14 @@ typedef const f32x4 __attribute__((address_space(1))) gf32x4;
 
 template <bool T>
 __device__ __forceinline__ void init_ptrs(const float* __restrict__ p0, int ld, int r0, int R, int k0,
-                                          int tid, gfloat* (&q)[4]) {
+                                          int tid, gfloat* (&q)[NLD]) {
   gfloat* p = (gfloat*)p0;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NLD; ++i) {
     const int f = tid + NTHREADS * i;
     if (!T) {
-      const int r = min(r0 + (f >> 3), R - 1);
-      q[i] = p + (long long)r * ld + (k0 + ((f & 7) << 2));
+      const int r = min(r0 + f / K4, R - 1);
+      q[i] = p + (long long)r * ld + (k0 + ((f % K4) << 2));
     } else {
       const int r = min(r0 + ((f & 31) << 2), R - 4);
       q[i] = p + (long long)(k0 + (f >> 5)) * ld + r;
@@ -113,20 +126,20 @@ __device__ __forceinline__ void init_ptrs(const float* __restrict__ p0, int ld, 
   }
 }
 template <bool T>
-__device__ __forceinline__ void load_fast(gfloat* (&q)[4], int ld, f32x4 (&v)[4]) {
+__device__ __forceinline__ void load_fast(gfloat* (&q)[NLD], int ld, f32x4 (&v)[NLD]) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NLD; ++i) {
     v[i] = *(gf32x4*)q[i];
     q[i] += T ? (long long)BK * ld : BK;
   }
 }
 
 template <bool T>
-__device__ __forceinline__ void store_tile(float* s, int tid, const f32x4 (&v)[4]) {
+__device__ __forceinline__ void store_tile(float* s, int tid, const f32x4 (&v)[NLD]) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NLD; ++i) {
     const int f = tid + NTHREADS * i;
-    if (!T) *reinterpret_cast<f32x4*>(s + (f >> 3) * LD_RK + ((f & 7) << 2)) = v[i];
+    if (!T) *reinterpret_cast<f32x4*>(s + (f / K4) * LD_RK + ((f % K4) << 2)) = v[i];
     else    *reinterpret_cast<f32x4*>(s + (f >> 5) * BM + ((f & 31) << 2)) = v[i];
   }
 }
@@ -156,9 +169,9 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& g, float* smem, co
     v10 = (m0 + wr * 64 + 32) < g.M;
     v01 = (n0 + wc * 64 + 32) < g.N;
   }
-  gfloat* pa[4];
-  gfloat* pb[4];
-  f32x4 ra[4], rb[4];
+  gfloat* pa[NLD];
+  gfloat* pb[NLD];
+  f32x4 ra[NLD], rb[NLD];
   if (FAST) {
     init_ptrs<TA>(gA, g.lda, m0, g.M, kbeg, tid, pa);
     init_ptrs<TB>(gB, g.ldb, n0, g.N, kbeg, tid, pb);
@@ -233,7 +246,7 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& g, float* smem, co
 }
 
 template <bool TA, bool TB, bool FAST>
-__global__ void __launch_bounds__(NTHREADS, 2) gemm_f32_kernel(GemmArgs g) {
+__global__ void __launch_bounds__(NTHREADS, VQF_GEMM_WAVES_PER_SIMD) gemm_f32_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform (scalar branches)
@@ -362,15 +375,18 @@ extern "C" int vqf_gemm_f32(int ta, int tb, int M, int N, int K, const float* A,
   g.vecA = aligned16(A) && (lda % 4 == 0);
   g.vecB = aligned16(B) && (ldb % 4 == 0);
 
-  // split-K: only when the output has too few tiles to fill 256 CUs x 2 and K is deep
+  // split-K: only when the output has too few tiles to fill the chip and K is deep.  Two
+  // workgroups per CU already keep the matrix pipe busy (the others only cover bubbles), so the
+  // wave-quantisation model uses 512 slots; measured: img_conv1d wgrad (640 tiles) 134 TF at 4
+  // splits vs 124 TF at 8.
   const long long tiles = (long long)g.tiles_m * g.tiles_n;
   const int ktiles = (K + BK - 1) / BK;
   int splits = 1;
-  if (ws && tiles < 1024 && ktiles >= 16) {
+  const int slots = 512;
+  if (ws && tiles < 1024 && ktiles >= 32) {
     double best = 1e30;
-    const int slots = 512;
     for (int sp = 1; sp <= 16; ++sp) {
-      if (ktiles / sp < 8) break;
+      if (ktiles / sp < 16) break;
       if ((size_t)sp * M * N * sizeof(float) > ws_bytes) break;
       const double blocks = (double)tiles * sp;
       const double rounds = (double)((long long)((blocks + slots - 1) / slots));

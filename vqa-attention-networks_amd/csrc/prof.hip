@@ -44,7 +44,7 @@ void vqf_prof_dims(int d0, int d1, int d2) { t_dims[0] = d0; t_dims[1] = d1; t_d
 extern "C" {
 int vqf_abi_version(void) { return 1; }
 const char* vqf_build_info(void) {
-  return "libvqa_fusion gfx950 fp32-mfma(v_mfma_f32_32x32x2_f32) tile128x128x32 wave64 philox4x32-10";
+  return "libvqa_fusion gfx950 fp32-mfma(v_mfma_f32_32x32x2_f32) tile128x128x16 wave64 philox4x32-10";
 }
 void vqf_prof_enable(int on) { g_vqf_prof_on = on ? 1 : 0; }
 void vqf_prof_reset(void) {
