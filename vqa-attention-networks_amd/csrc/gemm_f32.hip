@@ -63,6 +63,22 @@ struct GemmArgs {
   long long sA, sB, sC;    // batch strides (grid.z), 0 when not batched
 };
 
+// Thread -> (row, k) of its i-th float4 in the K-contiguous ("RK") tile image.  A ds_write_b128
+// is serviced in groups of 8 consecutive lanes; with 64-byte tile rows (BK = 16) padded to 80 B,
+// two ADJACENT rows overlap on 4 banks (2-way conflict on the staging stores; the fragment reads
+// are conflict-free either way).  Remapping each 8-lane group to rows (r, r+4) removes the
+// conflict (SQ_LDS_BANK_CONFLICT 5.1e8 -> 0, LDS busy -33 %) but measured 3 % SLOWER in a
+// same-process A/B (130.5 vs 134.6 TF, tools/gemm_ab.py): the kernel is not LDS-bound and the
+// plain order keeps consecutive lanes on consecutive global rows.  Hence off by default.
+#ifndef VQF_GEMM_RK_REMAP
+#define VQF_GEMM_RK_REMAP 0
+#endif
+__device__ __forceinline__ int rk_row(int f) {
+  if (VQF_GEMM_RK_REMAP && K4 == 4) return ((f >> 5) << 3) + (((f >> 2) & 1) << 2) + ((f >> 3) & 3);
+  return f / K4;
+}
+__device__ __forceinline__ int rk_k(int f) { return (f % K4) << 2; }
+
 // ---- global -> register staging ------------------------------------------
 // T == false: operand(row r, k) = p[r*ld + k]   (tile rows x BK, 8 float4 per row)
 // T == true : operand(row r, k) = p[k*ld + r]   (BK k-rows x 128, 32 float4 per k-row)
@@ -73,7 +89,7 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ p, int ld, i
   for (int i = 0; i < NLD; ++i) {
     const int f = tid + NTHREADS * i;
     int r, k;
-    if (!T) { r = r0 + f / K4; k = k0 + ((f % K4) << 2); }
+    if (!T) { r = r0 + rk_row(f); k = k0 + rk_k(f); }
     else    { k = k0 + (f >> 5); r = r0 + ((f & 31) << 2); }
     f32x4 x = {0.f, 0.f, 0.f, 0.f};
     if (!T) {
@@ -117,8 +133,8 @@ __device__ __forceinline__ void init_ptrs(const float* __restrict__ p0, int ld, 
   for (int i = 0; i < NLD; ++i) {
     const int f = tid + NTHREADS * i;
     if (!T) {
-      const int r = min(r0 + f / K4, R - 1);
-      q[i] = p + (long long)r * ld + (k0 + ((f % K4) << 2));
+      const int r = min(r0 + rk_row(f), R - 1);
+      q[i] = p + (long long)r * ld + (k0 + rk_k(f));
     } else {
       const int r = min(r0 + ((f & 31) << 2), R - 4);
       q[i] = p + (long long)(k0 + (f >> 5)) * ld + r;
@@ -139,7 +155,7 @@ __device__ __forceinline__ void store_tile(float* s, int tid, const f32x4 (&v)[N
 #pragma unroll
   for (int i = 0; i < NLD; ++i) {
     const int f = tid + NTHREADS * i;
-    if (!T) *reinterpret_cast<f32x4*>(s + (f / K4) * LD_RK + ((f % K4) << 2)) = v[i];
+    if (!T) *reinterpret_cast<f32x4*>(s + rk_row(f) * LD_RK + rk_k(f)) = v[i];
     else    *reinterpret_cast<f32x4*>(s + (f >> 5) * BM + ((f & 31) << 2)) = v[i];
   }
 }
