@@ -48,8 +48,8 @@ def test_binding_table_covers_the_header(vqa):
 
 def test_workspace_size_queries_need_no_gpu(vqa):
     lib = vqa.lib.load()
-    assert lib.vqf_colsum_ws_bytes(1000, 512) == 4 * 512 * 4
-    assert lib.vqf_mfb_fuse_bwd_ws_bytes(512, 196, 1000) == 2 * 512 * 4 * 5000 * 4
+    assert lib.vqf_colsum_ws_bytes(1000, 512) == (4 + 32) * 512 * 4
+    assert lib.vqf_mfb_fuse_bwd_ws_bytes(512, 196, 1000) == (2 * 512 * 4 + 32) * 5000 * 4
     assert lib.vqf_att_logits_bwd_ws_bytes(100352, 1024) > 0
     assert lib.vqf_colsum_ws_bytes(0, 5) == 0
 

@@ -282,7 +282,7 @@ int vqf_att_logits_fwd(const float* hid, const float* w2, const float* b2, int M
 
 size_t vqf_att_logits_bwd_ws_bytes(int M, int Hh) {
   if (M <= 0 || Hh <= 0) return 0;
-  return (size_t)((M + LB_ROWS - 1) / LB_ROWS + 1) * (size_t)(3 * Hh + 4) * sizeof(float);
+  return (size_t)((M + LB_ROWS - 1) / LB_ROWS + 1 + VQF_REDUCE_SPLITS) * (size_t)(3 * Hh + 4) * sizeof(float);
 }
 
 int vqf_att_logits_bwd(const float* dlogits, const float* hid, const float* w2, int M, int Hh, int G,
@@ -305,7 +305,7 @@ int vqf_att_logits_bwd(const float* dlogits, const float* hid, const float* w2, 
 #undef VQF_LB
   int rc = vqf_last_error();
   if (rc) return rc;
-  rc = vqf_group_reduce_f32(part, 1, nb, pw, red, stream);
+  rc = vqf_colreduce_2stage(part, nb, pw, red, red + pw, s);
   if (rc) return rc;
   hipError_t e = hipMemcpyAsync(dw2, red, (size_t)G * Hh * sizeof(float), hipMemcpyDeviceToDevice, s);
   if (e != hipSuccess) return (int)e;

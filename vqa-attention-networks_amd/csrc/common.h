@@ -49,6 +49,10 @@ void vqf_prof_dims(int d0, int d1, int d2);   // shape tag attached to the next 
     if (g_vqf_prof_on) vqf_prof_end((id), (stream));                               \
   } while (0)
 
+// two-stage column reduction (reduce.hip); scratch holds VQF_REDUCE_SPLITS x W floats
+#define VQF_REDUCE_SPLITS 32
+int vqf_colreduce_2stage(const float* in, int J, int W, float* out, float* scratch, hipStream_t s);
+
 static inline int vqf_last_error() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? VQF_OK : (int)e;

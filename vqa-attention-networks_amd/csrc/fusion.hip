@@ -196,7 +196,7 @@ int vqf_mfb_fuse_fwd(const float* P, const float* q, const float* cascade, const
 
 size_t vqf_mfb_fuse_bwd_ws_bytes(int N, int L, int O) {
   if (N <= 0 || L <= 0 || O <= 0) return 0;
-  return (size_t)2 * N * pick_ls(N, L) * KP * O * sizeof(float);
+  return ((size_t)2 * N * pick_ls(N, L) + VQF_REDUCE_SPLITS) * KP * O * sizeof(float);
 }
 
 int vqf_mfb_fuse_bwd(const float* dY, const float* dzdrop, const float* Y, const float* inv,
@@ -239,7 +239,8 @@ int vqf_mfb_fuse_bwd(const float* dY, const float* dzdrop, const float* Y, const
     rc = vqf_group_reduce_f32(dq_part, N, LS, W5, dq, stream);
     if (rc) return rc;
   }
-  if (dbiasP) rc = vqf_group_reduce_f32(db_part, 1, N * LS, W5, dbiasP, stream);
+  if (dbiasP)
+    rc = vqf_colreduce_2stage(db_part, N * LS, W5, dbiasP, (float*)ws + (size_t)2 * N * LS * W5, s);
   return rc;
 }
 

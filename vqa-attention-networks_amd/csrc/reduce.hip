@@ -38,6 +38,24 @@ __global__ void group_reduce_kernel(const float* __restrict__ in, int G, int J, 
   out[(long long)g * W + c] = a0 + a1;
 }
 
+// stage 1 of the two-stage column reduction: block (x, y) folds rows [y*chunk, (y+1)*chunk)
+__global__ void group_reduce_stage1_kernel(const float* __restrict__ in, int J, int W, int chunk,
+                                           float* __restrict__ part) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= W) return;
+  const int j0 = blockIdx.y * chunk, j1 = min(J, j0 + chunk);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int j = j0;
+  for (; j + 3 < j1; j += 4) {
+    a0 += in[(long long)j * W + c];
+    a1 += in[(long long)(j + 1) * W + c];
+    a2 += in[(long long)(j + 2) * W + c];
+    a3 += in[(long long)(j + 3) * W + c];
+  }
+  for (; j < j1; ++j) a0 += in[(long long)j * W + c];
+  part[(long long)blockIdx.y * W + c] = (a0 + a1) + (a2 + a3);
+}
+
 __global__ void relu_bwd_kernel(const float* __restrict__ dX, const float* __restrict__ Y,
                                 long long n, float* __restrict__ dXpre) {
   const long long stride = (long long)gridDim.x * blockDim.x;
@@ -120,11 +138,26 @@ __global__ void l2_norm_bwd_coef_kernel(const float* __restrict__ rowdot,
 
 }  // namespace
 
+// out[c] = sum_{j<J} in[j, c] with enough workgroups to be bandwidth-bound: rows are folded in
+// VQF_REDUCE_SPLITS chunks (grid.y) into `scratch` (VQF_REDUCE_SPLITS x W floats), then once more.
+int vqf_colreduce_2stage(const float* in, int J, int W, float* out, float* scratch, hipStream_t s) {
+  if (J <= 2 * VQF_REDUCE_SPLITS)
+    return vqf_group_reduce_f32(in, 1, J, W, out, (void*)s);
+  const int chunk = (J + VQF_REDUCE_SPLITS - 1) / VQF_REDUCE_SPLITS;
+  const int ny = (J + chunk - 1) / chunk;
+  dim3 grid((W + 255) / 256, ny);
+  VQF_LAUNCH(KID_GROUP_REDUCE, group_reduce_stage1_kernel, grid, dim3(256), 0, s, in, J, W, chunk,
+             scratch);
+  int rc = vqf_last_error();
+  if (rc) return rc;
+  return vqf_group_reduce_f32(scratch, 1, ny, W, out, (void*)s);
+}
+
 extern "C" {
 
 size_t vqf_colsum_ws_bytes(int M, int N) {
   if (M <= 0 || N <= 0) return 0;
-  return (size_t)((M + CS_ROWS - 1) / CS_ROWS) * (size_t)N * sizeof(float);
+  return (size_t)((M + CS_ROWS - 1) / CS_ROWS + VQF_REDUCE_SPLITS) * (size_t)N * sizeof(float);
 }
 
 int vqf_colsum_f32(const float* dY, int M, int N, int ldy, float* db, void* ws, size_t ws_bytes,
@@ -141,7 +174,7 @@ int vqf_colsum_f32(const float* dY, int M, int N, int ldy, float* db, void* ws, 
   VQF_LAUNCH(KID_COLSUM, colsum_partial_kernel, grid, dim3(256), 0, s, dY, M, N, ldy, (float*)ws);
   int rc = vqf_last_error();
   if (rc) return rc;
-  return vqf_group_reduce_f32((const float*)ws, 1, nb, N, db, stream);
+  return vqf_colreduce_2stage((const float*)ws, nb, N, db, (float*)ws + (size_t)nb * N, s);
 }
 
 int vqf_group_reduce_f32(const float* in, int G, int J, int W, float* out, void* stream) {
