@@ -204,9 +204,17 @@ def main():
     roofline = None
     if n_f:
         ach = flops / (ms_f / n_f * 1e-3) / 1e12
+        traffic, traffic_note = None, None
+        try:        # PMC passes cannot run inside the timed process; use the committed rocprofv3 --pmc result
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_gemm.json")))
+            if (pmc["M"], pmc["N"], pmc["K"]) == (M, N, K):
+                traffic, traffic_note = pmc["traffic_bytes"], pmc["note"] + "; " + pmc["formula"]
+        except Exception:
+            pass
         roofline = {"bound": "mfma", "kernel": "gemm_f32_a0b0 img_conv1d forward (M=%d,N=%d,K=%d)" % (M, N, K),
                     "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                    "traffic_note": traffic_note,
                     "avg_launch_ms": round(ms_f / n_f, 4), "launches": n_f,
                     "flops_per_launch": flops}
         if n_w:

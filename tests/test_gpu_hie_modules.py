@@ -289,3 +289,29 @@ def test_attention_modules_match_reference_golden(case):
         (o * o).sum().backward()
     assert rel_err(f1.grad.cpu().numpy(), gold["df1"]) <= 5e-4
     check_grads(_grads(m), gold, 5e-3)
+
+
+def test_config4_hiecoatten_full_batch_256_row_pairing():
+    """BASELINE config 4 shapes (HieCoAtten, B=256, img 2048 -> 512): attention weights normalise and,
+    because x = cat((v,q),0).view(N,-1) pairs rows (hieCoAtten.py:52-53), output row i < N/2 only depends
+    on samples 2i and 2i+1: it must equal row 0 of the oracle run on those two samples."""
+    vqa = _vqa()
+    N, L, T = 256, 196, 14
+    case = dict(salt=25, img_size=2048, V=1000, E=512, A=1000)
+    model = _load(vqa.HieCoAtten(block_num=L, word_num=T, img_size=2048, vocab_size=1000, embed_size=512,
+                                 output_size=1000), case["salt"])
+    model.drop_p = 0.0
+    g = torch.Generator().manual_seed(4321)
+    img = torch.relu(torch.randn((N, L, 2048), generator=g))
+    q = torch.randint(1, 1000, (N, T), generator=torch.Generator().manual_seed(4322))
+    ans = torch.randint(0, 1000, (N,), generator=torch.Generator().manual_seed(4323))
+    x, av, aq = model.forward(img.cuda(), q.cuda())
+    torch.nn.CrossEntropyLoss()(x, ans.cuda()).backward()
+    assert torch.allclose(av.detach().sum(1).cpu(), torch.ones(N), atol=1e-4)
+    assert torch.allclose(aq.detach().sum(1).cpu(), torch.ones(N), atol=1e-4)
+    assert all(p.grad is None or torch.isfinite(p.grad).all() for p in model.parameters())
+    sd = recipe_sd(O.hiecoatten_shapes(2048, 1000, 512, 1000), case["salt"])
+    for i in (0, 77, 127):
+        ox, oav, _ = O.hiecoatten_forward(sd, img[2 * i:2 * i + 2], q[2 * i:2 * i + 2])
+        assert rel_err(x[i].detach().cpu().numpy(), ox[0].numpy()) <= OUT_TOL
+        assert rel_err(av[2 * i:2 * i + 2].detach().cpu().numpy(), oav.numpy()) <= OUT_TOL

@@ -247,3 +247,25 @@ def test_state_dict_keys_match_reference_layout():
     m = vqa.MHBCoAtt(cfgh)
     assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == \
         {k: tuple(v) for k, v in O.mfb_shapes(cfgh, mhb=True).items()}
+
+
+def test_config3_mhbcoatt_full_batch_512_prefix_causality():
+    """BASELINE config 3 shapes (MHBCoAtt, B=512, fp32 here): the batch-axis LSTM recursion
+    (mhb_coAtt.py:72-74) is causal, so rows 0..3 of the B=512 result equal the oracle run on the first
+    4 samples alone; log-probs normalise; gradients are finite for every parameter."""
+    vqa = _vqa()
+    case = dict(name="c3", salt=79, N=512, model_name="mhb_coAtt", glove=False,
+                H=1024, E=300, D=2048, L=196, V=1000, A=1000, T=14)
+    cfg = make_cfg(case)
+    model = _no_dropout_train(_load(vqa.MHBCoAtt(cfg), case["salt"]))
+    g = torch.Generator().manual_seed(1234)
+    img = torch.relu(torch.randn((512, 196, 2048), generator=g))
+    q = torch.randint(1, 1000, (512, 14), generator=torch.Generator().manual_seed(1235))
+    soft = torch.softmax(torch.randn((512, 1000), generator=torch.Generator().manual_seed(1236)), 1)
+    out = model.forward(img.cuda(), q.cuda())
+    torch.nn.KLDivLoss()(out, soft.cuda()).backward()
+    assert torch.allclose(out.detach().exp().sum(1).cpu(), torch.ones(512), atol=1e-4)
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+    sd = recipe_sd(O.mfb_shapes(cfg, mhb=True), case["salt"])
+    ref = O.mhbcoatt_forward(sd, cfg, img[:4], q[:4])
+    assert rel_err(out[:4].detach().cpu().numpy(), ref.numpy()) <= OUT_TOL
