@@ -132,6 +132,8 @@ def main():
     ap.add_argument("--batch", type=int, default=512, help="QA pairs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--model", default="mfb", choices=["mfb", "mhb_coAtt"])
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="operand type of the two large GEMM families (bf16 = BASELINE config 3 mode)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); "
                     "'gloo' lets several ranks share one GPU for rehearsals")
     args = ap.parse_args()
@@ -156,6 +158,7 @@ def main():
     model = (vqa_amd.MFB if args.model == "mfb" else vqa_amd.MHBCoAtt)(cfg)
     init_like_reference(model)
     model = model.to(dev).train()
+    model.gemm_dtype = "bf16" if args.dtype == "bf16" else "fp32"
     reducer = parallel.GradientAllReducer(model)        # broadcasts rank 0's weights; no-op at world 1
     try:
         opt = torch.optim.Adam(model.parameters(), lr=7e-4, fused=True)
@@ -227,10 +230,11 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "QA-pairs/sec fwd+bwd, MFB-baseline batch 512",
+            "metric": "QA-pairs/sec fwd+bwd, MFB-baseline batch 512" if args.model == "mfb"
+                      else "QA-pairs/sec fwd+bwd, MHBCoAtt batch %d" % B,
             "value": round(value, 2), "unit": "QA-pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "MFB-baseline train step (fwd+loss+bwd+grad all-reduce+Adam), "
                                    "batch %d per GPU, 196x2048 image grid, 14 tokens, fp32, mode=faithful"
                                    % B if args.model == "mfb" else "MHBCoAtt train step, batch %d per GPU" % B,

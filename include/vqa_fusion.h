@@ -81,6 +81,20 @@ int vqf_gemm_f32_batched(int ta, int tb, int batch, int M, int N, int K,
                          const float* B, int ldb, long long strideB,
                          float* C, int ldc, long long strideC, int flags, void* stream);
 
+/* bf16 x bf16 -> fp32 form (v_mfma_f32_32x32x16_bf16, fp32 accumulate; BASELINE config 3: bf16
+ * storage of the image tensor / activations / weights of the large projections).  A and B point
+ * to bf16 (uint16) data, same ta/tb meaning as vqf_gemm_f32; C, bias fp32.  Returns
+ * VQF_E_UNSUPPORTED unless: bases 16-byte aligned, lda/ldb % 8 == 0, K % 8 == 0 for a
+ * K-contiguous operand, row extent % 8 == 0 (and >= 8) for a K-major operand. */
+int vqf_gemm_bf16(int ta, int tb, int M, int N, int K,
+                  const void* A, int lda, const void* B, int ldb,
+                  float* C, int ldc, const float* bias, int flags,
+                  void* ws, size_t ws_bytes, void* stream);
+
+/* y (R x ldy, bf16) = round-to-nearest-even(x (R x C, fp32)), columns C..ldy-1 zero-filled
+ * (padding K up to a multiple of 8/32 for vqf_gemm_bf16).  ldy % 8 == 0. */
+int vqf_cast_f32_bf16(const float* x, int R, int C, int ldx, void* y, int ldy, void* stream);
+
 /* db[n] = sum_m dY[m,n]   (bias gradients of the Linear/Conv layers).
  * ws: scratch of at least vqf_colsum_ws_bytes(M,N) bytes. */
 size_t vqf_colsum_ws_bytes(int M, int N);

@@ -1,0 +1,119 @@
+"""bf16 path (BASELINE config 3): vqf_cast_f32_bf16 + vqf_gemm_bf16 in all four layouts vs fp64
+matmuls of the SAME bf16-rounded values (so only fp32 accumulation differs: tolerance 2e-5), and
+vs the fp32 inputs (bf16 rounding: tolerance 2e-2, stated)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import vqa_amd
+    vqa_amd.lib.load()
+    return vqa_amd.ops
+
+
+def _r(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(shape, generator=g) * 2 - 1) * scale
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def test_cast_rounds_to_nearest_even_and_pads(ops):
+    x = _r((37, 1000), 1)
+    y = ops.cast_bf16(x.cuda(), pad_to=32)
+    assert y.shape == (37, 1024) and y.dtype == torch.bfloat16
+    assert torch.equal(y[:, :1000].cpu(), x.to(torch.bfloat16))
+    assert float(y[:, 1000:].abs().max()) == 0.0
+    big = _r((70000, 16), 2)                      # > 65535 rows: slab loop
+    assert torch.equal(ops.cast_bf16(big.cuda()).cpu(), big.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (136, 264, 72), (392, 1000, 2048), (8, 8, 8),
+                                   (1000, 1024, 392), (640, 512, 8192)])
+def test_gemm_bf16_all_layouts(ops, ta, tb, M, N, K):
+    A = _r((K, M) if ta else (M, K), 3).to(torch.bfloat16)
+    B = _r((K, N) if tb else (N, K), 4).to(torch.bfloat16)
+    bias = _r((N,), 5)
+    ref = (A.double().t() if ta else A.double()) @ (B.double() if tb else B.double().t()) + bias.double()
+    out = ops.gemm_bf16(A.cuda(), B.cuda(), ta=bool(ta), tb=bool(tb), bias=bias.cuda())
+    assert out.shape == (M, N) and out.dtype == torch.float32
+    assert _rel(out, ref) <= 2e-5 * max(1.0, np.sqrt(K) / 16)
+    out2 = ops.gemm_bf16(A.cuda(), B.cuda(), ta=bool(ta), tb=bool(tb), bias=bias.cuda(), relu=True)
+    assert _rel(out2, torch.relu(ref)) <= 2e-5 * max(1.0, np.sqrt(K) / 16)
+
+
+def test_gemm_bf16_padded_k_and_vs_fp32(ops):
+    """K = 1000 padded to 1024 by the cast (the co_att_conv1 shape); error vs un-rounded fp32 inputs."""
+    M, N, K = 392, 512, 1000
+    X, W = _r((M, K), 6), _r((N, K), 7, 0.05)
+    Xb, Wb = ops.cast_bf16(X.cuda(), pad_to=32), ops.cast_bf16(W.cuda(), pad_to=32)
+    out = ops.gemm_bf16(Xb, Wb, K=1024)
+    ref = X.double() @ W.double().t()
+    assert _rel(out, ref) <= 2e-2                  # bf16 storage: 8 mantissa bits
+    ref_b = Xb.double().cpu() @ Wb.double().cpu().t()
+    assert _rel(out, ref_b) <= 2e-5
+
+
+def test_gemm_bf16_rejects_unsupported_shapes(ops):
+    import vqa_amd
+    a = torch.zeros((16, 20), dtype=torch.bfloat16, device="cuda")      # K = 20 not a multiple of 8
+    b = torch.zeros((16, 20), dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(vqa_amd.VqfError):
+        ops.gemm_bf16(a, b)
+    with pytest.raises(vqa_amd.VqfError):
+        ops.gemm_bf16(torch.zeros(4, 8, device="cuda"), torch.zeros(4, 8, device="cuda"))   # fp32 tensors
+
+
+@pytest.mark.parametrize("mhb", [False, True])
+def test_models_in_bf16_mode_track_the_fp32_oracle(mhb):
+    """gemm_dtype='bf16' (config 3): bf16 operands in img_conv1d / co_att_conv1, fp32 elsewhere.
+    Tolerance vs the fp32 oracle: 3e-2 relative on the outputs (8-bit mantissa operands, K = 2048),
+    gradients within 10 % in norm per tensor (sanity; bf16 gradients are not a parity target).
+    Excluded from the gradient check: img_conv1d / ques_proj1 (and the attention biases whose
+    gradient is mathematically 0).  Their gradient passes through the signed square root of the
+    196 000 pooled sums, whose derivative 0.5*|s|^-1/2 is dominated by the few sums nearest 0; a
+    bf16 rounding of the projection (4e-3 relative on P) replaces exactly those sums by noise, so
+    these two gradients move by O(1) (measured 75-90 %, tools/bf16_vs_fp32.py: the co_att_conv1
+    GEMMs in bf16 alone change them by 1.5 %).  That is a property of the model's loss surface,
+    not of the kernels: vqf_gemm_bf16 itself is checked to 2e-5 above."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import vqa_amd, recipe
+    from cases import MFB_CASES, MHBCOATT_CASES
+    from golden_util import mfb_inputs
+    case = dict((MHBCOATT_CASES if mhb else MFB_CASES)[-1 if mhb else -2])      # full-size dims, N=2
+    cfg, img, q, glove, hard, soft = mfb_inputs(case, "cuda")
+    model = (vqa_amd.MHBCoAtt if mhb else vqa_amd.MFB)(cfg)
+    model.load_state_dict({k: torch.from_numpy(recipe.weight_for(k, tuple(v.shape), case["salt"]))
+                           for k, v in model.state_dict().items()})
+    model = model.cuda().train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    if not mhb:
+        model.unit_softmax = False          # live attention so that the bf16 GEMMs reach the output
+    res = {}
+    for mode in ("fp32", "bf16"):           # fp32 mode is parity-proven against the oracle elsewhere
+        model.gemm_dtype = mode
+        model.zero_grad(set_to_none=True)
+        out = model.forward(img, q)
+        loss = torch.nn.KLDivLoss()(out, soft) if mhb else torch.nn.CrossEntropyLoss()(out, hard)
+        loss.backward()
+        res[mode] = (out.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters()})
+    ref, gref = res["fp32"]
+    out, gb = res["bf16"]
+    assert _rel(out, ref) <= 3e-2
+    assert not torch.equal(out, ref)        # the bf16 kernels really ran
+    skip = ("img_conv1d", "ques_proj1", "co_att_conv2.bias", "ques_att_conv2.bias")
+    for k, g_ref in gref.items():
+        if float(g_ref.norm()) < 1e-9 or k.startswith(skip):
+            continue
+        assert float((gb[k] - g_ref).norm()) <= 0.1 * float(g_ref.norm()) + 1e-9, k

@@ -70,3 +70,19 @@ if "small" in which:
     dQ = rnd(args.batch, 5000)
     timeit("img_proj2 dgrad", lambda: ops.gemm(dQ, W4, tb=True), 2.0 * args.batch * 5000 * 4096)
     timeit("img_proj2 wgrad", lambda: ops.gemm(dQ, A4, ta=True, tb=True), 2.0 * args.batch * 5000 * 4096)
+
+if "bf16" in which:
+    Xb = ops.cast_bf16(torch.relu(rnd(M, 2048)))
+    Wb = ops.cast_bf16(rnd(5000, 2048) * 0.03)
+    b = rnd(5000)
+    out = torch.empty(M, 5000, device=dev)
+    timeit("bf16 img_conv1d fwd (a0b0)", lambda: ops.gemm_bf16(Xb, Wb, bias=b, out=out), 2.0 * M * 5000 * 2048)
+    dPb = ops.cast_bf16(rnd(M, 5000))
+    timeit("bf16 img_conv1d wgrad (a1b1)", lambda: ops.gemm_bf16(dPb, Xb, ta=True, tb=True), 2.0 * M * 5000 * 2048)
+    Yb, W1b = ops.cast_bf16(rnd(M, 1000), 32), ops.cast_bf16(rnd(1024, 1000), 32)
+    timeit("bf16 co_att_conv1 fwd", lambda: ops.gemm_bf16(Yb, W1b, K=1024, relu=True), 2.0 * M * 1024 * 1000)
+    dHb = ops.cast_bf16(rnd(M, 1024))
+    timeit("bf16 co_att_conv1 dgrad", lambda: ops.gemm_bf16(dHb, W1b, tb=True, N=1000), 2.0 * M * 1024 * 1000)
+    timeit("bf16 co_att_conv1 wgrad", lambda: ops.gemm_bf16(dHb, Yb, ta=True, tb=True), 2.0 * M * 1024 * 1000)
+    x32 = rnd(M, 5000)
+    timeit("cast f32->bf16 (2 GB)", lambda: ops.cast_bf16(x32), 1.0)

@@ -32,6 +32,8 @@ enum VqfKernelId {
   KID_TANH_DROP_BWD,
   KID_SOFTMAX_FWD,
   KID_SOFTMAX_BWD,
+  KID_GEMM_BF16,
+  KID_CAST_BF16,
   KID_COUNT
 };
 
@@ -52,6 +54,9 @@ void vqf_prof_dims(int d0, int d1, int d2);   // shape tag attached to the next 
 // two-stage column reduction (reduce.hip); scratch holds VQF_REDUCE_SPLITS x W floats
 #define VQF_REDUCE_SPLITS 32
 int vqf_colreduce_2stage(const float* in, int J, int W, float* out, float* scratch, hipStream_t s);
+
+int vqf_splitk_reduce(const float* slab, int splits, int M, int N, float* C, int ldc,
+                      const float* bias, int flags, hipStream_t s);   // gemm_f32.hip
 
 static inline int vqf_last_error() {
   hipError_t e = hipGetLastError();

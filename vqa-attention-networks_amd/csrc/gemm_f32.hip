@@ -376,6 +376,17 @@ int launch_gemm(const GemmArgs& g, dim3 grid, hipStream_t s, int kid) {
 
 }  // namespace
 
+// shared with gemm_bf16.hip
+int vqf_splitk_reduce(const float* slab, int splits, int M, int N, float* C, int ldc,
+                      const float* bias, int flags, hipStream_t s) {
+  const long long total = (long long)M * N;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  VQF_LAUNCH(KID_SPLITK_REDUCE, splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, slab, splits, M,
+             N, C, ldc, bias, flags);
+  return vqf_last_error();
+}
+
 extern "C" int vqf_gemm_f32(int ta, int tb, int M, int N, int K, const float* A, int lda,
                             const float* B, int ldb, float* C, int ldc, const float* bias,
                             int flags, void* ws, size_t ws_bytes, void* stream) {
@@ -425,14 +436,7 @@ extern "C" int vqf_gemm_f32(int ta, int tb, int M, int N, int K, const float* A,
   else if (ta && !tb) rc = launch_gemm<true, false>(g, grid, s, kid);
   else rc = launch_gemm<true, true>(g, grid, s, kid);
   if (rc != VQF_OK) return rc;
-  if (splits > 1) {
-    const long long total = (long long)M * N;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 4096) blocks = 4096;
-    VQF_LAUNCH(KID_SPLITK_REDUCE, splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s,
-               (const float*)ws, splits, M, N, C, ldc, bias, flags);
-    rc = vqf_last_error();
-  }
+  if (splits > 1) rc = vqf_splitk_reduce((const float*)ws, splits, M, N, C, ldc, bias, flags, s);
   return rc;
 }
 

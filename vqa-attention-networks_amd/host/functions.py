@@ -64,10 +64,17 @@ class AttHeadFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, feat, w1, b1, wm, bm, w2, b2, unit_softmax):
+    def forward(ctx, x, feat, w1, b1, wm, bm, w2, b2, unit_softmax, bf16=False):
         x = _c(x)
         feat = _c(feat)
-        hid1 = ops.gemm(x, _w2d(w1), bias=b1, relu=True)
+        ctx.bf16 = bool(bf16)
+        if ctx.bf16:
+            # bf16 operands, fp32 accumulate (BASELINE config 3); K padded to a multiple of 32
+            xb, w1b = ops.cast_bf16(x, 32), ops.cast_bf16(_w2d(w1), 32)
+            hid1 = ops.gemm_bf16(xb, w1b, K=xb.shape[1], bias=b1, relu=True)
+            x = xb                                      # the backward only needs the bf16 copy
+        else:
+            hid1 = ops.gemm(x, _w2d(w1), bias=b1, relu=True)
         hid2 = ops.gemm(hid1, _w2d(wm), bias=bm, relu=True) if wm is not None else None
         last = hid2 if hid2 is not None else hid1
         logits = ops.att_logits_fwd(last, _w2d(w2), b2)
@@ -92,9 +99,18 @@ class AttHeadFn(torch.autograd.Function):
             d1_pre, db1 = ops.relu_bwd(dhid1, hid1, want_bias=True)
         else:
             d1_pre, db1 = dlast_pre, dblast
-        dw1 = ops.gemm(d1_pre, x, ta=True, tb=True).view_as(w1)
-        dx = ops.gemm(d1_pre, _w2d(w1), tb=True) if ctx.needs_input_grad[0] else None
-        return dx, dfeat, dw1, db1, dwm, dbm, dw2.view_as(w2), db2, None
+        if ctx.bf16:
+            cin = _w2d(w1).shape[1]
+            d1b = ops.cast_bf16(d1_pre)
+            dw1 = ops.gemm_bf16(d1b, x, ta=True, tb=True)[:, :cin].contiguous().view_as(w1)
+            dx = None
+            if ctx.needs_input_grad[0]:
+                w1b = ops.cast_bf16(_w2d(w1), 32)
+                dx = ops.gemm_bf16(d1b, w1b, tb=True, N=cin)
+        else:
+            dw1 = ops.gemm(d1_pre, x, ta=True, tb=True).view_as(w1)
+            dx = ops.gemm(d1_pre, _w2d(w1), tb=True) if ctx.needs_input_grad[0] else None
+        return dx, dfeat, dw1, db1, dwm, dbm, dw2.view_as(w2), db2, None, None
 
 
 class ImgFuseFn(torch.autograd.Function):
@@ -106,13 +122,19 @@ class ImgFuseFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, img, wi, bi, q, keep, seed, p_drop):
+    def forward(ctx, img, wi, bi, q, keep, seed, p_drop, bf16=False):
         img = _c(img)
         q = _c(q)
         N, L, D = img.shape
         wi2 = _w2d(wi)
         O = wi2.shape[0] // ops.POOL_K
-        P = ops.gemm(img.view(N * L, D), wi2, bias=bi)
+        ctx.bf16 = bool(bf16)
+        if ctx.bf16:
+            # bf16 storage of the image tensor and the projection weight, fp32 accumulation
+            img = ops.cast_bf16(img.view(N * L, D))
+            P = ops.gemm_bf16(img, ops.cast_bf16(wi2), bias=bi)
+        else:
+            P = ops.gemm(img.view(N * L, D), wi2, bias=bi)
         Y, norm, inv, _ = ops.mfb_fuse_fwd(P, q, N, L, O, keep=keep, seed=seed, p_drop=p_drop)
         ctx.save_for_backward(img, wi, q, P, Y, norm, inv, keep)
         ctx.seed, ctx.p_drop, ctx.dims = seed, p_drop, (N, L, D, O)
@@ -124,8 +146,11 @@ class ImgFuseFn(torch.autograd.Function):
         N, L, D, O = ctx.dims
         dP, dq, _, dbi = ops.mfb_fuse_bwd(_c(dY), Y, norm, inv, P, q, N, L, O, keep=keep, seed=ctx.seed,
                                           p_drop=ctx.p_drop, want_dbias=True)
-        dwi = ops.gemm(dP, img.view(N * L, D), ta=True, tb=True).view_as(wi)   # wgrad, K = N*L
-        return None, dwi, dbi, dq, None, None, None
+        if ctx.bf16:
+            dwi = ops.gemm_bf16(ops.cast_bf16(dP), img, ta=True, tb=True).view_as(wi)
+        else:
+            dwi = ops.gemm(dP, img.view(N * L, D), ta=True, tb=True).view_as(wi)   # wgrad, K = N*L
+        return None, dwi, dbi, dq, None, None, None, None
 
 
 class FinalMfbFn(torch.autograd.Function):

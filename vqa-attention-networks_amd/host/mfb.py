@@ -55,6 +55,9 @@ class MFB(nn.Module):
         self.linear_pred = nn.Linear(1000, cfg.a_vocab_size)
         # reference_compat: mfb.py:84,118 run both softmaxes over a singleton axis (weights == 1)
         self.unit_softmax = True
+        # "fp32" (default, parity 1e-4) or "bf16": bf16 operands / fp32 accumulate for the two large
+        # GEMM families (img_conv1d and co_att_conv1, 96 % of the FLOPs); everything else stays fp32
+        self.gemm_dtype = "fp32"
         self._seeds = _DropSeeds()
 
     # -- helpers -----------------------------------------------------------
@@ -87,11 +90,12 @@ class MFB(nn.Module):
         seed, p = self._seeds.next(self.training, pm)
         k1 = keep.get('m1')
         Y = ImgFuseFn.apply(img_features, self.img_conv1d.weight, self.img_conv1d.bias, qp,
-                            k1, seed, pm if k1 is not None else p)
+                            k1, seed, pm if k1 is not None else p, self.gemm_dtype in ("bf16", "bf16-img"))
         # a7+a8: co-attention over the regions                               mfb.py:109-123
         wm, bm = self._mc('co_att_multiconv')
         va = AttHeadFn.apply(Y, img_features, self.co_att_conv1.weight, self.co_att_conv1.bias, wm, bm,
-                             self.co_att_conv2.weight, self.co_att_conv2.bias, self.unit_softmax)
+                             self.co_att_conv2.weight, self.co_att_conv2.bias, self.unit_softmax,
+                             self.gemm_dtype in ("bf16", "bf16-att"))
         # a9: final MFB block                                                mfb.py:126-135
         seed, p = self._seeds.next(self.training, pm)
         k2 = keep.get('m2')

@@ -34,6 +34,7 @@ class MHBCoAtt(nn.Module):
         self.img_proj3 = nn.Linear(2 * cfg.img_feature_channel, 5000)
         self.linear_pred = nn.Linear(2000, cfg.a_vocab_size)
         self.fix_lstm_orientation = False
+        self.gemm_dtype = "fp32"          # or "bf16" (BASELINE config 3), see MFB.gemm_dtype
         self._seeds = _DropSeeds()
 
     def set_keep_masks(self, **masks):
@@ -62,9 +63,10 @@ class MHBCoAtt(nn.Module):
         seed, p = self._seeds.next(self.training, pm)
         k1 = keep.get('m1')
         Y = ImgFuseFn.apply(img_features, self.img_conv1d.weight, self.img_conv1d.bias, qp,
-                            k1, seed, pm if k1 is not None else p)
+                            k1, seed, pm if k1 is not None else p, self.gemm_dtype in ("bf16", "bf16-img"))
         va = AttHeadFn.apply(Y, img_features, self.co_att_conv1.weight, self.co_att_conv1.bias, None, None,
-                             self.co_att_conv2.weight, self.co_att_conv2.bias, False)
+                             self.co_att_conv2.weight, self.co_att_conv2.bias, False,
+                             self.gemm_dtype in ("bf16", "bf16-att"))
         ys = []
         for tag, qpj, ipj in (('m2', self.ques_proj2, self.img_proj2), ('m3', self.ques_proj3, self.img_proj3)):
             seed, p = self._seeds.next(self.training, pm)

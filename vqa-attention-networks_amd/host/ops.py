@@ -92,6 +92,43 @@ def gemm(a, b, ta=False, tb=False, bias=None, relu=False, out=None, accumulate=F
     return out
 
 
+def _chk_bf16(*ts):
+    for t in ts:
+        if not t.is_cuda or t.dtype != torch.bfloat16 or t.stride(-1) != 1:
+            raise _l.VqfError("bf16 GPU tensor with contiguous rows expected")
+
+
+def cast_bf16(x, pad_to=8):
+    """fp32 (R,C) -> bf16 (R, C rounded up to a multiple of pad_to), zero-padded columns."""
+    _chk(x)
+    R, C = x.shape
+    Cp = (C + pad_to - 1) // pad_to * pad_to
+    y = torch.empty((R, Cp), dtype=torch.bfloat16, device=x.device)
+    _l.check(_lib().vqf_cast_f32_bf16(_ptr(x), R, C, x.stride(0), _ptr(y), Cp, _stream()), "vqf_cast_f32_bf16")
+    return y
+
+
+def gemm_bf16(a, b, ta=False, tb=False, bias=None, relu=False, M=None, N=None, K=None, out=None,
+              accumulate=False):
+    """C fp32 = Aop @ Bop^T with bf16 operands (row strides may exceed the logical widths)."""
+    _chk_bf16(a, b)
+    _chk(bias, out)
+    if M is None:
+        M = a.shape[1] if ta else a.shape[0]
+    if K is None:
+        K = a.shape[0] if ta else a.shape[1]
+    if N is None:
+        N = b.shape[1] if tb else b.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    flags = (GEMM_RELU if relu else 0) | (GEMM_ACCUM if accumulate else 0)
+    ws = workspace(a.device, SPLITK_WS_BYTES)
+    rc = _lib().vqf_gemm_bf16(int(ta), int(tb), M, N, K, _ptr(a), a.stride(0), _ptr(b), b.stride(0),
+                              _ptr(out), out.stride(0), _ptr(bias), flags, _ptr(ws), ws.numel(), _stream())
+    _l.check(rc, "vqf_gemm_bf16")
+    return out
+
+
 def bgemm(a, b, ta=False, tb=False, out=None, accumulate=False):
     """Batched: a (B,M,K)|(B,K,M), b (B,N,K)|(B,K,N) -> (B,M,N)."""
     _chk(a, b, out)
