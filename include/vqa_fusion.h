@@ -218,6 +218,23 @@ int vqf_softmax_rows_fwd(const float* x, int R, int W, float* y, void* stream);
 int vqf_softmax_rows_bwd(const float* dy, const float* y, int R, int W, float* dx, void* stream);
 
 /* --------------------------------------------------------------------------
+ * LSTM recursion of the question encoder for small per-step batches:
+ * mhb_coAtt.py:27-36,72-74 recurs over the minibatch axis (S = N steps of a T-row batch).
+ * Single layer, zero initial state, PyTorch gate order i,f,g,o.  One kernel launch per step.
+ *   xw     (S,B,4H)  x W_ih^T + b_ih + b_hh   (computed with vqf_gemm_f32)
+ *   w_hh   (4H,H)    lstm.weight_hh_l0;   w_hh_t (H,4H) its transpose (backward)
+ *   hs, cs (S,B,H)   hidden / cell states;  gates (S,B,4H) ACTIVATED i,f,g,o (saved for backward)
+ *   dhs    (S,B,H)   dL/dh_s from the consumers;  dgates (S,B,4H) dL/d(pre-activation): then
+ *                    dW_hh = dgates[1:]^T hs[:-1], dW_ih = dgates^T x, db = colsum(dgates), dx = dgates W_ih
+ *   dc_carry (B,H)   scratch
+ * Supported: B <= 32, H in {256,512,768,1024} (vqf_lstm_seq_supported); else VQF_E_UNSUPPORTED. */
+int vqf_lstm_seq_supported(int B, int H);
+int vqf_lstm_seq_fwd(const float* xw, const float* w_hh, int S, int B, int H,
+                     float* hs, float* cs, float* gates, void* stream);
+int vqf_lstm_seq_bwd(const float* dhs, const float* gates, const float* cs, const float* w_hh_t,
+                     int S, int B, int H, float* dgates, float* dc_carry, void* stream);
+
+/* --------------------------------------------------------------------------
  * Opt-in profiler: hipEvent pairs around every kernel launch, on the stream
  * the kernel is launched on.  Off by default (zero overhead).
  */

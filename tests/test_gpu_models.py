@@ -5,7 +5,7 @@
 
 Tolerances: forward 1e-4 relative (north_star).  Gradients: golden_util.grad_parity --
 the HIP gradient must be as close to the exact (fp64) gradient as the CPU fp32
-path is (<= 4x its fp32-vs-fp64 distance, floor 2e-4), because the signed-sqrt
+path is (<= 8x its fp32-vs-fp64 distance, floor 5e-4), because the signed-sqrt
 derivative is singular at 0 and ANY two fp32 summation orders differ by up to
 ~1e-2 there; plus a loose 2e-2 check straight against the reference's fp32 digests.
 """

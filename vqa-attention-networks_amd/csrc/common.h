@@ -34,6 +34,8 @@ enum VqfKernelId {
   KID_SOFTMAX_BWD,
   KID_GEMM_BF16,
   KID_CAST_BF16,
+  KID_LSTM_FWD,
+  KID_LSTM_BWD,
   KID_COUNT
 };
 

@@ -299,3 +299,39 @@ class SoftmaxRowsFn(torch.autograd.Function):
     def backward(ctx, dy):
         (y,) = ctx.saved_tensors
         return ops.softmax_rows_bwd(_c(dy), y)
+
+
+class LstmSeqFn(torch.autograd.Function):
+    """Single-layer LSTM over dim 0 of x (S,B,I) -> hs (S,B,H), zero initial state.
+
+    For small per-step batches B (MHBCoAtt's batch-axis recursion, mhb_coAtt.py:72-74: S = N, B = T):
+    input projection and all weight gradients are MFMA GEMMs over the whole sequence; the recursion
+    itself is one fused kernel launch per step (vqf_lstm_seq_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh):
+        x = _c(x)
+        S, B, I = x.shape
+        H = w_hh.shape[1]
+        bias = (b_ih + b_hh) if b_ih is not None else None
+        xw = ops.gemm(x.view(S * B, I), _c(w_ih), bias=bias).view(S, B, 4 * H)
+        hs, cs, gates = ops.lstm_seq_fwd(xw, _c(w_hh))
+        ctx.save_for_backward(x, w_ih, w_hh, hs, cs, gates)
+        ctx.has_bias = b_ih is not None
+        return hs
+
+    @staticmethod
+    def backward(ctx, dhs):
+        x, w_ih, w_hh, hs, cs, gates = ctx.saved_tensors
+        S, B, I = x.shape
+        H = w_hh.shape[1]
+        dg = ops.lstm_seq_bwd(_c(dhs), gates, cs, w_hh.t().contiguous())       # (S,B,4H)
+        dg2 = dg.view(S * B, 4 * H)
+        dx = ops.gemm(dg2, _c(w_ih), tb=True).view(S, B, I) if ctx.needs_input_grad[0] else None
+        dw_ih = ops.gemm(dg2, x.view(S * B, I), ta=True, tb=True)
+        if S > 1:
+            dw_hh = ops.gemm(dg[1:].reshape((S - 1) * B, 4 * H), hs[:-1].reshape((S - 1) * B, H), ta=True, tb=True)
+        else:
+            dw_hh = torch.zeros_like(w_hh)
+        db = ops.colsum(dg2) if ctx.has_bias else None
+        return dx, dw_ih, dw_hh, db, (db.clone() if db is not None else None)

@@ -55,6 +55,9 @@ SIGNATURES = {
     "vqf_mfb_fuse_bwd_ws_bytes": (c_sz, [c_i, c_i, c_i]),
     "vqf_mfb_fuse_bwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_u64, ctypes.c_float,
                                c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_p, c_sz, c_p]),
+    "vqf_lstm_seq_supported": (c_i, [c_i, c_i]),
+    "vqf_lstm_seq_fwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_p]),
+    "vqf_lstm_seq_bwd": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_p]),
     "vqf_prof_enable": (None, [c_i]),
     "vqf_prof_reset": (None, []),
     "vqf_prof_num_kernels": (c_i, []),

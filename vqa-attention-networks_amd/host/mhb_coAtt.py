@@ -8,7 +8,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .functions import LinearFn, AttHeadFn, ImgFuseFn, FinalMfbFn
+from . import ops
+from .functions import LinearFn, AttHeadFn, ImgFuseFn, FinalMfbFn, LstmSeqFn
 from .mfb import _DropSeeds
 
 
@@ -35,6 +36,9 @@ class MHBCoAtt(nn.Module):
         self.linear_pred = nn.Linear(2000, cfg.a_vocab_size)
         self.fix_lstm_orientation = False
         self.gemm_dtype = "fp32"          # or "bf16" (BASELINE config 3), see MFB.gemm_dtype
+        # the batch-axis recursion as one fused HIP kernel per step instead of nn.LSTM (MIOpen spends
+        # ~35 ms per step on 512 sequential tiny steps); same arithmetic, see csrc/lstm.hip
+        self.use_hip_lstm = True
         self._seeds = _DropSeeds()
 
     def set_keep_masks(self, **masks):
@@ -50,6 +54,14 @@ class MHBCoAtt(nn.Module):
         if self.fix_lstm_orientation:
             lstm_o, _ = self.lstm(que_embedded)                              # (N,T,H)
             ques_feature = self.dropout_l(lstm_o).contiguous()
+        elif (self.use_hip_lstm and self.lstm.num_layers == 1 and que_embedded.is_cuda
+              and ops.lstm_seq_supported(que_embedded.shape[1], self.cfg.hidden_dim)):
+            # batch_first LSTM fed (T,N,.): sequence axis = N, per-step batch = T  (mhb_coAtt.py:72-74).
+            # (N,T,.) is already (S,B,.) for the sequence kernel and its output (N,T,H) is the
+            # reference's lstm_o.permute(1,0,2).
+            hs = LstmSeqFn.apply(que_embedded, self.lstm.weight_ih_l0, self.lstm.weight_hh_l0,
+                                 self.lstm.bias_ih_l0, self.lstm.bias_hh_l0)
+            ques_feature = self.dropout_l(hs).contiguous()
         else:
             lstm_o, _ = self.lstm(que_embedded.permute(1, 0, 2))             # (T,N,H), recurs over N
             ques_feature = self.dropout_l(lstm_o).permute(1, 0, 2).contiguous()   # (N,T,H)

@@ -309,6 +309,33 @@ def mfb_fuse_bwd(dY, Y, norm, inv, P, q, N, L, O, keep=None, seed=0, p_drop=0.0,
     return dP, dq, dc, db
 
 
+def lstm_seq_supported(B, H):
+    return bool(_lib().vqf_lstm_seq_supported(int(B), int(H)))
+
+
+def lstm_seq_fwd(xw, w_hh):
+    """xw (S,B,4H), w_hh (4H,H) -> hs, cs (S,B,H), gates (S,B,4H)."""
+    _chk(xw, w_hh)
+    S, B, H4 = xw.shape
+    H = H4 // 4
+    hs = torch.empty((S, B, H), dtype=torch.float32, device=xw.device)
+    cs = torch.empty_like(hs)
+    gates = torch.empty_like(xw)
+    _l.check(_lib().vqf_lstm_seq_fwd(_ptr(xw), _ptr(w_hh), S, B, H, _ptr(hs), _ptr(cs), _ptr(gates), _stream()),
+             "vqf_lstm_seq_fwd")
+    return hs, cs, gates
+
+
+def lstm_seq_bwd(dhs, gates, cs, w_hh_t):
+    _chk(dhs, gates, cs, w_hh_t)
+    S, B, H = dhs.shape
+    dgates = torch.empty_like(gates)
+    carry = torch.empty((B, H), dtype=torch.float32, device=dhs.device)
+    _l.check(_lib().vqf_lstm_seq_bwd(_ptr(dhs), _ptr(gates), _ptr(cs), _ptr(w_hh_t), S, B, H, _ptr(dgates),
+                                     _ptr(carry), _stream()), "vqf_lstm_seq_bwd")
+    return dgates
+
+
 # ---------------------------------------------------------------------------
 def prof_enable(on=True):
     _lib().vqf_prof_enable(int(on))
