@@ -13,6 +13,14 @@ import torch.nn as nn
 from .functions import LinearFn, AttHeadFn, ImgFuseFn, FinalMfbFn
 
 
+def _image_is_data(img):
+    """The image grid features are input data on this path (no d/d-image kernels: SURVEY 8a, a5)."""
+    if img.requires_grad:
+        from .lib import VqfError
+        raise VqfError("img_features.requires_grad=True: the HIP fusion path treats the image tensor as "
+                       "data and does not produce its gradient")
+
+
 class _DropSeeds:
     """Per-call dropout seeds for the in-kernel Philox masks (train mode)."""
 
@@ -70,6 +78,7 @@ class MFB(nn.Module):
         self._seeds.keep = masks
 
     def forward(self, img_features, questions, is_training=True):
+        _image_is_data(img_features)
         # a2: question encoder (PyTorch-ROCm)                                mfb.py:68-70
         que_embedded = torch.tanh(self.word_embedding(questions))
         lstm_o, _ = self.lstm(que_embedded)

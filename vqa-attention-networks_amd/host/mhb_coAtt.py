@@ -10,7 +10,7 @@ import torch.nn.functional as F
 
 from . import ops
 from .functions import LinearFn, AttHeadFn, ImgFuseFn, FinalMfbFn, LstmSeqFn
-from .mfb import _DropSeeds
+from .mfb import _DropSeeds, _image_is_data
 
 
 class MHBCoAtt(nn.Module):
@@ -45,6 +45,7 @@ class MHBCoAtt(nn.Module):
         self._seeds.keep = masks
 
     def forward(self, img_features, questions, glove_matrix=None, is_training=True):
+        _image_is_data(img_features)
         N, L, D = img_features.shape
         keep = self._seeds.keep
         que_embedded = torch.tanh(self.word_embedding(questions))            # (N,T,E)
