@@ -65,6 +65,15 @@ for r in range(args.rounds):
         b.record()
         torch.cuda.synchronize()
         times[i].append(a.elapsed_time(b) / 2)
+outs = []
+for l in libs:
+    C.zero_()
+    run(l)
+    torch.cuda.synchronize()
+    outs.append(C.clone())
+for p, o in zip(args.libs[1:], outs[1:]):
+    d = float((o - outs[0]).abs().max() / outs[0].abs().max())
+    print("%s vs %s: max rel diff %.2e" % (os.path.basename(p), os.path.basename(args.libs[0]), d), flush=True)
 fl = 2.0 * m * n * k
 for p, t in zip(args.libs, times):
     t = sorted(t)

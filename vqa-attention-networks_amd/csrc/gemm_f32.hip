@@ -40,8 +40,17 @@ namespace {
 #ifndef VQF_GEMM_WAVES_PER_SIMD
 #define VQF_GEMM_WAVES_PER_SIMD 4
 #endif
+// VQF_GEMM_GLDS = 1: tiles go global -> LDS directly (global_load_lds_dwordx4, no VGPR staging, no
+// ds_write pass).  The LDS destination of that instruction is wave-uniform base + lane*16 B, so
+// the K-contiguous image is UNPADDED [row][16] and bank conflicts are avoided by an XOR swizzle of
+// the 16-byte chunk index, applied on the global SOURCE address and again on the fragment reads.
+#ifndef VQF_GEMM_GLDS
+#define VQF_GEMM_GLDS 0
+#endif
 constexpr int BM = 128, BN = 128, BK = VQF_GEMM_BK, NTHREADS = 256;
-constexpr int LD_RK = BK + 4;                 // floats; [row][k] image, 16-B pad
+constexpr bool GLDS = (VQF_GEMM_GLDS != 0) && (BK == 16);
+constexpr int LD_RK = GLDS ? BK : BK + 4;     // floats; [row][k] image (16-B pad unless swizzled)
+__device__ __forceinline__ int rk_swz(int row) { return GLDS ? ((row >> 2) & 3) : 0; }   // chunk XOR
 constexpr int OP_FLOATS = BM * LD_RK;         // >= BK*BM
 constexpr int STAGE_FLOATS = 2 * OP_FLOATS;   // A + B
 constexpr int SMEM_BYTES = 2 * STAGE_FLOATS * 4;   // 73,728 B at BK=32 (double buffered)
@@ -150,12 +159,42 @@ __device__ __forceinline__ void load_fast(gfloat* (&q)[NLD], int ld, f32x4 (&v)[
   }
 }
 
+// ---- direct global -> LDS staging (GLDS): each wave issues 2 x 1 KiB per operand and tile -------
+constexpr int NGL = (BM * BK) / (4 * 64 * 4);     // wave-instructions per wave per operand (2 at BK=16)
+template <bool T>
+__device__ __forceinline__ void init_glds_ptrs(const float* __restrict__ p0, int ld, int r0, int R, int k0,
+                                               int wave, int lane, gfloat* (&q)[NGL]) {
+  gfloat* p = (gfloat*)p0;
+#pragma unroll
+  for (int i = 0; i < NGL; ++i) {
+    const int blk = wave * NGL + i;               // 1-KiB block of the 8-KiB operand image
+    if (!T) {
+      const int row = blk * 16 + (lane >> 2);
+      const int c = (lane & 3) ^ rk_swz(row);     // source chunk that belongs at LDS chunk position lane&3
+      q[i] = p + (long long)min(r0 + row, R - 1) * ld + (k0 + 4 * c);
+    } else {
+      const int k = blk * 2 + (lane >> 5);
+      q[i] = p + (long long)(k0 + k) * ld + min(r0 + ((lane & 31) << 2), R - 4);
+    }
+  }
+}
+template <bool T>
+__device__ __forceinline__ void glds_tile(gfloat* (&q)[NGL], int ld, float* s, int wave) {
+  typedef __attribute__((address_space(3))) float lds_float;
+#pragma unroll
+  for (int i = 0; i < NGL; ++i) {
+    lds_float* dst = (lds_float*)(s + (wave * NGL + i) * 256);
+    __builtin_amdgcn_global_load_lds(q[i], dst, 16, 0, 0);
+    q[i] += T ? (long long)BK * ld : BK;
+  }
+}
+
 template <bool T>
 __device__ __forceinline__ void store_tile(float* s, int tid, const f32x4 (&v)[NLD]) {
 #pragma unroll
   for (int i = 0; i < NLD; ++i) {
     const int f = tid + NTHREADS * i;
-    if (!T) *reinterpret_cast<f32x4*>(s + rk_row(f) * LD_RK + rk_k(f)) = v[i];
+    if (!T) *reinterpret_cast<f32x4*>(s + rk_row(f) * LD_RK + (((rk_k(f) >> 2) ^ rk_swz(rk_row(f))) << 2)) = v[i];
     else    *reinterpret_cast<f32x4*>(s + (f >> 5) * BM + ((f & 31) << 2)) = v[i];
   }
 }
@@ -163,7 +202,7 @@ __device__ __forceinline__ void store_tile(float* s, int tid, const f32x4 (&v)[N
 // fragment of one 32-row sub-tile for k-group g8 (8 consecutive k)
 template <bool T>
 __device__ __forceinline__ f32x4 read_frag(const float* s, int row, int g8, int h) {
-  if (!T) return *reinterpret_cast<const f32x4*>(s + row * LD_RK + g8 * 8 + 4 * h);
+  if (!T) return *reinterpret_cast<const f32x4*>(s + row * LD_RK + (((2 * g8 + h) ^ rk_swz(row)) << 2));
   f32x4 x;
   const float* q = s + (g8 * 8 + 4 * h) * BM + row;
   x[0] = q[0]; x[1] = q[BM]; x[2] = q[2 * BM]; x[3] = q[3 * BM];
@@ -185,38 +224,8 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& g, float* smem, co
     v10 = (m0 + wr * 64 + 32) < g.M;
     v01 = (n0 + wc * 64 + 32) < g.N;
   }
-  gfloat* pa[NLD];
-  gfloat* pb[NLD];
   f32x4 ra[NLD], rb[NLD];
-  if (FAST) {
-    init_ptrs<TA>(gA, g.lda, m0, g.M, kbeg, tid, pa);
-    init_ptrs<TB>(gB, g.ldb, n0, g.N, kbeg, tid, pb);
-  }
-  if (FAST && nfull > 0) {
-    load_fast<TA>(pa, g.lda, ra);
-    load_fast<TB>(pb, g.ldb, rb);
-  } else {
-    load_tile<TA>(gA, g.lda, m0, g.M, kbeg, kend, g.vecA, tid, ra);
-    load_tile<TB>(gB, g.ldb, n0, g.N, kbeg, kend, g.vecB, tid, rb);
-  }
-  store_tile<TA>(smem, tid, ra);
-  store_tile<TB>(smem + OP_FLOATS, tid, rb);
-  __syncthreads();
-
-  for (int t = 0; t < ntiles; ++t) {
-    const float* sA = smem + (t & 1) * STAGE_FLOATS;
-    const float* sB = sA + OP_FLOATS;
-    const bool more = (t + 1) < ntiles;
-    if (more) {                                    // prefetch tile t+1 into registers
-      if (FAST && (t + 1) < nfull) {
-        load_fast<TA>(pa, g.lda, ra);
-        load_fast<TB>(pb, g.ldb, rb);
-      } else {
-        const int k0 = kbeg + (t + 1) * BK;
-        load_tile<TA>(gA, g.lda, m0, g.M, k0, kend, g.vecA, tid, ra);
-        load_tile<TB>(gB, g.ldb, n0, g.N, k0, kend, g.vecB, tid, rb);
-      }
-    }
+  auto mma_tile = [&](const float* sA, const float* sB) {
 #pragma unroll
     for (int g8 = 0; g8 < BK / 8; ++g8) {
       if (!EDGE) {
@@ -252,6 +261,111 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& g, float* smem, co
         }
       }
     }
+  };
+
+  if (FAST && GLDS) {
+    // direct-to-LDS pipeline: the DMA of tile t+1 is in flight while tile t is multiplied; the
+    // __syncthreads() at the end of an iteration carries the s_waitcnt vmcnt(0) that retires it.
+    const int lane = tid & 63, wave = 2 * wr + wc;
+    gfloat* ga[NGL];
+    gfloat* gb[NGL];
+    init_glds_ptrs<TA>(gA, g.lda, m0, g.M, kbeg, wave, lane, ga);
+    init_glds_ptrs<TB>(gB, g.ldb, n0, g.N, kbeg, wave, lane, gb);
+    if (nfull > 0) {
+      glds_tile<TA>(ga, g.lda, smem, wave);
+      glds_tile<TB>(gb, g.ldb, smem + OP_FLOATS, wave);
+    } else {
+      load_tile<TA>(gA, g.lda, m0, g.M, kbeg, kend, g.vecA, tid, ra);
+      load_tile<TB>(gB, g.ldb, n0, g.N, kbeg, kend, g.vecB, tid, rb);
+      store_tile<TA>(smem, tid, ra);
+      store_tile<TB>(smem + OP_FLOATS, tid, rb);
+    }
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+      float* sA = smem + (t & 1) * STAGE_FLOATS;
+      float* sB = sA + OP_FLOATS;
+      float* dA = smem + ((t + 1) & 1) * STAGE_FLOATS;
+      const bool more = (t + 1) < ntiles;
+      const bool dma = (t + 1) < nfull;
+      if (!dma && more) {                          // K tail: guarded register path (zero fill)
+        const int k0 = kbeg + (t + 1) * BK;
+        load_tile<TA>(gA, g.lda, m0, g.M, k0, kend, g.vecA, tid, ra);
+        load_tile<TB>(gB, g.ldb, n0, g.N, k0, kend, g.vecB, tid, rb);
+      }
+      if (!EDGE) {
+        // all fragment reads of tile t FIRST, then the DMA of tile t+1, then the MFMAs: hipcc puts
+        // an s_waitcnt vmcnt(0) in front of any LDS read that follows an LDS-DMA (it cannot tell the
+        // two buffers apart), so a DMA issued before the reads would be waited for immediately.
+        f32x4 af[BK / 8][2], bf[BK / 8][2];
+#pragma unroll
+        for (int g8 = 0; g8 < BK / 8; ++g8) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) af[g8][i] = read_frag<TA>(sA, wr * 64 + i * 32 + l31, g8, h);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) bf[g8][j] = read_frag<TB>(sB, wc * 64 + j * 32 + l31, g8, h);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (dma) {
+          glds_tile<TA>(ga, g.lda, dA, wave);
+          glds_tile<TB>(gb, g.ldb, dA + OP_FLOATS, wave);
+        }
+#pragma unroll
+        for (int g8 = 0; g8 < BK / 8; ++g8)
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g8][i][kk], bf[g8][j][kk], acc[i][j], 0, 0, 0);
+      } else {
+        if (dma) {
+          glds_tile<TA>(ga, g.lda, dA, wave);
+          glds_tile<TB>(gb, g.ldb, dA + OP_FLOATS, wave);
+        }
+        mma_tile(sA, sB);
+      }
+      if (more && !dma) {
+        store_tile<TA>(dA, tid, ra);
+        store_tile<TB>(dA + OP_FLOATS, tid, rb);
+      }
+      __syncthreads();
+    }
+    return;
+  }
+
+  gfloat* pa[NLD];
+  gfloat* pb[NLD];
+  if (FAST) {
+    init_ptrs<TA>(gA, g.lda, m0, g.M, kbeg, tid, pa);
+    init_ptrs<TB>(gB, g.ldb, n0, g.N, kbeg, tid, pb);
+  }
+  if (FAST && nfull > 0) {
+    load_fast<TA>(pa, g.lda, ra);
+    load_fast<TB>(pb, g.ldb, rb);
+  } else {
+    load_tile<TA>(gA, g.lda, m0, g.M, kbeg, kend, g.vecA, tid, ra);
+    load_tile<TB>(gB, g.ldb, n0, g.N, kbeg, kend, g.vecB, tid, rb);
+  }
+  store_tile<TA>(smem, tid, ra);
+  store_tile<TB>(smem + OP_FLOATS, tid, rb);
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    const float* sA = smem + (t & 1) * STAGE_FLOATS;
+    const float* sB = sA + OP_FLOATS;
+    const bool more = (t + 1) < ntiles;
+    if (more) {                                    // prefetch tile t+1 into registers
+      if (FAST && (t + 1) < nfull) {
+        load_fast<TA>(pa, g.lda, ra);
+        load_fast<TB>(pb, g.ldb, rb);
+      } else {
+        const int k0 = kbeg + (t + 1) * BK;
+        load_tile<TA>(gA, g.lda, m0, g.M, k0, kend, g.vecA, tid, ra);
+        load_tile<TB>(gB, g.ldb, n0, g.N, k0, kend, g.vecB, tid, rb);
+      }
+    }
+    mma_tile(sA, sB);
     if (more) {
       float* d = smem + ((t + 1) & 1) * STAGE_FLOATS;
       store_tile<TA>(d, tid, ra);

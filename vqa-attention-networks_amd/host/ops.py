@@ -69,16 +69,21 @@ def gemm(a, b, ta=False, tb=False, bias=None, relu=False, out=None, accumulate=F
 
     ta=False: a is (M,K); ta=True: a is (K,M).   tb=False: b is (N,K); tb=True: b is (K,N).
     """
-    _chk(a, b, bias, out)
+    _chk(bias)
+    for t in (a, b, out):        # 2-D operands may be row-strided views (the ABI takes lda/ldb/ldc)
+        if t is None:
+            continue
+        if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1:
+            raise _l.VqfError("gemm: 2-D fp32 GPU tensors with contiguous rows expected")
     if M is None:
         M = a.shape[1] if ta else a.shape[0]
     if K is None:
         K = a.shape[0] if ta else a.shape[1]
+        kb = b.shape[0] if tb else b.shape[1]
+        if kb != K:
+            raise _l.VqfError("gemm: inner dimensions differ (%d vs %d)" % (K, kb))
     if N is None:
         N = b.shape[1] if tb else b.shape[0]
-    kb = b.shape[0] if tb else b.shape[1]
-    if kb != K:
-        raise _l.VqfError("gemm: inner dimensions differ (%d vs %d)" % (K, kb))
     if out is None:
         if accumulate:
             raise _l.VqfError("gemm: accumulate needs out")
