@@ -225,8 +225,23 @@ def main():
             roofline["wgrad"] = {"kernel": "gemm_f32_a1b1 img_conv1d wgrad (split-K)", "achieved": round(achw, 2),
                                  "frac": round(achw / FP32_MFMA_PEAK_TFLOPS, 4),
                                  "avg_launch_ms": round(ms_w / n_w, 4), "launches": n_w}
+    rep = ops.prof_report()
     kernels = {k: {"launches_per_step": round(n / args.steps, 2), "ms_per_step": round(ms / args.steps, 4)}
-               for k, (n, ms) in sorted(ops.prof_report().items(), key=lambda kv: -kv[1][1])}
+               for k, (n, ms) in sorted(rep.items(), key=lambda kv: -kv[1][1])}
+    # secondary roofline: the HBM-bound MFB fusion kernels (mfb.py:98-106 and its backward).
+    # algorithmic bytes per step: fwd reads P (+q) and writes R for the L=196 stage and the final block;
+    # bwd reads P, dY, Y and writes dP.
+    rows, o5 = B * 196, 5000
+    fwd_bytes = 4.0 * (rows * o5 + B * o5 + rows * 1000 + rows) + 4.0 * (2 * B * o5 + B * 1000)
+    bwd_bytes = 4.0 * (2 * rows * o5 + 2 * rows * 1000 + 2 * B * o5) + 4.0 * (3 * B * o5 + 2 * B * 1000)
+    roofline_hbm = {}
+    for name, nbytes in (("mfb_fuse_fwd", fwd_bytes), ("mfb_fuse_bwd", bwd_bytes)):
+        if name in rep and rep[name][1] > 0:
+            ms_step = rep[name][1] / args.steps
+            gbs = nbytes / (ms_step * 1e-3) / 1e9
+            roofline_hbm[name] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": round(gbs / HBM_PEAK_GBS, 4), "ms_per_step": round(ms_step, 4),
+                                  "algorithmic_bytes_per_step": nbytes}
 
     if rank == 0:
         out = {
@@ -242,6 +257,7 @@ def main():
                        "grad_allreduce_bytes": reducer.gradient_bytes()},
             "loss": round(float(loss.item()), 5),
             "roofline": roofline,
+            "roofline_hbm_kernels": roofline_hbm,
             "kernels_ms_per_step": kernels,
         }
         if world == 1 and not args.no_cpu_baseline:
