@@ -85,3 +85,43 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(dp, f)).read()
                 assert "oracle" not in src.replace("no oracle", ""), os.path.join(dp, f)
                 assert "/root/reference" not in src
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="reference checkout only exists in the build container")
+def test_checkpoints_interchange_with_the_reference_classes(vqa):
+    """solver.save() / train_models.py:58-60: a state_dict written by either implementation loads
+    strictly (same keys, same shapes) into the other."""
+    import importlib.util
+    import sys
+    sys.dont_write_bytecode = True
+
+    def ref_module(name):
+        spec = importlib.util.spec_from_file_location("_ref_" + name, "/root/reference/%s.py" % name)
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        return m
+
+    cfg = make_cfg(MFB_CASES[0])
+    ours, theirs = vqa.MFB(cfg), ref_module("mfb").MFB(cfg)
+    theirs.load_state_dict(ours.state_dict(), strict=True)
+    ours.load_state_dict(theirs.state_dict(), strict=True)
+    cfgh = make_cfg(MHBCOATT_CASES[3])
+    mh = ref_module("mhb_coAtt")
+    ours, theirs = vqa.MHBCoAtt(cfgh), mh.MHBCoAtt(cfgh)
+    theirs.load_state_dict(ours.state_dict(), strict=True)
+    ours.load_state_dict(theirs.state_dict(), strict=True)
+    cfgb = types.SimpleNamespace(q_vocab_size=50, a_vocab_size=30, emb_dim=24, hidden_dim=64,
+                                 img_feature_channel=96, img_feature_dim=196, model_name="mhb")
+    vqa.MHB(cfgb).load_state_dict(mh.MHB(cfgb).state_dict(), strict=True)
+    rh = ref_module("hieCoAtten")
+    kw = dict(block_num=20, word_num=7, img_size=96, vocab_size=50, embed_size=64, output_size=30)
+    vqa.HieCoAtten(**kw).load_state_dict(rh.HieCoAtten(**kw).state_dict(), strict=True)
+    sys.path.insert(0, "/root/reference")           # networks.py does `from modules import Attention_layer`
+    try:
+        rn = ref_module("networks")
+    finally:
+        sys.path.remove("/root/reference")
+        sys.modules.pop("modules", None)
+    kwn = dict(block_num=20, word_num=7, img_size=96, vocab_size=50, embed_size=64, att_num=6, output_size=30)
+    vqa.AttentionNet(**kwn).load_state_dict(rn.AttentionNet(**kwn).state_dict(), strict=True)
+    vqa.iBOWIMG(96, 50, 64, 30).load_state_dict(rn.iBOWIMG(96, 50, 64, 30).state_dict(), strict=True)
