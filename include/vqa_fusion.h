@@ -151,7 +151,9 @@ int vqf_glimpse_pool_bwd(const float* dpooled, const float* dwts_extra, const fl
  *   mfb.py:98-106 (L = 196 regions) and mfb.py:128-135 (L = 1, final block);
  *   mhb_coAtt.py:100-108,126-145.
  *
- *  P    (N*L, 5*O)  projected image features (with bias)
+ *  P    (N*L, 5*O)  projected image features
+ *  pbias (5*O) or NULL: bias of that projection, added on load (P then comes WITHOUT bias; lets the
+ *                   projection GEMM run on its own stream and keeps the bias gradient in this stage)
  *  q    (N,   5*O)  projected question, broadcast over the L rows of a sample
  *  cascade (N*L, 5*O) or NULL: third factor of MHB's high-order block
  *                   (mhb_coAtt.py:205, the dropped-out first-order product)
@@ -162,7 +164,7 @@ int vqf_glimpse_pool_bwd(const float* dpooled, const float* dwts_extra, const fl
  *  rowssq (N*L)     per-row sum of R^2 (= sum |pooled|)
  *  zdrop (N*L,5*O) or NULL: the dropped-out product itself (only MHB needs it)
  */
-int vqf_mfb_fuse_fwd(const float* P, const float* q, const float* cascade,
+int vqf_mfb_fuse_fwd(const float* P, const float* pbias, const float* q, const float* cascade,
                      const uint8_t* keep, uint64_t seed, float p_drop,
                      int N, int L, int O, float* R, float* rowssq, float* zdrop,
                      void* stream);
@@ -188,12 +190,13 @@ int vqf_l2_norm_bwd_coef(const float* rowdot, const float* norm, const float* in
  *   dz[c] = (dS[c/5] + dzdrop[c]) * keep[c] / (1-p)
  *   dP[m,c] = dz * q[n,c] (* cascade),  dq[n,c] = sum_l dz * P[m,c] (* cascade)
  *   dcascade[m,c] = dz * P * q          (if cascade != NULL)
- *   dbias_P[c] = sum_m dP[m,c]          (if dbiasP != NULL)
+ *   dbias_P[c] = sum_m dP[m,c]          (if dbiasP != NULL; this is d pbias as well)
+ * P is taken as P + pbias wherever it appears when pbias != NULL.
  * ws: at least vqf_mfb_fuse_bwd_ws_bytes(N,L,O). */
 size_t vqf_mfb_fuse_bwd_ws_bytes(int N, int L, int O);
 int vqf_mfb_fuse_bwd(const float* dY, const float* dzdrop, const float* Y, const float* inv,
                      const float* coefA, const float* coefB,
-                     const float* P, const float* q, const float* cascade,
+                     const float* P, const float* pbias, const float* q, const float* cascade,
                      const uint8_t* keep, uint64_t seed, float p_drop,
                      int N, int L, int O,
                      float* dP, float* dq, float* dcascade, float* dbiasP,

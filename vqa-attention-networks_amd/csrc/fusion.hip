@@ -64,7 +64,8 @@ __device__ __forceinline__ void keep_scale20(const uint8_t* __restrict__ keep, u
 
 // grid = N*L rows; block = 256
 __global__ void __launch_bounds__(256)
-mfb_fuse_fwd_kernel(const float* __restrict__ P, const float* __restrict__ q,
+mfb_fuse_fwd_kernel(const float* __restrict__ P, const float* __restrict__ pbias,
+                    const float* __restrict__ q,
                     const float* __restrict__ cascade, const uint8_t* __restrict__ keep,
                     uint64_t seed, uint32_t thr, float inv_keep, int L, int O,
                     float* __restrict__ R, float* __restrict__ rowssq, float* __restrict__ zdrop) {
@@ -78,6 +79,11 @@ mfb_fuse_fwd_kernel(const float* __restrict__ P, const float* __restrict__ q,
     const long long e0 = row * W5 + (long long)CPT * t;
     float p[CPT], qq[CPT], sc[CPT];
     load20(P + e0, p);
+    if (pbias) {                       // projection bias folded in here (P then comes without it)
+      load20(pbias + CPT * t, qq);
+#pragma unroll
+      for (int i = 0; i < CPT; ++i) p[i] += qq[i];
+    }
     load20(q + (long long)n * W5 + CPT * t, qq);
     keep_scale20(keep, seed, thr, inv_keep, e0, sc);
 #pragma unroll
@@ -114,6 +120,7 @@ mfb_fuse_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ dzdr
                     const float* __restrict__ Y,
                     const float* __restrict__ inv, const float* __restrict__ coefA,
                     const float* __restrict__ coefB, const float* __restrict__ P,
+                    const float* __restrict__ pbias,
                     const float* __restrict__ q, const float* __restrict__ cascade,
                     const uint8_t* __restrict__ keep, uint64_t seed, uint32_t thr, float inv_keep,
                     int L, int O, int LS, float* __restrict__ dP, float* __restrict__ dq_part,
@@ -122,8 +129,9 @@ mfb_fuse_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ dzdr
   const int W5 = KP * O;
   const float ca = coefA[n], cb = coefB[n], hi = 0.5f * inv[n];
   for (int t = threadIdx.x; t < O / TPT; t += 256) {
-    float qq[CPT], dq[CPT], db[CPT];
+    float qq[CPT], dq[CPT], db[CPT], pb[CPT];
     load20(q + (long long)n * W5 + CPT * t, qq);
+    if (pbias) load20(pbias + CPT * t, pb);
 #pragma unroll
     for (int i = 0; i < CPT; ++i) { dq[i] = 0.f; db[i] = 0.f; }
     for (int l = ls; l < L; l += LS) {
@@ -133,6 +141,10 @@ mfb_fuse_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ dzdr
       const f32x4 y = *reinterpret_cast<const f32x4*>(Y + row * O + TPT * t);
       float p[CPT], sc[CPT], cc[CPT];
       load20(P + e0, p);
+      if (pbias) {
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) p[i] += pb[i];
+      }
       if (CASC) load20(cascade + e0, cc);
       keep_scale20(keep, seed, thr, inv_keep, e0, sc);
       float ds[TPT];
@@ -177,20 +189,22 @@ int pick_ls(int N, int L) {
 
 extern "C" {
 
-int vqf_mfb_fuse_fwd(const float* P, const float* q, const float* cascade, const uint8_t* keep,
+int vqf_mfb_fuse_fwd(const float* P, const float* pbias, const float* q, const float* cascade,
+                     const uint8_t* keep,
                      uint64_t seed, float p_drop, int N, int L, int O, float* R, float* rowssq,
                      float* zdrop, void* stream) {
   if (!P || !q || !R || !rowssq || N <= 0 || L <= 0 || O <= 0) return VQF_E_BADARG;
   if (O % TPT) return VQF_E_UNSUPPORTED;
   if (p_drop < 0.f || p_drop >= 1.f) return VQF_E_BADARG;
-  if (!aligned16(P) || !aligned16(q) || !aligned16(R) || (cascade && !aligned16(cascade)) ||
+  if (!aligned16(P) || (pbias && !aligned16(pbias)) || !aligned16(q) || !aligned16(R) ||
+      (cascade && !aligned16(cascade)) ||
       (zdrop && !aligned16(zdrop)) || (keep && (((uintptr_t)keep) & 3)))
     return VQF_E_ALIGN;
   const uint32_t thr = (keep || p_drop == 0.f) ? 0u : drop_threshold_host(p_drop);
   const float inv_keep = (keep || p_drop > 0.f) ? 1.0f / (1.0f - p_drop) : 1.0f;
   const long long rows = (long long)N * L;
   VQF_LAUNCH(KID_MFB_FUSE_FWD, mfb_fuse_fwd_kernel, dim3((unsigned)rows), dim3(256), 0,
-             (hipStream_t)stream, P, q, cascade, keep, seed, thr, inv_keep, L, O, R, rowssq, zdrop);
+             (hipStream_t)stream, P, pbias, q, cascade, keep, seed, thr, inv_keep, L, O, R, rowssq, zdrop);
   return vqf_last_error();
 }
 
@@ -201,7 +215,8 @@ size_t vqf_mfb_fuse_bwd_ws_bytes(int N, int L, int O) {
 
 int vqf_mfb_fuse_bwd(const float* dY, const float* dzdrop, const float* Y, const float* inv,
                      const float* coefA,
-                     const float* coefB, const float* P, const float* q, const float* cascade,
+                     const float* coefB, const float* P, const float* pbias, const float* q,
+                     const float* cascade,
                      const uint8_t* keep, uint64_t seed, float p_drop, int N, int L, int O,
                      float* dP, float* dq, float* dcascade, float* dbiasP, void* ws,
                      size_t ws_bytes, void* stream) {
@@ -210,7 +225,7 @@ int vqf_mfb_fuse_bwd(const float* dY, const float* dzdrop, const float* Y, const
   if (O % TPT) return VQF_E_UNSUPPORTED;
   if ((cascade != nullptr) != (dcascade != nullptr)) return VQF_E_BADARG;
   if (p_drop < 0.f || p_drop >= 1.f) return VQF_E_BADARG;
-  if (!aligned16(dY) || (dzdrop && !aligned16(dzdrop)) || !aligned16(Y) || !aligned16(P) || !aligned16(q) || !aligned16(dP) ||
+  if (!aligned16(dY) || (dzdrop && !aligned16(dzdrop)) || (pbias && !aligned16(pbias)) || !aligned16(Y) || !aligned16(P) || !aligned16(q) || !aligned16(dP) ||
       !aligned16(dq) || (cascade && (!aligned16(cascade) || !aligned16(dcascade))) ||
       (keep && (((uintptr_t)keep) & 3)))
     return VQF_E_ALIGN;
@@ -228,7 +243,7 @@ int vqf_mfb_fuse_bwd(const float* dY, const float* dzdrop, const float* Y, const
   dim3 grid(N, LS);
 #define VQF_BWD(C_, D_)                                                                        \
   VQF_LAUNCH(KID_MFB_FUSE_BWD, (mfb_fuse_bwd_kernel<C_, D_>), grid, dim3(256), 0, s, dY, dzdrop, Y, inv, \
-             coefA, coefB, P, q, cascade, keep, seed, thr, inv_keep, L, O, LS, dP, dq_part,    \
+             coefA, coefB, P, pbias, q, cascade, keep, seed, thr, inv_keep, L, O, LS, dP, dq_part, \
              dcascade, db_part)
   if (cascade) { if (dbiasP) VQF_BWD(true, true); else VQF_BWD(true, false); }
   else         { if (dbiasP) VQF_BWD(false, true); else VQF_BWD(false, false); }

@@ -153,6 +153,59 @@ class ImgFuseFn(torch.autograd.Function):
         return None, dwi, dbi, dq, None, None, None, None
 
 
+class ImgProjFn(torch.autograd.Function):
+    """a5 alone: P0 = img W^T (NO bias: the bias is added inside the fusion kernel).  Split from the
+    fusion so that the module can run this GEMM -- 86 % of the forward FLOPs, independent of the
+    question path -- on a side stream; autograd then runs its weight-gradient GEMM on that same
+    stream, concurrently with the question-side backward and the gradient all-reduce."""
+
+    @staticmethod
+    def forward(ctx, img, wi, bf16=False):
+        img = _c(img)
+        N, L, D = img.shape
+        wi2 = _w2d(wi)
+        ctx.bf16 = bool(bf16)
+        if ctx.bf16:
+            img2 = ops.cast_bf16(img.view(N * L, D))
+            P0 = ops.gemm_bf16(img2, ops.cast_bf16(wi2))
+        else:
+            img2 = img.view(N * L, D)
+            P0 = ops.gemm(img2, wi2)
+        ctx.save_for_backward(img2, wi)
+        return P0
+
+    @staticmethod
+    def backward(ctx, dP):
+        img2, wi = ctx.saved_tensors
+        dP = _c(dP)
+        if ctx.bf16:
+            dwi = ops.gemm_bf16(ops.cast_bf16(dP), img2, ta=True, tb=True).view_as(wi)
+        else:
+            dwi = ops.gemm(dP, img2, ta=True, tb=True).view_as(wi)            # wgrad, K = N*L
+        return None, dwi, None
+
+
+class MfbFuseFn(torch.autograd.Function):
+    """a6: Y = L2norm_n(ssqrt(pool5(dropout((P0 + bias) * q[n])))) for the L regions of each sample."""
+
+    @staticmethod
+    def forward(ctx, P0, bi, q, keep, seed, p_drop, N, L):
+        P0, q = _c(P0), _c(q)
+        O = P0.shape[1] // ops.POOL_K
+        Y, norm, inv, _ = ops.mfb_fuse_fwd(P0, q, N, L, O, keep=keep, seed=seed, p_drop=p_drop, pbias=bi)
+        ctx.save_for_backward(P0, bi, q, Y, norm, inv, keep)
+        ctx.seed, ctx.p_drop, ctx.dims = seed, p_drop, (N, L, O)
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        P0, bi, q, Y, norm, inv, keep = ctx.saved_tensors
+        N, L, O = ctx.dims
+        dP, dq, _, dbi = ops.mfb_fuse_bwd(_c(dY), Y, norm, inv, P0, q, N, L, O, keep=keep, seed=ctx.seed,
+                                          p_drop=ctx.p_drop, want_dbias=True, pbias=bi)
+        return dP, dbi, dq, None, None, None, None, None
+
+
 class FinalMfbFn(torch.autograd.Function):
     """a9: y = L2norm_row(ssqrt(pool5(dropout((qa Wq^T + bq) * (va Wv^T + bv))))), (N,1000).
 

@@ -47,13 +47,13 @@ SIGNATURES = {
     "vqf_tanh_dropout_bwd": (c_i, [c_f, c_f, c_p, c_u64, ctypes.c_float, ctypes.c_longlong, c_f, c_p]),
     "vqf_softmax_rows_fwd": (c_i, [c_f, c_i, c_i, c_f, c_p]),
     "vqf_softmax_rows_bwd": (c_i, [c_f, c_f, c_i, c_i, c_f, c_p]),
-    "vqf_mfb_fuse_fwd": (c_i, [c_f, c_f, c_f, c_p, c_u64, ctypes.c_float, c_i, c_i, c_i, c_f, c_f, c_f, c_p]),
+    "vqf_mfb_fuse_fwd": (c_i, [c_f, c_f, c_f, c_f, c_p, c_u64, ctypes.c_float, c_i, c_i, c_i, c_f, c_f, c_f, c_p]),
     "vqf_l2_group_norm": (c_i, [c_f, c_i, c_i, c_f, c_f, c_p]),
     "vqf_scale_rows": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f, c_p]),
     "vqf_rowdot": (c_i, [c_f, c_f, c_i, c_i, c_f, c_p]),
     "vqf_l2_norm_bwd_coef": (c_i, [c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_p]),
     "vqf_mfb_fuse_bwd_ws_bytes": (c_sz, [c_i, c_i, c_i]),
-    "vqf_mfb_fuse_bwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_u64, ctypes.c_float,
+    "vqf_mfb_fuse_bwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_u64, ctypes.c_float,
                                c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_p, c_sz, c_p]),
     "vqf_lstm_seq_supported": (c_i, [c_i, c_i]),
     "vqf_lstm_seq_fwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_p]),

@@ -10,7 +10,7 @@ runs in libvqa_fusion.so.
 import torch
 import torch.nn as nn
 
-from .functions import LinearFn, AttHeadFn, ImgFuseFn, FinalMfbFn
+from .functions import LinearFn, AttHeadFn, ImgFuseFn, ImgProjFn, MfbFuseFn, FinalMfbFn
 
 
 def _image_is_data(img):
@@ -19,6 +19,31 @@ def _image_is_data(img):
         from .lib import VqfError
         raise VqfError("img_features.requires_grad=True: the HIP fusion path treats the image tensor as "
                        "data and does not produce its gradient")
+
+
+class _SideStream:
+    """Runs the image projection on a second HIP stream (one per device, created lazily)."""
+
+    def __init__(self):
+        self.streams = {}
+
+    def project(self, img, conv, bf16):
+        dev = img.device
+        side = self.streams.get(dev)
+        if side is None:
+            side = self.streams[dev] = torch.cuda.Stream(device=dev)
+        cur = torch.cuda.current_stream(dev)
+        side.wait_stream(cur)                    # inputs / weights produced on the caller's stream
+        with torch.cuda.stream(side):
+            P0 = ImgProjFn.apply(img, conv.weight, bf16)
+        return P0, side
+
+    @staticmethod
+    def join(P0, side):
+        cur = torch.cuda.current_stream(P0.device)
+        cur.wait_stream(side)
+        P0.record_stream(cur)                    # allocated on the side stream, consumed here
+        return P0
 
 
 class _DropSeeds:
@@ -66,6 +91,10 @@ class MFB(nn.Module):
         # "fp32" (default, parity 1e-4) or "bf16": bf16 operands / fp32 accumulate for the two large
         # GEMM families (img_conv1d and co_att_conv1, 96 % of the FLOPs); everything else stays fp32
         self.gemm_dtype = "fp32"
+        # run img_conv1d (and, through autograd, its weight gradient) on a side stream, concurrently
+        # with the question encoder / question attention (and their backward + gradient all-reduce)
+        self.overlap_streams = True
+        self._side = _SideStream()
         self._seeds = _DropSeeds()
 
     # -- helpers -----------------------------------------------------------
@@ -79,6 +108,9 @@ class MFB(nn.Module):
 
     def forward(self, img_features, questions, is_training=True):
         _image_is_data(img_features)
+        bf16_img = self.gemm_dtype in ("bf16", "bf16-img")
+        # a5 starts first, on the side stream: it only needs the image and its weights
+        proj = self._side.project(img_features, self.img_conv1d, bf16_img) if self.overlap_streams else None
         # a2: question encoder (PyTorch-ROCm)                                mfb.py:68-70
         que_embedded = torch.tanh(self.word_embedding(questions))
         lstm_o, _ = self.lstm(que_embedded)
@@ -98,8 +130,12 @@ class MFB(nn.Module):
         pm = self.dropout_m.p
         seed, p = self._seeds.next(self.training, pm)
         k1 = keep.get('m1')
-        Y = ImgFuseFn.apply(img_features, self.img_conv1d.weight, self.img_conv1d.bias, qp,
-                            k1, seed, pm if k1 is not None else p, self.gemm_dtype in ("bf16", "bf16-img"))
+        if proj is not None:
+            P0 = self._side.join(*proj)
+            Y = MfbFuseFn.apply(P0, self.img_conv1d.bias, qp, k1, seed, pm if k1 is not None else p, N, L)
+        else:
+            Y = ImgFuseFn.apply(img_features, self.img_conv1d.weight, self.img_conv1d.bias, qp,
+                                k1, seed, pm if k1 is not None else p, bf16_img)
         # a7+a8: co-attention over the regions                               mfb.py:109-123
         wm, bm = self._mc('co_att_multiconv')
         va = AttHeadFn.apply(Y, img_features, self.co_att_conv1.weight, self.co_att_conv1.bias, wm, bm,

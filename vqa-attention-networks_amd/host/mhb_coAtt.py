@@ -9,8 +9,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .functions import LinearFn, AttHeadFn, ImgFuseFn, FinalMfbFn, LstmSeqFn
-from .mfb import _DropSeeds, _image_is_data
+from .functions import LinearFn, AttHeadFn, ImgFuseFn, MfbFuseFn, FinalMfbFn, LstmSeqFn
+from .mfb import _DropSeeds, _image_is_data, _SideStream
 
 
 class MHBCoAtt(nn.Module):
@@ -39,6 +39,8 @@ class MHBCoAtt(nn.Module):
         # the batch-axis recursion as one fused HIP kernel per step instead of nn.LSTM (MIOpen spends
         # ~35 ms per step on 512 sequential tiny steps); same arithmetic, see csrc/lstm.hip
         self.use_hip_lstm = True
+        self.overlap_streams = True       # img_conv1d on a side stream, see MFB.overlap_streams
+        self._side = _SideStream()
         self._seeds = _DropSeeds()
 
     def set_keep_masks(self, **masks):
@@ -48,6 +50,8 @@ class MHBCoAtt(nn.Module):
         _image_is_data(img_features)
         N, L, D = img_features.shape
         keep = self._seeds.keep
+        bf16_img = self.gemm_dtype in ("bf16", "bf16-img")
+        proj = self._side.project(img_features, self.img_conv1d, bf16_img) if self.overlap_streams else None
         que_embedded = torch.tanh(self.word_embedding(questions))            # (N,T,E)
         if self.cfg.glove:
             assert glove_matrix is not None, 'glove should not be NoneType.'
@@ -75,8 +79,12 @@ class MHBCoAtt(nn.Module):
         pm = self.dropout_m.p
         seed, p = self._seeds.next(self.training, pm)
         k1 = keep.get('m1')
-        Y = ImgFuseFn.apply(img_features, self.img_conv1d.weight, self.img_conv1d.bias, qp,
-                            k1, seed, pm if k1 is not None else p, self.gemm_dtype in ("bf16", "bf16-img"))
+        if proj is not None:
+            P0 = self._side.join(*proj)
+            Y = MfbFuseFn.apply(P0, self.img_conv1d.bias, qp, k1, seed, pm if k1 is not None else p, N, L)
+        else:
+            Y = ImgFuseFn.apply(img_features, self.img_conv1d.weight, self.img_conv1d.bias, qp,
+                                k1, seed, pm if k1 is not None else p, bf16_img)
         va = AttHeadFn.apply(Y, img_features, self.co_att_conv1.weight, self.co_att_conv1.bias, None, None,
                              self.co_att_conv2.weight, self.co_att_conv2.bias, False,
                              self.gemm_dtype in ("bf16", "bf16-att"))

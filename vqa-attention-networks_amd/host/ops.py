@@ -40,17 +40,19 @@ def _chk(*ts):
 
 
 class _Workspace:
-    """Grow-only scratch buffer per device (split-K slabs, partial sums)."""
+    """Grow-only scratch buffer per (device, stream): kernels on different streams may run
+    concurrently (the image projection runs on a side stream), so they must not share slabs."""
 
     def __init__(self):
         self.bufs = {}
 
     def get(self, device, nbytes):
         nbytes = max(int(nbytes), 256)
-        b = self.bufs.get(device)
+        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        b = self.bufs.get(key)
         if b is None or b.numel() < nbytes:
             b = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
-            self.bufs[device] = b
+            self.bufs[key] = b
         return b
 
 
@@ -273,14 +275,14 @@ def _keep_ptr(keep):
     return ctypes.c_void_p(keep.data_ptr())
 
 
-def mfb_fuse_fwd(P, q, N, L, O, keep=None, seed=0, p_drop=0.0, cascade=None, want_zdrop=False):
-    """-> (Y normalised (N*L,O), norm (N), inv (N), zdrop or None)."""
-    _chk(P, q, cascade)
+def mfb_fuse_fwd(P, q, N, L, O, keep=None, seed=0, p_drop=0.0, cascade=None, want_zdrop=False, pbias=None):
+    """-> (Y normalised (N*L,O), norm (N), inv (N), zdrop or None).  pbias: projection bias added on load."""
+    _chk(P, q, cascade, pbias)
     dev = P.device
     R = torch.empty((N * L, O), dtype=torch.float32, device=dev)
     rowssq = torch.empty(N * L, dtype=torch.float32, device=dev)
     zdrop = torch.empty_like(P) if want_zdrop else None
-    _l.check(_lib().vqf_mfb_fuse_fwd(_ptr(P), _ptr(q), _ptr(cascade), _keep_ptr(keep), int(seed),
+    _l.check(_lib().vqf_mfb_fuse_fwd(_ptr(P), _ptr(pbias), _ptr(q), _ptr(cascade), _keep_ptr(keep), int(seed),
                                      float(p_drop), N, L, O, _ptr(R), _ptr(rowssq), _ptr(zdrop), _stream()),
              "vqf_mfb_fuse_fwd")
     norm = torch.empty(N, dtype=torch.float32, device=dev)
@@ -292,9 +294,9 @@ def mfb_fuse_fwd(P, q, N, L, O, keep=None, seed=0, p_drop=0.0, cascade=None, wan
 
 
 def mfb_fuse_bwd(dY, Y, norm, inv, P, q, N, L, O, keep=None, seed=0, p_drop=0.0, cascade=None,
-                 want_dbias=False, dzdrop=None):
+                 want_dbias=False, dzdrop=None, pbias=None):
     """-> (dP (N*L,5O), dq (N,5O), dcascade or None, dbiasP or None)."""
-    _chk(dY, Y, norm, inv, P, q, cascade, dzdrop)
+    _chk(dY, Y, norm, inv, P, q, cascade, dzdrop, pbias)
     dev = P.device
     rowdot = torch.empty(N * L, dtype=torch.float32, device=dev)
     _l.check(_lib().vqf_rowdot(_ptr(Y), _ptr(dY), N * L, O, _ptr(rowdot), _stream()), "vqf_rowdot")
@@ -307,7 +309,7 @@ def mfb_fuse_bwd(dY, Y, norm, inv, P, q, N, L, O, keep=None, seed=0, p_drop=0.0,
     dc = torch.empty_like(P) if cascade is not None else None
     db = torch.empty(POOL_K * O, dtype=torch.float32, device=dev) if want_dbias else None
     ws = workspace(dev, _lib().vqf_mfb_fuse_bwd_ws_bytes(N, L, O))
-    _l.check(_lib().vqf_mfb_fuse_bwd(_ptr(dY), _ptr(dzdrop), _ptr(Y), _ptr(inv), _ptr(cA), _ptr(cB), _ptr(P), _ptr(q),
+    _l.check(_lib().vqf_mfb_fuse_bwd(_ptr(dY), _ptr(dzdrop), _ptr(Y), _ptr(inv), _ptr(cA), _ptr(cB), _ptr(P), _ptr(pbias), _ptr(q),
                                      _ptr(cascade), _keep_ptr(keep), int(seed), float(p_drop), N, L, O,
                                      _ptr(dP), _ptr(dq), _ptr(dc), _ptr(db), _ptr(ws), ws.numel(), _stream()),
              "vqf_mfb_fuse_bwd")

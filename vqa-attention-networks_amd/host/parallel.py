@@ -103,10 +103,24 @@ class GradientAllReducer:
         bi, off = self._index[p]
         b = self.buckets[bi]
         b["flat"][off:off + p.numel()].copy_(p.grad.reshape(-1))
+        if p.is_cuda:
+            # gradients of one bucket may be produced on different streams (the image projection and
+            # its weight gradient run on a side stream): remember where each copy was enqueued
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(p.device))
+            b.setdefault("events", []).append(ev)
         b["pending"] -= 1
         if b["pending"] == 0:
-            b["handle"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.AVG if self._has_avg() else dist.ReduceOp.SUM,
-                                          group=self.group, async_op=True)
+            self._launch(b)
+
+    def _launch(self, b):
+        if b.get("events"):
+            cur = torch.cuda.current_stream(b["flat"].device)
+            for ev in b["events"]:
+                cur.wait_event(ev)             # the collective is ordered after EVERY copy into the bucket
+            b["events"] = []
+        b["handle"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.AVG if self._has_avg() else dist.ReduceOp.SUM,
+                                      group=self.group, async_op=True)
 
     def _has_avg(self):
         return dist.get_backend(self.group) == "nccl"
@@ -121,8 +135,7 @@ class GradientAllReducer:
                 for p, off, n in b["params"]:
                     if p.grad is None:
                         b["flat"][off:off + n].zero_()
-                b["handle"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.AVG if self._has_avg() else dist.ReduceOp.SUM,
-                                              group=self.group, async_op=True)
+                self._launch(b)
         for b in self.buckets:
             b["handle"].wait()
             if not self._has_avg():
