@@ -14,9 +14,12 @@ from .functions import LinearFn, AttHeadFn, ImgFuseFn, ImgProjFn, MfbFuseFn, Fin
 
 
 def _image_is_data(img):
-    """The image grid features are input data on this path (no d/d-image kernels: SURVEY 8a, a5)."""
+    """The image grid features are input data on this path (no d/d-image kernels: SURVEY 8a, a5),
+    and they must live on the GPU: there is no CPU fallback."""
+    from .lib import VqfError
+    if not img.is_cuda:
+        raise VqfError("vqa fusion modules need GPU tensors (HIP extension is the only path; no CPU fallback)")
     if img.requires_grad:
-        from .lib import VqfError
         raise VqfError("img_features.requires_grad=True: the HIP fusion path treats the image tensor as "
                        "data and does not produce its gradient")
 
