@@ -131,7 +131,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=512, help="QA pairs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--model", default="mfb", choices=["mfb", "mhb_coAtt"])
+    ap.add_argument("--model", default="mfb", choices=["mfb", "mhb_coAtt", "hieCoAtten"],
+                    help="mfb = the headline (BASELINE config 2/5); the others time configs 3 and 4")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="operand type of the two large GEMM families (bf16 = BASELINE config 3 mode)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); "
@@ -154,11 +155,18 @@ def main():
     dev = torch.device("cuda", local)
 
     B = args.batch
-    cfg = full_cfg(args.model)
-    model = (vqa_amd.MFB if args.model == "mfb" else vqa_amd.MHBCoAtt)(cfg)
+    if args.model == "hieCoAtten":
+        if args.batch == 512:
+            B = 256                                   # BASELINE config 4
+        model = vqa_amd.HieCoAtten(block_num=196, word_num=14, img_size=2048, vocab_size=1000,
+                                   embed_size=512, output_size=1000)
+    else:
+        cfg = full_cfg(args.model)
+        model = (vqa_amd.MFB if args.model == "mfb" else vqa_amd.MHBCoAtt)(cfg)
     init_like_reference(model)
     model = model.to(dev).train()
-    model.gemm_dtype = "bf16" if args.dtype == "bf16" else "fp32"
+    if args.model != "hieCoAtten":
+        model.gemm_dtype = "bf16" if args.dtype == "bf16" else "fp32"
     reducer = parallel.GradientAllReducer(model)        # broadcasts rank 0's weights; no-op at world 1
     try:
         opt = torch.optim.Adam(model.parameters(), lr=7e-4, fused=True)
@@ -170,7 +178,9 @@ def main():
     def step():
         opt.zero_grad(set_to_none=True)
         out = model.forward(img, q)
-        loss = F.cross_entropy(out, a) if args.model == "mfb" else F.kl_div(out, soft, reduction="mean")
+        if args.model == "hieCoAtten":
+            out = out[0]
+        loss = F.kl_div(out, soft, reduction="mean") if args.model == "mhb_coAtt" else F.cross_entropy(out, a)
         loss.backward()
         reducer.finish()
         opt.step()
@@ -246,13 +256,13 @@ def main():
     if rank == 0:
         out = {
             "metric": "QA-pairs/sec fwd+bwd, MFB-baseline batch 512" if args.model == "mfb"
-                      else "QA-pairs/sec fwd+bwd, MHBCoAtt batch %d" % B,
+                      else "QA-pairs/sec fwd+bwd, %s batch %d" % (args.model, B),
             "value": round(value, 2), "unit": "QA-pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "MFB-baseline train step (fwd+loss+bwd+grad all-reduce+Adam), "
                                    "batch %d per GPU, 196x2048 image grid, 14 tokens, fp32, mode=faithful"
-                                   % B if args.model == "mfb" else "MHBCoAtt train step, batch %d per GPU" % B,
+                                   % B if args.model == "mfb" else "%s train step, batch %d per GPU" % (args.model, B),
                        "global_batch": B * world, "parallelism": "dp%d" % world,
                        "grad_allreduce_bytes": reducer.gradient_bytes()},
             "loss": round(float(loss.item()), 5),
