@@ -168,10 +168,9 @@ def main():
     if args.model != "hieCoAtten":
         model.gemm_dtype = "bf16" if args.dtype == "bf16" else "fp32"
     reducer = parallel.GradientAllReducer(model)        # broadcasts rank 0's weights; no-op at world 1
-    try:
-        opt = torch.optim.Adam(model.parameters(), lr=7e-4, fused=True)
-    except Exception:
-        opt = torch.optim.Adam(model.parameters(), lr=7e-4)
+    # solver.py:25-29: criterion + Adam, both on the HIP path (host/train_step.py)
+    opt = vqa_amd.Adam(model.parameters(), lr=7e-4)
+    criterion = vqa_amd.train_step.criterion_for(args.model)
     img, q, a = synth_batch(B, rank, dev)
     soft = torch.softmax(torch.randn((B, 1000), generator=torch.Generator().manual_seed(1236 + rank)), 1).to(dev)
 
@@ -180,7 +179,7 @@ def main():
         out = model.forward(img, q)
         if args.model == "hieCoAtten":
             out = out[0]
-        loss = F.kl_div(out, soft, reduction="mean") if args.model == "mhb_coAtt" else F.cross_entropy(out, a)
+        loss = criterion(out, soft if args.model == "mhb_coAtt" else a)
         loss.backward()
         reducer.finish()
         opt.step()

@@ -238,6 +238,39 @@ int vqf_lstm_seq_bwd(const float* dhs, const float* gates, const float* cs, cons
                      int S, int B, int H, float* dgates, float* dc_carry, void* stream);
 
 /* --------------------------------------------------------------------------
+ * Training-step tail (outside the modules, called by the solver loop).
+ *
+ * vqf_ce_loss     nn.CrossEntropyLoss() of solver.py:28,91: logits (N,A), int64 targets (N);
+ *                 loss[0] = mean over rows whose target != -100 of (logsumexp - logit[target]);
+ *                 dlogits (N,A) = d loss / d logits (may be NULL).  Same pass for both.
+ * vqf_kldiv_loss  nn.KLDivLoss() of solver.py:26,91 (default reduction: mean over all N*A
+ *                 elements): loss[0] = mean(t * (log t - logp)), 0 where t == 0;
+ *                 dlogp = -t / (N*A) (may be NULL).
+ * ws: vqf_loss_ws_bytes(N, A) bytes of scratch (fixed-order partial sums; no atomics).
+ */
+size_t vqf_loss_ws_bytes(int N, int A);
+int vqf_ce_loss(const float* logits, const long long* target, int N, int A, float* loss, float* dlogits,
+                void* ws, size_t ws_bytes, void* stream);
+int vqf_kldiv_loss(const float* logp, const float* target, int N, int A, float* loss, float* dlogp,
+                   void* ws, size_t ws_bytes, void* stream);
+
+/* torch.optim.Adam(model.parameters(), lr) of solver.py:29,93 (amsgrad off, maximize off), all
+ * tensors of a step in as few launches as possible (VQF_ADAM_MAX_TENSORS per launch):
+ *   g += wd*p;  m += (g-m)(1-b1);  v = v*b2 + (1-b2) g g;
+ *   p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps)          (step counts from 1)
+ * `tensors` is a HOST array of `count` descriptors holding device pointers. */
+#define VQF_ADAM_MAX_TENSORS 32
+typedef struct VqfAdamTensor {
+  float* param;
+  const float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  long long n;
+} VqfAdamTensor;
+int vqf_adam_step(const VqfAdamTensor* tensors, int count, double lr, double beta1, double beta2, double eps,
+                  double weight_decay, long long step, void* stream);
+
+/* --------------------------------------------------------------------------
  * Opt-in profiler: hipEvent pairs around every kernel launch, on the stream
  * the kernel is launched on.  Off by default (zero overhead).
  */

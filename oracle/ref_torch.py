@@ -348,6 +348,28 @@ def kldiv_loss(logp, soft):
     return F.kl_div(logp, soft, reduction="mean")                      # solver.py:27 default 'mean'
 
 
+def adam_step(params, grads, state, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    """One torch.optim.Adam step (solver.py:29 constructs it with defaults but lr; :93 steps it).
+    The optimizer is a third-party dependency of the reference (torch, version unpinned; 2.10.0
+    here); this restates its published single-tensor algorithm (amsgrad/maximize off) and
+    tests/test_oracle_golden.py pins it against torch.optim.Adam itself.
+    `state` is a list of dicts {'step', 'exp_avg', 'exp_avg_sq'} updated in place."""
+    b1, b2 = betas
+    for p, g, st in zip(params, grads, state):
+        if not st:
+            st["step"] = 0
+            st["exp_avg"] = torch.zeros_like(p)
+            st["exp_avg_sq"] = torch.zeros_like(p)
+        st["step"] += 1
+        t = st["step"]
+        if weight_decay != 0:
+            g = g + weight_decay * p
+        st["exp_avg"] += (g - st["exp_avg"]) * (1 - b1)
+        st["exp_avg_sq"].mul_(b2).add_(g * g * (1 - b2))
+        denom = st["exp_avg_sq"].sqrt() / math.sqrt(1 - b2 ** t) + eps
+        p -= (lr / (1 - b1 ** t)) * (st["exp_avg"] / denom)
+
+
 # --------------------------------------------------------------------------
 # state_dict shape tables (what the reference constructors allocate)
 # --------------------------------------------------------------------------

@@ -245,3 +245,42 @@ def test_mhbcoatt_oracle_fp64_matches_reference_fp64(case):
     assert abs(loss.item() - float(gold["loss64"])) <= 1e-9 * max(1.0, abs(float(gold["loss64"])))
     loss.backward()
     check_grads64({k: v.grad for k, v in sd.items()}, gold)
+
+
+def _sym(name, shape, amp):
+    return torch.from_numpy(recipe.sym_tensor(tuple(shape), amp, recipe.name_seed(name, 0)))
+
+
+@pytest.mark.parametrize("wd", [0.0, 0.01])
+def test_adam_restatement_matches_torch_optim(wd):
+    """solver.py:29,93: the optimizer is torch's; the oracle's restatement must reproduce it."""
+    shapes = [(7,), (33, 5), (4, 3, 1, 1), (1025,)]
+    ps = [torch.nn.Parameter(_sym("adam.p%d" % i, s, 0.5)) for i, s in enumerate(shapes)]
+    mine = [p.detach().clone() for p in ps]
+    state = [dict() for _ in ps]
+    opt = torch.optim.Adam(ps, lr=7e-4, weight_decay=wd)
+    for step in range(6):
+        gs = [_sym("adam.g%d.%d" % (i, step), s, 0.1) for i, s in enumerate(shapes)]
+        for p, g in zip(ps, gs):
+            p.grad = g.clone()
+        lr = 7e-4 * (0.5 if step >= 3 else 1.0)          # solver.py:47-50 adjusts lr in place
+        for grp in opt.param_groups:
+            grp["lr"] = lr
+        opt.step()
+        O.adam_step(mine, gs, state, lr, weight_decay=wd)
+    for p, m in zip(ps, mine):
+        assert rel_err(m, p.detach()) < 1e-6
+
+
+def test_loss_restatements_match_closed_form():
+    """solver.py:26-28: mean CE over rows; KLDivLoss() default = mean over ALL N*A elements."""
+    x = _sym("loss.x", (5, 11), 2.0)
+    a = torch.tensor([0, 10, 3, 3, 7])
+    lse = torch.logsumexp(x.double(), 1)
+    want = (lse - x.double()[torch.arange(5), a]).mean()
+    assert abs(O.ce_loss(x, a).double() - want) < 1e-6
+    t = torch.softmax(_sym("loss.t", (5, 11), 1.0), 1)
+    t[0, :4] = 0.0
+    logp = torch.log_softmax(x, 1)
+    want = torch.where(t > 0, t.double() * (t.double().log() - logp.double()), torch.zeros((), dtype=torch.float64)).sum() / 55
+    assert abs(O.kldiv_loss(logp, t).double() - want) < 1e-7

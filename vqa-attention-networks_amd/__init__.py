@@ -24,8 +24,10 @@ def __getattr__(name):
         "Attention_2": ".host.modules", "Nonlinear_layer": ".host.modules",
         "AttentionNet": ".host.networks", "iBOWIMG": ".host.networks",
         "ops": ".host.ops", "functions": ".host.functions", "parallel": ".host.parallel",
+        "train_step": ".host.train_step", "CrossEntropyLoss": ".host.train_step",
+        "KLDivLoss": ".host.train_step", "Adam": ".host.train_step",
     }
     if name in table:
         mod = importlib.import_module(table[name], __name__)
-        return mod if name in ("ops", "functions", "parallel") else getattr(mod, name)
+        return mod if name in ("ops", "functions", "parallel", "train_step") else getattr(mod, name)
     raise AttributeError(name)

@@ -36,6 +36,9 @@ enum VqfKernelId {
   KID_CAST_BF16,
   KID_LSTM_FWD,
   KID_LSTM_BWD,
+  KID_CE_LOSS,
+  KID_KLDIV_LOSS,
+  KID_ADAM,
   KID_COUNT
 };
 

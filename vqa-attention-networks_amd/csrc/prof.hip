@@ -20,7 +20,8 @@ const char* const kNames[KID_COUNT] = {
     "mfb_fuse_fwd", "l2_group_norm", "scale_rows", "rowdot", "l2_norm_bwd_coef", "mfb_fuse_bwd",
     "dropout", "tanh_dropout_fwd", "tanh_dropout_bwd", "softmax_rows_fwd", "softmax_rows_bwd",
     "gemm_bf16", "cast_f32_bf16",
-    "lstm_seq_fwd(all steps)", "lstm_seq_bwd(all steps)"};
+    "lstm_seq_fwd(all steps)", "lstm_seq_bwd(all steps)",
+    "ce_loss", "kldiv_loss", "adam_step"};
 
 hipEvent_t get_event() {
   std::lock_guard<std::mutex> lk(g_mu);

@@ -58,6 +58,11 @@ SIGNATURES = {
     "vqf_lstm_seq_supported": (c_i, [c_i, c_i]),
     "vqf_lstm_seq_fwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_p]),
     "vqf_lstm_seq_bwd": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_p]),
+    "vqf_loss_ws_bytes": (c_sz, [c_i, c_i]),
+    "vqf_ce_loss": (c_i, [c_f, c_p, c_i, c_i, c_f, c_f, c_p, c_sz, c_p]),
+    "vqf_kldiv_loss": (c_i, [c_f, c_f, c_i, c_i, c_f, c_f, c_p, c_sz, c_p]),
+    "vqf_adam_step": (c_i, [c_p, c_i, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                            ctypes.c_double, ctypes.c_longlong, c_p]),
     "vqf_prof_enable": (None, [c_i]),
     "vqf_prof_reset": (None, []),
     "vqf_prof_num_kernels": (c_i, []),
@@ -66,6 +71,12 @@ SIGNATURES = {
     "vqf_prof_get_shape": (c_i, [c_i, c_i, c_i, c_i, ctypes.POINTER(ctypes.c_longlong),
                                  ctypes.POINTER(ctypes.c_double)]),
 }
+
+class AdamTensor(ctypes.Structure):
+    """VqfAdamTensor of include/vqa_fusion.h."""
+    _fields_ = [("param", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p),
+                ("exp_avg_sq", ctypes.c_void_p), ("n", ctypes.c_longlong)]
+
 
 _ERR = {-1: "VQF_E_BADARG", -2: "VQF_E_ALIGN", -3: "VQF_E_UNSUPPORTED", -4: "VQF_E_WORKSPACE"}
 

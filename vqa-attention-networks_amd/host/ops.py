@@ -344,6 +344,61 @@ def lstm_seq_bwd(dhs, gates, cs, w_hh_t):
 
 
 # ---------------------------------------------------------------------------
+# training-step tail (solver.py:25-29,91-94)
+def _loss_ws(N, A, device):
+    nbytes = int(_lib().vqf_loss_ws_bytes(N, A))
+    return workspace(device, nbytes), nbytes
+
+
+def ce_loss(logits, target, want_grad=True):
+    """-> (loss (1,), dlogits | None): nn.CrossEntropyLoss() forward and gradient in one pass."""
+    _chk(logits)
+    if logits.dim() != 2 or target.shape != (logits.shape[0],):
+        raise _l.VqfError("ce_loss: logits (N,A) and targets (N,) expected")
+    if not target.is_cuda or target.dtype != torch.int64 or not target.is_contiguous():
+        raise _l.VqfError("ce_loss: contiguous int64 GPU targets expected")
+    N, A = logits.shape
+    loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+    d = torch.empty_like(logits) if want_grad else None
+    ws, nb = _loss_ws(N, A, logits.device)
+    _l.check(_lib().vqf_ce_loss(_ptr(logits), _ptr(target), N, A, _ptr(loss), _ptr(d), _ptr(ws), nb, _stream()),
+             "vqf_ce_loss")
+    return loss, d
+
+
+def kldiv_loss(logp, target, want_grad=True):
+    """-> (loss (1,), dlogp | None): nn.KLDivLoss() (element-wise mean) forward and gradient."""
+    _chk(logp, target)
+    if logp.dim() != 2 or target.shape != logp.shape:
+        raise _l.VqfError("kldiv_loss: log-probs and targets of the same (N,A) shape expected")
+    N, A = logp.shape
+    loss = torch.empty(1, dtype=torch.float32, device=logp.device)
+    d = torch.empty_like(logp) if want_grad else None
+    ws, nb = _loss_ws(N, A, logp.device)
+    _l.check(_lib().vqf_kldiv_loss(_ptr(logp), _ptr(target), N, A, _ptr(loss), _ptr(d), _ptr(ws), nb, _stream()),
+             "vqf_kldiv_loss")
+    return loss, d
+
+
+def adam_step(params, grads, exp_avgs, exp_avg_sqs, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0):
+    """In-place torch.optim.Adam update of every tensor in the lists (one launch per 32 tensors)."""
+    n = len(params)
+    if not (len(grads) == len(exp_avgs) == len(exp_avg_sqs) == n):
+        raise _l.VqfError("adam_step: list lengths differ")
+    if n == 0:
+        return
+    tab = (_l.AdamTensor * n)()
+    for i, (p, g, m, v) in enumerate(zip(params, grads, exp_avgs, exp_avg_sqs)):
+        _chk(p, g, m, v)
+        if not (p.numel() == g.numel() == m.numel() == v.numel()):
+            raise _l.VqfError("adam_step: tensor %d: sizes differ" % i)
+        tab[i].param, tab[i].grad = p.data_ptr(), g.data_ptr()
+        tab[i].exp_avg, tab[i].exp_avg_sq, tab[i].n = m.data_ptr(), v.data_ptr(), p.numel()
+    _l.check(_lib().vqf_adam_step(ctypes.cast(tab, ctypes.c_void_p), n, float(lr), float(beta1), float(beta2),
+                                  float(eps), float(weight_decay), int(step), _stream()), "vqf_adam_step")
+
+
+# ---------------------------------------------------------------------------
 def prof_enable(on=True):
     _lib().vqf_prof_enable(int(on))
 
