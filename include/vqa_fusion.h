@@ -238,6 +238,14 @@ int vqf_lstm_seq_bwd(const float* dhs, const float* gates, const float* cs, cons
                      int S, int B, int H, float* dgates, float* dc_carry, void* stream);
 
 /* --------------------------------------------------------------------------
+ * Input staging.  data_loader.py:30-32 loads one [2048,14,14] .npy per image
+ * and makes it (196,2048) on the CPU (np.transpose(x,(1,2,0)).reshape(-1,2048)).  Here the raw
+ * batch src (N, D, L) fp32 (channels outermost, as stored) is transposed on the device into the
+ * layout every kernel above consumes, dst (N, L, D), as fp32 (out_bf16 = 0, bit-exact copy) or
+ * bf16 (out_bf16 = 1, round-to-nearest-even).  src and dst must not overlap. */
+int vqf_feat_transpose(const float* src, int N, int D, int L, int out_bf16, void* dst, void* stream);
+
+/* --------------------------------------------------------------------------
  * Training-step tail (outside the modules, called by the solver loop).
  *
  * vqf_ce_loss     nn.CrossEntropyLoss() of solver.py:28,91: logits (N,A), int64 targets (N);

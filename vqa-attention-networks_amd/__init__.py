@@ -26,8 +26,9 @@ def __getattr__(name):
         "ops": ".host.ops", "functions": ".host.functions", "parallel": ".host.parallel",
         "train_step": ".host.train_step", "CrossEntropyLoss": ".host.train_step",
         "KLDivLoss": ".host.train_step", "Adam": ".host.train_step",
+        "data_loader": ".host.data_loader", "FeatureStager": ".host.data_loader",
     }
     if name in table:
         mod = importlib.import_module(table[name], __name__)
-        return mod if name in ("ops", "functions", "parallel", "train_step") else getattr(mod, name)
+        return mod if name in ("ops", "functions", "parallel", "train_step", "data_loader") else getattr(mod, name)
     raise AttributeError(name)

@@ -39,6 +39,7 @@ enum VqfKernelId {
   KID_CE_LOSS,
   KID_KLDIV_LOSS,
   KID_ADAM,
+  KID_FEAT_TRANSPOSE,
   KID_COUNT
 };
 

@@ -58,6 +58,7 @@ SIGNATURES = {
     "vqf_lstm_seq_supported": (c_i, [c_i, c_i]),
     "vqf_lstm_seq_fwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_p]),
     "vqf_lstm_seq_bwd": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_p]),
+    "vqf_feat_transpose": (c_i, [c_f, c_i, c_i, c_i, c_i, c_p, c_p]),
     "vqf_loss_ws_bytes": (c_sz, [c_i, c_i]),
     "vqf_ce_loss": (c_i, [c_f, c_p, c_i, c_i, c_f, c_f, c_p, c_sz, c_p]),
     "vqf_kldiv_loss": (c_i, [c_f, c_f, c_i, c_i, c_f, c_f, c_p, c_sz, c_p]),

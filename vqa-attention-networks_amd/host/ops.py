@@ -344,6 +344,24 @@ def lstm_seq_bwd(dhs, gates, cs, w_hh_t):
 
 
 # ---------------------------------------------------------------------------
+# input staging (data_loader.py:30-32)
+def feat_transpose(src, out=None, bf16=False):
+    """src (N, D, L) fp32 as stored by the feature extractor -> (N, L, D) fp32 | bf16."""
+    _chk(src)
+    if src.dim() != 3:
+        raise _l.VqfError("feat_transpose: (N, D, L) expected")
+    N, D, L = src.shape
+    dt = torch.bfloat16 if bf16 else torch.float32
+    if out is None:
+        out = torch.empty((N, L, D), dtype=dt, device=src.device)
+    elif out.shape != (N, L, D) or out.dtype != dt or not out.is_contiguous() or not out.is_cuda:
+        raise _l.VqfError("feat_transpose: out must be a contiguous (N, L, D) %s GPU tensor" % dt)
+    _l.check(_lib().vqf_feat_transpose(_ptr(src), N, D, L, 1 if bf16 else 0, _ptr(out), _stream()),
+             "vqf_feat_transpose")
+    return out
+
+
+# ---------------------------------------------------------------------------
 # training-step tail (solver.py:25-29,91-94)
 def _loss_ws(N, A, device):
     nbytes = int(_lib().vqf_loss_ws_bytes(N, A))
