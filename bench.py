@@ -172,6 +172,10 @@ def main():
     opt = vqa_amd.Adam(model.parameters(), lr=7e-4)
     criterion = vqa_amd.train_step.criterion_for(args.model)
     img, q, a = synth_batch(B, rank, dev)
+    if args.dtype == "bf16" and args.model != "hieCoAtten":
+        # the image grid is stored in bf16 (vqf_cast_f32_bf16 == what
+        # FeatureStager(bf16=True) delivers); products accumulate in fp32
+        img = ops.cast_bf16(img.view(-1, img.shape[-1])).view(img.shape)
     soft = torch.softmax(torch.randn((B, 1000), generator=torch.Generator().manual_seed(1236 + rank)), 1).to(dev)
 
     def step():

@@ -146,6 +146,15 @@ int vqf_glimpse_pool_bwd(const float* dpooled, const float* dwts_extra, const fl
                          const float* wts, int N, int S, int C, int G, int unit_softmax,
                          float* dlogits, float* dfeat, void* stream);
 
+/* The same two stages over a bf16 feature tensor (bf16 storage of the image grid, BASELINE config 3;
+ * produced by vqf_feat_transpose(out_bf16=1) or vqf_cast_f32_bf16): products and sums in fp32.
+ * The feature tensor is data, so there is no dfeat.  C % 4 == 0 for the vector path. */
+int vqf_glimpse_pool_fwd_bf16(const void* feat, const float* logits, int N, int S, int C, int G,
+                              int unit_softmax, float* wts, float* pooled, void* stream);
+int vqf_glimpse_pool_bwd_bf16(const float* dpooled, const float* dwts_extra, const void* feat,
+                              const float* wts, int N, int S, int C, int G, int unit_softmax,
+                              float* dlogits, void* stream);
+
 /* --------------------------------------------------------------------------
  * MFB fusion: product, dropout, k=5 sum-pool, signed sqrt, L2 normalise.
  *   mfb.py:98-106 (L = 196 regions) and mfb.py:128-135 (L = 1, final block);

@@ -117,3 +117,81 @@ def test_models_in_bf16_mode_track_the_fp32_oracle(mhb):
         if float(g_ref.norm()) < 1e-9 or k.startswith(skip):
             continue
         assert float((gb[k] - g_ref).norm()) <= 0.1 * float(g_ref.norm()) + 1e-9, k
+
+
+# ---- bf16 FEATURE STORAGE: the image grid kept in bf16 in HBM ------------------
+@pytest.mark.parametrize("G,unit", [(2, False), (2, True), (1, False)])
+@pytest.mark.parametrize("N,S,C", [(3, 196, 2048), (2, 20, 96), (2, 7, 52)])
+def test_glimpse_kernels_on_bf16_features_equal_fp32_kernels_on_the_same_values(ops, N, S, C, G, unit):
+    """Same arithmetic, narrower loads: results must be BIT-identical to the fp32-feature kernels run
+    on the bf16-rounded values widened back to fp32."""
+    feat_b = _r((N, S, C), 11).to(torch.bfloat16).cuda()
+    feat_f = feat_b.float()
+    logits = _r((N * S, G), 12, 2.0).cuda()
+    w_b, p_b = ops.glimpse_pool_fwd(feat_b, logits, unit)
+    w_f, p_f = ops.glimpse_pool_fwd(feat_f, logits, unit)
+    assert torch.equal(w_b, w_f) and torch.equal(p_b, p_f)
+    dpool = _r((N, G * C), 13).cuda()
+    dl_b, none = ops.glimpse_pool_bwd(dpool, feat_b, w_b, unit, False)
+    dl_f, _ = ops.glimpse_pool_bwd(dpool, feat_f, w_f, unit, False)
+    assert none is None and torch.equal(dl_b, dl_f)
+    from vqa_amd import VqfError
+    with pytest.raises(VqfError):
+        ops.glimpse_pool_bwd(dpool, feat_b, w_b, unit, True)        # no gradient into bf16 data
+
+
+@pytest.mark.parametrize("mhb", [False, True])
+def test_models_take_bf16_feature_tensors(mhb):
+    """A bf16 image tensor (what FeatureStager(bf16=True) delivers) gives, in gemm_dtype='bf16', exactly
+    the outputs and gradients of the fp32 tensor holding the same bf16-representable values (the per-step
+    cast is then exact, so both runs multiply identical operands); fp32 mode refuses bf16 features."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import vqa_amd, recipe
+    from vqa_amd import VqfError
+    from cases import MFB_CASES, MHBCOATT_CASES
+    from golden_util import mfb_inputs
+    case = dict((MHBCOATT_CASES if mhb else MFB_CASES)[-1 if mhb else -2])
+    cfg, img, q, glove, hard, soft = mfb_inputs(case, "cuda")
+    model = (vqa_amd.MHBCoAtt if mhb else vqa_amd.MFB)(cfg)
+    model.load_state_dict({k: torch.from_numpy(recipe.weight_for(k, tuple(v.shape), case["salt"]))
+                           for k, v in model.state_dict().items()})
+    model = model.cuda().train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    if not mhb:
+        model.unit_softmax = False
+    img_b = img.to(torch.bfloat16)
+    res = []
+    model.gemm_dtype = "bf16"
+    for x in (img_b, img_b.float()):
+        model.zero_grad(set_to_none=True)
+        out = model.forward(x, q)
+        loss = torch.nn.KLDivLoss()(out, soft) if mhb else torch.nn.CrossEntropyLoss()(out, hard)
+        loss.backward()
+        res.append((out.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters()}))
+    assert torch.equal(res[0][0], res[1][0])
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k
+    model.gemm_dtype = "fp32"
+    with pytest.raises(VqfError):
+        model.forward(img_b, q)
+
+
+def test_mhb_mean_pool_accepts_bf16_features():
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import vqa_amd
+    from cases import MFB_CASES, make_cfg
+    cfg = make_cfg(dict(MFB_CASES[0], model_name="mhb"))
+    N, T = 3, 7
+    torch.manual_seed(0)
+    m = vqa_amd.MHB(cfg).cuda().eval()
+    img = torch.rand(N, cfg.img_feature_dim, cfg.img_feature_channel, device="cuda").to(torch.bfloat16)
+    q = torch.randint(1, cfg.q_vocab_size, (N, T), device="cuda")
+    ql = torch.tensor([T, 3, 5])
+    with torch.no_grad():
+        a = m.forward(img, q, ql)
+        b = m.forward(img.float(), q, ql)
+    assert torch.equal(a, b)

@@ -121,10 +121,23 @@ __global__ void att_logits_bwd_kernel(const float* __restrict__ dl, const float*
   }
 }
 
+// feature element loaders: the pooled tensor is fp32 or (bf16 feature storage) bf16
+template <typename FT> __device__ __forceinline__ f32x4 load4(const FT* p);
+template <> __device__ __forceinline__ f32x4 load4<float>(const float* p) {
+  return *reinterpret_cast<const f32x4*>(p);
+}
+template <> __device__ __forceinline__ f32x4 load4<__bf16>(const __bf16* p) {
+  const uint2 r = *reinterpret_cast<const uint2*>(p);        // 4 bf16 = 8 bytes
+  f32x4 o;
+  o[0] = __uint_as_float(r.x << 16); o[1] = __uint_as_float(r.x & 0xffff0000u);
+  o[2] = __uint_as_float(r.y << 16); o[3] = __uint_as_float(r.y & 0xffff0000u);
+  return o;
+}
+
 // ---- softmax over S + G glimpse sums ---------------------------------------------------------
 // grid (ceil(C/1024), N); thread = 4 consecutive channels
-template <int G>
-__global__ void glimpse_pool_fwd_kernel(const float* __restrict__ feat,
+template <int G, typename FT>
+__global__ void glimpse_pool_fwd_kernel(const FT* __restrict__ feat,
                                         const float* __restrict__ logits, int N, int S, int C,
                                         int unit, float* __restrict__ wts,
                                         float* __restrict__ pooled) {
@@ -154,7 +167,7 @@ __global__ void glimpse_pool_fwd_kernel(const float* __restrict__ feat,
 
   const int c = (blockIdx.x * blockDim.x + tid) * 4;
   if (c >= C) return;
-  const float* f = feat + (long long)n * S * C + c;
+  const FT* f = feat + (long long)n * S * C + c;
   const bool vec = ((C & 3) == 0) && aligned16_dev(feat) && aligned16_dev(pooled);
   f32x4 a[G];
 #pragma unroll
@@ -162,10 +175,10 @@ __global__ void glimpse_pool_fwd_kernel(const float* __restrict__ feat,
   if (vec) {
     int s = 0;
     for (; s + 3 < S; s += 4) {
-      const f32x4 x0 = *reinterpret_cast<const f32x4*>(f + (long long)s * C);
-      const f32x4 x1 = *reinterpret_cast<const f32x4*>(f + (long long)(s + 1) * C);
-      const f32x4 x2 = *reinterpret_cast<const f32x4*>(f + (long long)(s + 2) * C);
-      const f32x4 x3 = *reinterpret_cast<const f32x4*>(f + (long long)(s + 3) * C);
+      const f32x4 x0 = load4<FT>(f + (long long)s * C);
+      const f32x4 x1 = load4<FT>(f + (long long)(s + 1) * C);
+      const f32x4 x2 = load4<FT>(f + (long long)(s + 2) * C);
+      const f32x4 x3 = load4<FT>(f + (long long)(s + 3) * C);
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         a[g] += x0 * w[g][s];
@@ -175,7 +188,7 @@ __global__ void glimpse_pool_fwd_kernel(const float* __restrict__ feat,
       }
     }
     for (; s < S; ++s) {
-      const f32x4 x = *reinterpret_cast<const f32x4*>(f + (long long)s * C);
+      const f32x4 x = load4<FT>(f + (long long)s * C);
 #pragma unroll
       for (int g = 0; g < G; ++g) a[g] += x * w[g][s];
     }
@@ -186,7 +199,7 @@ __global__ void glimpse_pool_fwd_kernel(const float* __restrict__ feat,
     const int nc = min(4, C - c);
     for (int s = 0; s < S; ++s)
       for (int j = 0; j < nc; ++j) {
-        const float x = f[(long long)s * C + j];
+        const float x = (float)f[(long long)s * C + j];
 #pragma unroll
         for (int g = 0; g < G; ++g) a[g][j] += x * w[g][s];
       }
@@ -198,10 +211,10 @@ __global__ void glimpse_pool_fwd_kernel(const float* __restrict__ feat,
 
 // block per sample; wave per position s (strided); then the softmax backward.
 // dwts_extra (N,G,S) or null: gradient arriving through the returned attention weights.
-template <int G>
+template <int G, typename FT>
 __global__ void glimpse_pool_bwd_kernel(const float* __restrict__ dpooled,
                                         const float* __restrict__ dwts_extra,
-                                        const float* __restrict__ feat,
+                                        const FT* __restrict__ feat,
                                         const float* __restrict__ wts, int N, int S, int C, int unit,
                                         float* __restrict__ dlogits, float* __restrict__ dfeat) {
   __shared__ float dw[G][MAXS];
@@ -214,14 +227,14 @@ __global__ void glimpse_pool_bwd_kernel(const float* __restrict__ dpooled,
   const bool vec = ((C & 3) == 0) && aligned16_dev(feat) && aligned16_dev(dpooled) &&
                    (dfeat == nullptr || aligned16_dev(dfeat));
   for (int s = wave; s < S; s += nwave) {
-    const float* f = feat + ((long long)n * S + s) * C;
+    const FT* f = feat + ((long long)n * S + s) * C;
     float* df = dfeat ? dfeat + ((long long)n * S + s) * C : nullptr;
     float a[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) a[g] = 0.f;
     if (vec) {
       for (int c = lane * 4; c < C; c += 256) {
-        const f32x4 x = *reinterpret_cast<const f32x4*>(f + c);
+        const f32x4 x = load4<FT>(f + c);
         f32x4 o = {0, 0, 0, 0};
 #pragma unroll
         for (int g = 0; g < G; ++g) {
@@ -233,7 +246,7 @@ __global__ void glimpse_pool_bwd_kernel(const float* __restrict__ dpooled,
       }
     } else {
       for (int c = lane; c < C; c += 64) {
-        const float x = f[c];
+        const float x = (float)f[c];
         float o = 0.f;
 #pragma unroll
         for (int g = 0; g < G; ++g) { a[g] += x * dp[g * C + c]; o += ws[g][s] * dp[g * C + c]; }
@@ -317,34 +330,65 @@ int vqf_att_logits_bwd(const float* dlogits, const float* hid, const float* w2, 
   return e == hipSuccess ? VQF_OK : (int)e;
 }
 
-int vqf_glimpse_pool_fwd(const float* feat, const float* logits, int N, int S, int C, int G,
-                         int unit_softmax, float* wts, float* pooled, void* stream) {
+}  // extern "C"
+
+namespace {
+template <typename FT>
+int glimpse_fwd_launch(const FT* feat, const float* logits, int N, int S, int C, int G, int unit_softmax,
+                       float* wts, float* pooled, void* stream) {
   if (!feat || !logits || !pooled || N <= 0 || S <= 0 || C <= 0) return VQF_E_BADARG;
   if (S > MAXS || (G != 1 && G != 2) || N > 65535) return VQF_E_UNSUPPORTED;
   dim3 grid((C + 1023) / 1024, N);
   hipStream_t s = (hipStream_t)stream;
   if (G == 2)
-    VQF_LAUNCH(KID_GLIMPSE_FWD, glimpse_pool_fwd_kernel<2>, grid, dim3(256), 0, s, feat, logits, N, S,
+    VQF_LAUNCH(KID_GLIMPSE_FWD, (glimpse_pool_fwd_kernel<2, FT>), grid, dim3(256), 0, s, feat, logits, N, S,
                C, unit_softmax, wts, pooled);
   else
-    VQF_LAUNCH(KID_GLIMPSE_FWD, glimpse_pool_fwd_kernel<1>, grid, dim3(256), 0, s, feat, logits, N, S,
+    VQF_LAUNCH(KID_GLIMPSE_FWD, (glimpse_pool_fwd_kernel<1, FT>), grid, dim3(256), 0, s, feat, logits, N, S,
                C, unit_softmax, wts, pooled);
   return vqf_last_error();
+}
+
+template <typename FT>
+int glimpse_bwd_launch(const float* dpooled, const float* dwts_extra, const FT* feat, const float* wts, int N,
+                       int S, int C, int G, int unit_softmax, float* dlogits, float* dfeat, void* stream) {
+  if (!dpooled || !feat || !wts || !dlogits || N <= 0 || S <= 0 || C <= 0) return VQF_E_BADARG;
+  if (S > MAXS || (G != 1 && G != 2)) return VQF_E_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  if (G == 2)
+    VQF_LAUNCH(KID_GLIMPSE_BWD, (glimpse_pool_bwd_kernel<2, FT>), dim3(N), dim3(256), 0, s, dpooled,
+               dwts_extra, feat, wts, N, S, C, unit_softmax, dlogits, dfeat);
+  else
+    VQF_LAUNCH(KID_GLIMPSE_BWD, (glimpse_pool_bwd_kernel<1, FT>), dim3(N), dim3(256), 0, s, dpooled,
+               dwts_extra, feat, wts, N, S, C, unit_softmax, dlogits, dfeat);
+  return vqf_last_error();
+}
+}  // namespace
+
+extern "C" {
+
+int vqf_glimpse_pool_fwd(const float* feat, const float* logits, int N, int S, int C, int G,
+                         int unit_softmax, float* wts, float* pooled, void* stream) {
+  return glimpse_fwd_launch<float>(feat, logits, N, S, C, G, unit_softmax, wts, pooled, stream);
+}
+
+int vqf_glimpse_pool_fwd_bf16(const void* feat, const float* logits, int N, int S, int C, int G,
+                              int unit_softmax, float* wts, float* pooled, void* stream) {
+  return glimpse_fwd_launch<__bf16>((const __bf16*)feat, logits, N, S, C, G, unit_softmax, wts, pooled, stream);
 }
 
 int vqf_glimpse_pool_bwd(const float* dpooled, const float* dwts_extra, const float* feat,
                          const float* wts, int N, int S, int C, int G, int unit_softmax,
                          float* dlogits, float* dfeat, void* stream) {
-  if (!dpooled || !feat || !wts || !dlogits || N <= 0 || S <= 0 || C <= 0) return VQF_E_BADARG;
-  if (S > MAXS || (G != 1 && G != 2)) return VQF_E_UNSUPPORTED;
-  hipStream_t s = (hipStream_t)stream;
-  if (G == 2)
-    VQF_LAUNCH(KID_GLIMPSE_BWD, glimpse_pool_bwd_kernel<2>, dim3(N), dim3(256), 0, s, dpooled,
-               dwts_extra, feat, wts, N, S, C, unit_softmax, dlogits, dfeat);
-  else
-    VQF_LAUNCH(KID_GLIMPSE_BWD, glimpse_pool_bwd_kernel<1>, dim3(N), dim3(256), 0, s, dpooled,
-               dwts_extra, feat, wts, N, S, C, unit_softmax, dlogits, dfeat);
-  return vqf_last_error();
+  return glimpse_bwd_launch<float>(dpooled, dwts_extra, feat, wts, N, S, C, G, unit_softmax, dlogits, dfeat,
+                                   stream);
+}
+
+int vqf_glimpse_pool_bwd_bf16(const float* dpooled, const float* dwts_extra, const void* feat,
+                              const float* wts, int N, int S, int C, int G, int unit_softmax,
+                              float* dlogits, void* stream) {
+  return glimpse_bwd_launch<__bf16>(dpooled, dwts_extra, (const __bf16*)feat, wts, N, S, C, G, unit_softmax,
+                                    dlogits, nullptr, stream);
 }
 
 }  // extern "C"

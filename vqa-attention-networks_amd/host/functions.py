@@ -131,7 +131,7 @@ class ImgFuseFn(torch.autograd.Function):
         ctx.bf16 = bool(bf16)
         if ctx.bf16:
             # bf16 storage of the image tensor and the projection weight, fp32 accumulation
-            img = ops.cast_bf16(img.view(N * L, D))
+            img = img.view(N * L, D) if img.dtype == torch.bfloat16 else ops.cast_bf16(img.view(N * L, D))
             P = ops.gemm_bf16(img, ops.cast_bf16(wi2), bias=bi)
         else:
             P = ops.gemm(img.view(N * L, D), wi2, bias=bi)
@@ -166,7 +166,8 @@ class ImgProjFn(torch.autograd.Function):
         wi2 = _w2d(wi)
         ctx.bf16 = bool(bf16)
         if ctx.bf16:
-            img2 = ops.cast_bf16(img.view(N * L, D))
+            # bf16 feature storage (FeatureStager(bf16=True)): the batch is used as it is, no per-step cast
+            img2 = img.view(N * L, D) if img.dtype == torch.bfloat16 else ops.cast_bf16(img.view(N * L, D))
             P0 = ops.gemm_bf16(img2, ops.cast_bf16(wi2))
         else:
             img2 = img.view(N * L, D)

@@ -42,6 +42,8 @@ SIGNATURES = {
     "vqf_att_logits_bwd": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_p, c_sz, c_p]),
     "vqf_glimpse_pool_fwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_p]),
     "vqf_glimpse_pool_bwd": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_p]),
+    "vqf_glimpse_pool_fwd_bf16": (c_i, [c_p, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_p]),
+    "vqf_glimpse_pool_bwd_bf16": (c_i, [c_f, c_f, c_p, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_p]),
     "vqf_dropout_f32": (c_i, [c_f, c_p, c_u64, ctypes.c_float, ctypes.c_longlong, c_f, c_p]),
     "vqf_tanh_dropout_fwd": (c_i, [c_f, c_f, c_p, c_u64, ctypes.c_float, ctypes.c_longlong, c_f, c_p]),
     "vqf_tanh_dropout_bwd": (c_i, [c_f, c_f, c_p, c_u64, ctypes.c_float, ctypes.c_longlong, c_f, c_p]),

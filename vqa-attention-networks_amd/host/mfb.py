@@ -13,12 +13,21 @@ import torch.nn as nn
 from .functions import LinearFn, AttHeadFn, ImgFuseFn, ImgProjFn, MfbFuseFn, FinalMfbFn
 
 
-def _image_is_data(img):
+def _image_is_data(img, gemm_dtype="fp32"):
     """The image grid features are input data on this path (no d/d-image kernels: SURVEY 8a, a5),
-    and they must live on the GPU: there is no CPU fallback."""
+    and they must live on the GPU: there is no CPU fallback.  A bf16 feature tensor (bf16 storage,
+    data_loader.FeatureStager(bf16=True)) is accepted when the image projection runs in bf16."""
     from .lib import VqfError
     if not img.is_cuda:
         raise VqfError("vqa fusion modules need GPU tensors (HIP extension is the only path; no CPU fallback)")
+    if img.dtype == torch.bfloat16:
+        if gemm_dtype not in ("bf16", "bf16-img"):
+            raise VqfError("bf16 img_features need model.gemm_dtype = 'bf16' (or 'bf16-img'); "
+                           "the fp32 path takes fp32 features")
+        if img.shape[-1] % 8:
+            raise VqfError("bf16 img_features: the channel count must be a multiple of 8")
+    elif img.dtype != torch.float32:
+        raise VqfError("img_features must be fp32 or bf16, got %s" % img.dtype)
     if img.requires_grad:
         raise VqfError("img_features.requires_grad=True: the HIP fusion path treats the image tensor as "
                        "data and does not produce its gradient")
@@ -110,7 +119,7 @@ class MFB(nn.Module):
         self._seeds.keep = masks
 
     def forward(self, img_features, questions, is_training=True):
-        _image_is_data(img_features)
+        _image_is_data(img_features, self.gemm_dtype)
         bf16_img = self.gemm_dtype in ("bf16", "bf16-img")
         # a5 starts first, on the side stream: it only needs the image and its weights
         proj = self._side.project(img_features, self.img_conv1d, bf16_img) if self.overlap_streams else None

@@ -47,7 +47,7 @@ class MHBCoAtt(nn.Module):
         self._seeds.keep = masks
 
     def forward(self, img_features, questions, glove_matrix=None, is_training=True):
-        _image_is_data(img_features)
+        _image_is_data(img_features, self.gemm_dtype)
         N, L, D = img_features.shape
         keep = self._seeds.keep
         bf16_img = self.gemm_dtype in ("bf16", "bf16-img")
@@ -131,7 +131,13 @@ class MHB(nn.Module):
         batch_size, max_len = questions.size()
         keep = self._seeds.keep
         # AvgPool2d(14,14) over the (N,C,14,14) view == mean over the 196 regions   :178-180
-        i_mean = img_feature.reshape(batch_size, -1, self.cfg.img_feature_channel).mean(1)
+        # (the glimpse kernel with unit weights sums the regions; fp32 or bf16 feature storage)
+        img3 = img_feature.reshape(batch_size, -1, self.cfg.img_feature_channel)
+        _image_is_data(img3, "bf16")
+        img3 = img3 if img3.is_contiguous() else img3.contiguous()
+        L = img3.shape[1]
+        _, i_sum = ops.glimpse_pool_fwd(img3, torch.zeros((batch_size * L, 1), device=img3.device), True)
+        i_mean = i_sum * (1.0 / L)
         q_embedded = self.Embedding(questions).permute(1, 0, 2)              # (T,N,E)  :181-182
         lstm_outs, _ = self.LSTM(q_embedded)                                 # (T,N,H)
         idx = (q_length.to(torch.long) - 1).to(lstm_outs.device)

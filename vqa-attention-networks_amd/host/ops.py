@@ -204,22 +204,36 @@ def att_logits_bwd(dlogits, hid, w2, relu_mask=True):
 
 
 def glimpse_pool_fwd(feat, logits, unit_softmax):
-    """feat (N,S,C), logits (N*S,G) -> wts (N,G,S), pooled (N,G*C)."""
-    _chk(feat, logits)
+    """feat (N,S,C) fp32 | bf16, logits (N*S,G) -> wts (N,G,S), pooled (N,G*C) (fp32)."""
+    bf = feat.dtype == torch.bfloat16
+    (_chk_bf16 if bf else _chk)(feat)
+    if not feat.is_contiguous():
+        raise _l.VqfError("contiguous feature tensor expected")
+    _chk(logits)
     N, S, C = feat.shape
     G = logits.shape[1]
     wts = torch.empty((N, G, S), dtype=torch.float32, device=feat.device)
     pooled = torch.empty((N, G * C), dtype=torch.float32, device=feat.device)
-    _l.check(_lib().vqf_glimpse_pool_fwd(_ptr(feat), _ptr(logits), N, S, C, G, int(bool(unit_softmax)),
-                                         _ptr(wts), _ptr(pooled), _stream()), "vqf_glimpse_pool_fwd")
+    fn = _lib().vqf_glimpse_pool_fwd_bf16 if bf else _lib().vqf_glimpse_pool_fwd
+    _l.check(fn(_ptr(feat), _ptr(logits), N, S, C, G, int(bool(unit_softmax)), _ptr(wts), _ptr(pooled), _stream()),
+             "vqf_glimpse_pool_fwd")
     return wts, pooled
 
 
 def glimpse_pool_bwd(dpooled, feat, wts, unit_softmax, want_dfeat, dwts=None):
-    _chk(dpooled, feat, wts, dwts)
+    _chk(dpooled, wts, dwts)
     N, S, C = feat.shape
     G = wts.shape[1]
     dlogits = torch.empty((N * S, G), dtype=torch.float32, device=feat.device)
+    if feat.dtype == torch.bfloat16:             # bf16 feature storage: the tensor is data
+        _chk_bf16(feat)
+        if want_dfeat:
+            raise _l.VqfError("glimpse_pool_bwd: a bf16 feature tensor cannot receive a gradient")
+        _l.check(_lib().vqf_glimpse_pool_bwd_bf16(_ptr(dpooled), _ptr(dwts), _ptr(feat), _ptr(wts), N, S, C, G,
+                                                  int(bool(unit_softmax)), _ptr(dlogits), _stream()),
+                 "vqf_glimpse_pool_bwd_bf16")
+        return dlogits, None
+    _chk(feat)
     dfeat = torch.empty_like(feat) if want_dfeat else None
     _l.check(_lib().vqf_glimpse_pool_bwd(_ptr(dpooled), _ptr(dwts), _ptr(feat), _ptr(wts), N, S, C, G,
                                          int(bool(unit_softmax)), _ptr(dlogits), _ptr(dfeat), _stream()),
