@@ -40,6 +40,7 @@ extern "C" {
 #define VQF_E_ALIGN (-2)       /* pointer or leading dimension not 16-B aligned where required */
 #define VQF_E_UNSUPPORTED (-3) /* shape outside what the kernel supports     */
 #define VQF_E_WORKSPACE (-4)   /* caller's scratch buffer too small          */
+#define VQF_E_TIMEOUT (-5)     /* an in-launch hand-off timed out (vqf_lstm_persist_status) */
 
 #define VQF_POOL_K 5           /* mfb.py:100  .view(N, L, 1000, 5)           */
 
@@ -245,6 +246,22 @@ int vqf_lstm_seq_fwd(const float* xw, const float* w_hh, int S, int B, int H,
                      float* hs, float* cs, float* gates, void* stream);
 int vqf_lstm_seq_bwd(const float* dhs, const float* gates, const float* cs, const float* w_hh_t,
                      int S, int B, int H, float* dgates, float* dc_carry, void* stream);
+
+/* The same recursion as ONE launch for the whole sequence (csrc/lstm_persist.hip): W_hh stays in
+ * registers, the H/4 workgroups hand the recurrent state to each other through HBM with
+ * write-through stores + per-step arrival counters (forward: all-gather of h_s; backward:
+ * reduce-scatter of the partial products dG_s W_hh, summed in a fixed order).  Same tensors as
+ * above; the backward takes W_hh itself, not its transpose.  ws: vqf_lstm_persist_ws_bytes(S,B,H)
+ * bytes (the forward only needs the counters at its start).  Supported: B <= 16, H in
+ * {256,512,768,1024}.  All spins are bounded: vqf_lstm_persist_status(ws, stream) synchronises the
+ * stream and returns VQF_E_TIMEOUT if the last launch gave up (its outputs then hold NaN). */
+int vqf_lstm_persist_supported(int B, int H);
+size_t vqf_lstm_persist_ws_bytes(int S, int B, int H);
+int vqf_lstm_seq_fwd_persist(const float* xw, const float* w_hh, int S, int B, int H, float* hs, float* cs,
+                             float* gates, void* ws, size_t ws_bytes, void* stream);
+int vqf_lstm_seq_bwd_persist(const float* dhs, const float* gates, const float* cs, const float* w_hh,
+                             int S, int B, int H, float* dgates, void* ws, size_t ws_bytes, void* stream);
+int vqf_lstm_persist_status(const void* ws, void* stream);
 
 /* --------------------------------------------------------------------------
  * Input staging.  data_loader.py:30-32 loads one [2048,14,14] .npy per image

@@ -12,8 +12,9 @@
 // A workgroup owns 4 hidden units = 16 gate columns = one 16x16 MFMA tile (256 workgroups at
 // H = 1024, one per CU); its waves split the reduction dimension and v_mfma_f32_16x16x4_f32 does
 // the cross-lane sums (a VALU + shuffle formulation measured 21-28 us per step, of which most was
-// the 340-shuffle reduction tree per wave).  Forward: every lane first issues ALL its W_hh loads,
-// h_{s-1} (B x H fp32, 57 KB at B=14) is staged once per workgroup in LDS.  Backward: dG_{s+1}
+// the 340-shuffle reduction tree per wave).  Forward: every lane first issues ALL its W_hh loads and
+// reads its h_{s-1} fragments (B x H fp32, 57 KB at B=14, shared by all workgroups) straight from L2
+// (staging them in LDS measured 10.6 instead of 8.9 us per step).  Backward: dG_{s+1}
 // (B x 4H) and the W_hh^T rows are read straight from L2.  W_hh (16 MB) stays resident in the
 // Infinity Cache across the 512 steps.  The input
 // projection xw = x W_ih^T + b_ih + b_hh and all weight gradients (dW_ih, dW_hh, dx) are plain
@@ -26,6 +27,9 @@ namespace {
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
+#ifndef VQF_LSTM_DIRECT
+#define VQF_LSTM_DIRECT 1
+#endif
 constexpr int UPB = 4;           // hidden units per workgroup = 16 gate columns = one MFMA 16x16 tile
 constexpr int FWD_WAVES = 4;     // forward: K = H split over 4 waves
 constexpr int BWD_WAVES = 8;     // backward: K = 4H split over 8 waves
@@ -48,8 +52,12 @@ lstm_step_fwd_kernel(const float* __restrict__ xw_s, const float* __restrict__ w
                      float* __restrict__ gates_out) {
   constexpr int H = 256 * KI, KW = H / FWD_WAVES, NC = KW / 16;
   extern __shared__ __attribute__((aligned(16))) float smem[];
+#if VQF_LSTM_DIRECT
+  float* part = smem;                        // [FWD_WAVES][2][16][16]   (two 16-row batch halves)
+#else
   float* hbuf = smem;                        // [B][H]
   float* part = smem + 32 * H;               // [FWD_WAVES][2][16][16]   (two 16-row batch halves)
+#endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, g = lane >> 4;
@@ -61,19 +69,28 @@ lstm_step_fwd_kernel(const float* __restrict__ xw_s, const float* __restrict__ w
     const float* wr = w_hh + (long long)((r >> 2) * H + u0 + (r & 3)) * H + wave * KW + 4 * g;
 #pragma unroll
     for (int c = 0; c < NC; ++c) wv[c] = *reinterpret_cast<const f32x4*>(wr + 16 * c);
+#if !VQF_LSTM_DIRECT
     for (int i = tid * 4; i < B * H; i += 64 * FWD_WAVES * 4)
       *reinterpret_cast<f32x4*>(hbuf + i) = *reinterpret_cast<const f32x4*>(h_prev + i);
     __syncthreads();
+#endif
     for (int hb = 0; hb < nh; ++hb) {
       const int b = hb * 16 + r;
+#if VQF_LSTM_DIRECT
+      // A fragments straight from L2 (h_{s-1} is 56 KB, shared by all workgroups): no LDS staging, so the
+      // kernel needs 4 KB of LDS and can share a CU with the image-projection GEMM of the side stream
+      const float* hr = h_prev + (long long)(b < B ? b : 0) * H + wave * KW + 4 * g;
+#else
       const float* hr = hbuf + (b < B ? b : 0) * H + wave * KW + 4 * g;
+#endif
       const float keep = b < B ? 1.f : 0.f;
+      f32x4 hv[NC];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) hv[c] = *reinterpret_cast<const f32x4*>(hr + 16 * c);
       f32x4v acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
 #pragma unroll
       for (int c = 0; c < NC; c += 2) {
-        f32x4 h0 = *reinterpret_cast<const f32x4*>(hr + 16 * c);
-        f32x4 h1 = *reinterpret_cast<const f32x4*>(hr + 16 * (c + 1));
-        h0 *= keep; h1 *= keep;
+        const f32x4 h0 = hv[c] * keep, h1 = hv[c + 1] * keep;
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
           acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(h0[jj], wv[c][jj], acc0, 0, 0, 0);
@@ -197,7 +214,11 @@ template <int KI>
 int run_fwd(const float* xw, const float* w_hh, int S, int B, float* hs, float* cs, float* gates,
             hipStream_t s) {
   constexpr int H = 256 * KI;
+#if VQF_LSTM_DIRECT
+  const size_t smem = (size_t)FWD_WAVES * 2 * 256 * sizeof(float);
+#else
   const size_t smem = ((size_t)32 * H + (size_t)FWD_WAVES * 2 * 256) * sizeof(float);
+#endif
   int rc = set_smem(lstm_step_fwd_kernel<KI>, smem);
   if (rc) return rc;
   const long long bh = (long long)B * H;

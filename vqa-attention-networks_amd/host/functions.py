@@ -360,7 +360,8 @@ class LstmSeqFn(torch.autograd.Function):
 
     For small per-step batches B (MHBCoAtt's batch-axis recursion, mhb_coAtt.py:72-74: S = N, B = T):
     input projection and all weight gradients are MFMA GEMMs over the whole sequence; the recursion
-    itself is one fused kernel launch per step (vqf_lstm_seq_fwd / _bwd)."""
+    itself is ONE launch for the whole sequence when B <= 16 (vqf_lstm_seq_fwd_persist / _bwd_persist,
+    ops.LSTM_PERSISTENT), else one fused kernel launch per step (vqf_lstm_seq_fwd / _bwd)."""
 
     @staticmethod
     def forward(ctx, x, w_ih, w_hh, b_ih, b_hh):
@@ -369,7 +370,9 @@ class LstmSeqFn(torch.autograd.Function):
         H = w_hh.shape[1]
         bias = (b_ih + b_hh) if b_ih is not None else None
         xw = ops.gemm(x.view(S * B, I), _c(w_ih), bias=bias).view(S, B, 4 * H)
-        hs, cs, gates = ops.lstm_seq_fwd(xw, _c(w_hh))
+        persist = bool(ops.LSTM_PERSISTENT) and ops.lstm_persist_supported(B, H)
+        ctx.persist_bwd = persist and ops.LSTM_PERSISTENT != "fwd"
+        hs, cs, gates = (ops.lstm_seq_fwd_persist if persist else ops.lstm_seq_fwd)(xw, _c(w_hh))
         ctx.save_for_backward(x, w_ih, w_hh, hs, cs, gates)
         ctx.has_bias = b_ih is not None
         return hs
@@ -379,7 +382,10 @@ class LstmSeqFn(torch.autograd.Function):
         x, w_ih, w_hh, hs, cs, gates = ctx.saved_tensors
         S, B, I = x.shape
         H = w_hh.shape[1]
-        dg = ops.lstm_seq_bwd(_c(dhs), gates, cs, w_hh.t().contiguous())       # (S,B,4H)
+        if ctx.persist_bwd:
+            dg = ops.lstm_seq_bwd_persist(_c(dhs), gates, cs, _c(w_hh))            # (S,B,4H)
+        else:
+            dg = ops.lstm_seq_bwd(_c(dhs), gates, cs, w_hh.t().contiguous())
         dg2 = dg.view(S * B, 4 * H)
         dx = ops.gemm(dg2, _c(w_ih), tb=True).view(S, B, I) if ctx.needs_input_grad[0] else None
         dw_ih = ops.gemm(dg2, x.view(S * B, I), ta=True, tb=True)

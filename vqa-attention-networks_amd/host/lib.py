@@ -13,6 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_DIR = os.path.dirname(_HERE)
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libvqa_fusion.so")
+if os.environ.get("VQF_LIB"):          # A/B builds (tools/build_variant.sh); never a different implementation
+    LIB_PATH = os.path.abspath(os.environ["VQF_LIB"])
 HEADER_PATH = os.path.join(os.path.dirname(PKG_DIR), "include", "vqa_fusion.h")
 
 _lock = threading.Lock()
@@ -60,6 +62,11 @@ SIGNATURES = {
     "vqf_lstm_seq_supported": (c_i, [c_i, c_i]),
     "vqf_lstm_seq_fwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_p]),
     "vqf_lstm_seq_bwd": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_p]),
+    "vqf_lstm_persist_supported": (c_i, [c_i, c_i]),
+    "vqf_lstm_persist_ws_bytes": (c_sz, [c_i, c_i, c_i]),
+    "vqf_lstm_seq_fwd_persist": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_p, c_sz, c_p]),
+    "vqf_lstm_seq_bwd_persist": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_p, c_sz, c_p]),
+    "vqf_lstm_persist_status": (c_i, [c_p, c_p]),
     "vqf_feat_transpose": (c_i, [c_f, c_i, c_i, c_i, c_i, c_p, c_p]),
     "vqf_loss_ws_bytes": (c_sz, [c_i, c_i]),
     "vqf_ce_loss": (c_i, [c_f, c_p, c_i, c_i, c_f, c_f, c_p, c_sz, c_p]),
@@ -81,7 +88,7 @@ class AdamTensor(ctypes.Structure):
                 ("exp_avg_sq", ctypes.c_void_p), ("n", ctypes.c_longlong)]
 
 
-_ERR = {-1: "VQF_E_BADARG", -2: "VQF_E_ALIGN", -3: "VQF_E_UNSUPPORTED", -4: "VQF_E_WORKSPACE"}
+_ERR = {-1: "VQF_E_BADARG", -2: "VQF_E_ALIGN", -3: "VQF_E_UNSUPPORTED", -4: "VQF_E_WORKSPACE", -5: "VQF_E_TIMEOUT"}
 
 
 class VqfError(RuntimeError):

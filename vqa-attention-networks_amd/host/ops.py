@@ -357,6 +357,59 @@ def lstm_seq_bwd(dhs, gates, cs, w_hh_t):
     return dgates
 
 
+# whole-sequence ("persistent") LSTM: one launch for all steps (csrc/lstm_persist.hip)
+# module-level switch (A/B and tests): True / "both" = forward and backward, "fwd" = forward only,
+# False = the per-step kernels.  Env VQF_LSTM_PERSIST=0|fwd|both overrides the default.
+import os as _os
+LSTM_PERSISTENT = {"0": False, "fwd": "fwd", "both": True}.get(_os.environ.get("VQF_LSTM_PERSIST", "0"), False)
+_lstm_ws = {}
+
+
+def lstm_persist_supported(B, H):
+    return bool(_lib().vqf_lstm_persist_supported(int(B), int(H)))
+
+
+def _lstm_persist_ws(S, B, H, device):
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    nbytes = int(_lib().vqf_lstm_persist_ws_bytes(S, B, H))
+    b = _lstm_ws.get(key)
+    if b is None or b.numel() < nbytes:
+        b = _lstm_ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return b, nbytes
+
+
+def lstm_seq_fwd_persist(xw, w_hh):
+    _chk(xw, w_hh)
+    S, B, H4 = xw.shape
+    H = H4 // 4
+    hs = torch.empty((S, B, H), dtype=torch.float32, device=xw.device)
+    cs = torch.empty_like(hs)
+    gates = torch.empty_like(xw)
+    ws, nb = _lstm_persist_ws(S, B, H, xw.device)
+    _l.check(_lib().vqf_lstm_seq_fwd_persist(_ptr(xw), _ptr(w_hh), S, B, H, _ptr(hs), _ptr(cs), _ptr(gates),
+                                             _ptr(ws), nb, _stream()), "vqf_lstm_seq_fwd_persist")
+    return hs, cs, gates
+
+
+def lstm_seq_bwd_persist(dhs, gates, cs, w_hh):
+    _chk(dhs, gates, cs, w_hh)
+    S, B, H = dhs.shape
+    dgates = torch.empty_like(gates)
+    ws, nb = _lstm_persist_ws(S, B, H, dhs.device)
+    _l.check(_lib().vqf_lstm_seq_bwd_persist(_ptr(dhs), _ptr(gates), _ptr(cs), _ptr(w_hh), S, B, H, _ptr(dgates),
+                                             _ptr(ws), nb, _stream()), "vqf_lstm_seq_bwd_persist")
+    return dgates
+
+
+def lstm_persist_status(device=None):
+    """Synchronises and raises VqfError(VQF_E_TIMEOUT) if the last persistent LSTM launch on the current
+    stream gave up on a hand-off (its outputs were poisoned with NaN)."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    b = _lstm_ws.get((device, torch.cuda.current_stream(device).cuda_stream))
+    if b is not None:
+        _l.check(_lib().vqf_lstm_persist_status(_ptr(b), _stream()), "vqf_lstm_persist_status")
+
+
 # ---------------------------------------------------------------------------
 # input staging (data_loader.py:30-32)
 def feat_transpose(src, out=None, bf16=False):
