@@ -235,17 +235,20 @@ int vqf_softmax_rows_bwd(const float* dy, const float* y, int R, int W, float* d
  * mhb_coAtt.py:27-36,72-74 recurs over the minibatch axis (S = N steps of a T-row batch).
  * Single layer, zero initial state, PyTorch gate order i,f,g,o.  One kernel launch per step.
  *   xw     (S,B,4H)  x W_ih^T + b_ih + b_hh   (computed with vqf_gemm_f32)
- *   w_hh   (4H,H)    lstm.weight_hh_l0;   w_hh_t (H,4H) its transpose (backward)
+ *   w_hh   (4H,H)    lstm.weight_hh_l0 (both directions take it as stored; each call packs the
+ *                    operand image it needs into ws)
  *   hs, cs (S,B,H)   hidden / cell states;  gates (S,B,4H) ACTIVATED i,f,g,o (saved for backward)
  *   dhs    (S,B,H)   dL/dh_s from the consumers;  dgates (S,B,4H) dL/d(pre-activation): then
  *                    dW_hh = dgates[1:]^T hs[:-1], dW_ih = dgates^T x, db = colsum(dgates), dx = dgates W_ih
- *   dc_carry (B,H)   scratch
+ *   dc_carry (B,H)   scratch;  ws: vqf_lstm_seq_ws_bytes(B,H) bytes of scratch (16-byte aligned)
  * Supported: B <= 32, H in {256,512,768,1024} (vqf_lstm_seq_supported); else VQF_E_UNSUPPORTED. */
 int vqf_lstm_seq_supported(int B, int H);
+size_t vqf_lstm_seq_ws_bytes(int B, int H);
 int vqf_lstm_seq_fwd(const float* xw, const float* w_hh, int S, int B, int H,
-                     float* hs, float* cs, float* gates, void* stream);
-int vqf_lstm_seq_bwd(const float* dhs, const float* gates, const float* cs, const float* w_hh_t,
-                     int S, int B, int H, float* dgates, float* dc_carry, void* stream);
+                     float* hs, float* cs, float* gates, void* ws, size_t ws_bytes, void* stream);
+int vqf_lstm_seq_bwd(const float* dhs, const float* gates, const float* cs, const float* w_hh,
+                     int S, int B, int H, float* dgates, float* dc_carry, void* ws, size_t ws_bytes,
+                     void* stream);
 
 /* The same recursion as ONE launch for the whole sequence (csrc/lstm_persist.hip): W_hh stays in
  * registers, the H/4 workgroups hand the recurrent state to each other through HBM with

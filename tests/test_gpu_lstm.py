@@ -104,7 +104,7 @@ def test_persistent_sequence_equals_per_step_kernels(S, B, H):
     hs1, cs1, g1 = ops.lstm_seq_fwd_persist(xw, w_hh)
     ops.lstm_persist_status()
     assert torch.equal(hs0, hs1) and torch.equal(cs0, cs1) and torch.equal(g0, g1)
-    d0 = ops.lstm_seq_bwd(dhs, g0, cs0, w_hh.t().contiguous())
+    d0 = ops.lstm_seq_bwd(dhs, g0, cs0, w_hh)
     d1 = ops.lstm_seq_bwd_persist(dhs, g0, cs0, w_hh)
     ops.lstm_persist_status()
     assert _rel(d1, d0) <= 2e-5
@@ -121,7 +121,7 @@ def test_persistent_sequence_under_concurrent_load():
     S, B, H = 512, 14, 1024
     xw, w_hh, dhs = _seq_inputs(S, B, H, 7)
     hs0, cs0, g0 = ops.lstm_seq_fwd(xw, w_hh)
-    d0 = ops.lstm_seq_bwd(dhs, g0, cs0, w_hh.t().contiguous())
+    d0 = ops.lstm_seq_bwd(dhs, g0, cs0, w_hh)
     a = torch.randn(8192, 2048, device="cuda")
     b = torch.randn(5000, 2048, device="cuda")
     side = torch.cuda.Stream()

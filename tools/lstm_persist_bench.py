@@ -25,7 +25,7 @@ def timed(fn, n=5):
 hs, cs, gt = ops.lstm_seq_fwd(xw, w_hh)
 for name, f in (("fwd per-step", lambda: ops.lstm_seq_fwd(xw, w_hh)),
                 ("fwd persist ", lambda: ops.lstm_seq_fwd_persist(xw, w_hh)),
-                ("bwd per-step", lambda: ops.lstm_seq_bwd(dhs, gt, cs, w_t)),
+                ("bwd per-step", lambda: ops.lstm_seq_bwd(dhs, gt, cs, w_hh)),
                 ("bwd persist ", lambda: ops.lstm_seq_bwd_persist(dhs, gt, cs, w_hh))):
     ms = timed(f)
     print("%s  %.3f ms  = %.2f us/step" % (name, ms, ms * 1e3 / S), flush=True)

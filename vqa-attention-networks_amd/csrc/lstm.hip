@@ -12,13 +12,25 @@
 // A workgroup owns 4 hidden units = 16 gate columns = one 16x16 MFMA tile (256 workgroups at
 // H = 1024, one per CU); its waves split the reduction dimension and v_mfma_f32_16x16x4_f32 does
 // the cross-lane sums (a VALU + shuffle formulation measured 21-28 us per step, of which most was
-// the 340-shuffle reduction tree per wave).  Forward: every lane first issues ALL its W_hh loads and
-// reads its h_{s-1} fragments (B x H fp32, 57 KB at B=14, shared by all workgroups) straight from L2
-// (staging them in LDS measured 10.6 instead of 8.9 us per step).  Backward: dG_{s+1}
-// (B x 4H) and the W_hh^T rows are read straight from L2.  W_hh (16 MB) stays resident in the
-// Infinity Cache across the 512 steps.  The input
-// projection xw = x W_ih^T + b_ih + b_hh and all weight gradients (dW_ih, dW_hh, dx) are plain
-// GEMMs over the whole sequence and use vqf_gemm_f32.
+// the 340-shuffle reduction tree per wave).
+//
+// A step is a chain of L2 round trips, so the operands are kept in FRAGMENT-MAJOR layouts: the 16
+// bytes lane l needs for chunk c of an operand sit at ((c * 64) + l) * 16, i.e. every wave-wide load
+// is one contiguous 1 KB read of 8 whole cache lines instead of 16 half lines from 16 rows
+// (7.8 -> 6.0 us per forward step, 13.5 -> 9.9 us per backward step):
+//   Wf  [q][kc][lane][4]   forward  B operand of workgroup q: W_hh[gate*H + 4q + u][16kc + 4g + e],
+//                          lane = 16g + (gate*4 + u)          (packed once per sequence)
+//   Wb  [q][jc][g][u][4]   backward B operand: W_hh[16jc + 4g + e][4q + u]   (tile columns 4..15 are 0)
+//   hf  [half][kc][lane][4]   h_s  as the next step's A operand: h[16 half + r][16kc + 4g + e], lane = 16g + r
+//   dgf [half][jc][lane][4]   dG_s as the previous step's A operand
+// hf / dgf are written by the point-wise tail of each step next to the regular (S,B,.) outputs
+// (double-buffered, rows >= B stay zero).  The input projection xw = x W_ih^T + b_ih + b_hh and all
+// weight gradients (dW_ih, dW_hh, dx) are plain GEMMs over the whole sequence (vqf_gemm_f32).
+// Other forms that were measured: h_{s-1} staged in LDS (10.6 us per forward step), operands read
+// in their natural row-major layouts (7.8 / 13.5 us), a v_mfma_f32_4x4x1_16B_f32 backward that wastes
+// no tile columns (17.0 us: the step is bound by its load chain, not by the 3.4 us of MFMAs), 8 or 16
+// hidden units per workgroup in the backward (14.5 / 17.1 us), and a whole-sequence persistent
+// kernel (lstm_persist.hip).
 // PyTorch gate order i,f,g,o; zero initial state (mfb.py:69, mhb_coAtt.py:72-74 pass no hx).
 // Constraints: B <= 32, H in {256, 512, 768, 1024} (else VQF_E_UNSUPPORTED: the caller keeps nn.LSTM).
 #include "common.h"
@@ -27,117 +39,124 @@ namespace {
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-#ifndef VQF_LSTM_DIRECT
-#define VQF_LSTM_DIRECT 1
-#endif
 constexpr int UPB = 4;           // hidden units per workgroup = 16 gate columns = one MFMA 16x16 tile
 constexpr int FWD_WAVES = 4;     // forward: K = H split over 4 waves
 constexpr int BWD_WAVES = 8;     // backward: K = 4H split over 8 waves
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// One step is a (B <= 16) x K x 16 product; v_mfma_f32_16x16x4_f32 does the cross-lane reduction
-// that a VALU formulation needs ~340 shuffles per wave for.  Operand maps (guide section 3):
+// ---- one-time packing of W_hh into the two fragment-major images ---------------------------------
+__global__ void pack_w_fwd_kernel(const float* __restrict__ w_hh, int H, float* __restrict__ wf) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;    // float4 index
+  const int KC = H / 16;
+  if (i >= (long long)(H / UPB) * KC * 64) return;
+  const int lane = (int)(i & 63), kc = (int)((i >> 6) % KC), q = (int)((i >> 6) / KC);
+  const int r = lane & 15, g = lane >> 4;
+  const float* src = w_hh + (long long)((r >> 2) * H + q * UPB + (r & 3)) * H + 16 * kc + 4 * g;
+  reinterpret_cast<f32x4*>(wf)[i] = *reinterpret_cast<const f32x4*>(src);
+}
+__global__ void pack_w_bwd_kernel(const float* __restrict__ w_hh, int H, float* __restrict__ wb) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;    // float4 index
+  const int JC = 4 * H / 16;
+  if (i >= (long long)(H / UPB) * JC * 16) return;
+  const int u = (int)(i & 3), g = (int)((i >> 2) & 3), jc = (int)((i >> 4) % JC), q = (int)((i >> 4) / JC);
+  const float* src = w_hh + (long long)(16 * jc + 4 * g) * H + q * UPB + u;
+  f32x4 v = {src[0], src[H], src[2 * H], src[3 * H]};
+  reinterpret_cast<f32x4*>(wb)[i] = v;
+}
+
+// offset (floats) of element (b, k) inside a fragment-major A image with KC chunks of 16 per row
+__device__ __forceinline__ long long frag_off(int b, int k, int KC) {
+  return (((long long)(b >> 4) * KC + (k >> 4)) * 64 + ((k & 15) >> 2) * 16 + (b & 15)) * 4 + (k & 3);
+}
+
+// One step is a (B <= 16 per half) x K x 16 product.  Operand maps of v_mfma_f32_16x16x4_f32:
 //   A[i = lane & 15][k = lane >> 4],  B[k = lane >> 4][j = lane & 15],
 //   D: col = lane & 15, row = 4 * (lane >> 4) + reg.
-// Lane (r, g) loads a float4 of 4 consecutive k at k0 + 4g for row r of each operand; MFMA number jj
-// of that chunk consumes element jj of both (same k on both sides).
-//
-// forward: A = h_{s-1} (rows b), B = W_hh rows of this workgroup's 16 gate columns n = gate*4 + u.
+// Lane (r, g) holds 4 consecutive k (k0 + 4g .. +3) of row r of each operand per 16-wide chunk; MFMA
+// number e of that chunk consumes element e of both (same k on both sides).
 template <int KI>
 __global__ void __launch_bounds__(64 * FWD_WAVES)
-lstm_step_fwd_kernel(const float* __restrict__ xw_s, const float* __restrict__ w_hh,
-                     const float* __restrict__ h_prev, const float* __restrict__ c_prev, int B,
+lstm_step_fwd_kernel(const float* __restrict__ xw_s, const float* __restrict__ wf,
+                     const float* __restrict__ hf_prev, const float* __restrict__ c_prev, int B,
                      float* __restrict__ h_out, float* __restrict__ c_out,
-                     float* __restrict__ gates_out) {
-  constexpr int H = 256 * KI, KW = H / FWD_WAVES, NC = KW / 16;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-#if VQF_LSTM_DIRECT
-  float* part = smem;                        // [FWD_WAVES][2][16][16]   (two 16-row batch halves)
-#else
-  float* hbuf = smem;                        // [B][H]
-  float* part = smem + 32 * H;               // [FWD_WAVES][2][16][16]   (two 16-row batch halves)
-#endif
+                     float* __restrict__ gates_out, float* __restrict__ hf_out) {
+  constexpr int H = 256 * KI, KC = H / 16, NC = KC / FWD_WAVES;
+  __shared__ float part[FWD_WAVES][2][16][16];       // [wave][half][b][n = gate*4 + u]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, g = lane >> 4;
   const int u0 = blockIdx.x * UPB;
   const int nh = (B + 15) >> 4;              // batch halves (1 or 2)
 
-  if (h_prev) {
+  // the (b,u) owner threads fetch their point-wise operands first: xw streams from HBM (~2 us), and
+  // that latency hides behind the operand loads and the MFMA chain instead of following them
+  const bool own = tid < B * UPB;
+  const int ob = tid / UPB, ou = tid % UPB, ocol = u0 + ou;
+  float xq[4] = {0.f, 0.f, 0.f, 0.f}, cpq = 0.f;
+  if (own) {
+    const float* x = xw_s + (long long)ob * 4 * H + ocol;
+    xq[0] = x[0]; xq[1] = x[H]; xq[2] = x[2 * H]; xq[3] = x[3 * H];
+    if (c_prev) cpq = c_prev[(long long)ob * H + ocol];
+  }
+
+  if (hf_prev) {
     f32x4 wv[NC];
-    const float* wr = w_hh + (long long)((r >> 2) * H + u0 + (r & 3)) * H + wave * KW + 4 * g;
+    const float* wp = wf + (((long long)blockIdx.x * KC + wave * NC) * 64 + lane) * 4;
 #pragma unroll
-    for (int c = 0; c < NC; ++c) wv[c] = *reinterpret_cast<const f32x4*>(wr + 16 * c);
-#if !VQF_LSTM_DIRECT
-    for (int i = tid * 4; i < B * H; i += 64 * FWD_WAVES * 4)
-      *reinterpret_cast<f32x4*>(hbuf + i) = *reinterpret_cast<const f32x4*>(h_prev + i);
-    __syncthreads();
-#endif
+    for (int c = 0; c < NC; ++c) wv[c] = *reinterpret_cast<const f32x4*>(wp + 256 * c);
     for (int hb = 0; hb < nh; ++hb) {
-      const int b = hb * 16 + r;
-#if VQF_LSTM_DIRECT
-      // A fragments straight from L2 (h_{s-1} is 56 KB, shared by all workgroups): no LDS staging, so the
-      // kernel needs 4 KB of LDS and can share a CU with the image-projection GEMM of the side stream
-      const float* hr = h_prev + (long long)(b < B ? b : 0) * H + wave * KW + 4 * g;
-#else
-      const float* hr = hbuf + (b < B ? b : 0) * H + wave * KW + 4 * g;
-#endif
-      const float keep = b < B ? 1.f : 0.f;
+      const float* hp = hf_prev + (((long long)hb * KC + wave * NC) * 64 + lane) * 4;
       f32x4 hv[NC];
 #pragma unroll
-      for (int c = 0; c < NC; ++c) hv[c] = *reinterpret_cast<const f32x4*>(hr + 16 * c);
+      for (int c = 0; c < NC; ++c) hv[c] = *reinterpret_cast<const f32x4*>(hp + 256 * c);
+      __builtin_amdgcn_sched_barrier(0);     // all loads in flight before the first MFMA
       f32x4v acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
 #pragma unroll
       for (int c = 0; c < NC; c += 2) {
-        const f32x4 h0 = hv[c] * keep, h1 = hv[c + 1] * keep;
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(h0[jj], wv[c][jj], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(h1[jj], wv[c + 1][jj], acc1, 0, 0, 0);
+        for (int e = 0; e < 4; ++e) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[c][e], wv[c][e], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[c + 1][e], wv[c + 1][e], acc1, 0, 0, 0);
         }
       }
-      float* pw = part + ((wave * 2 + hb) * 16) * 16;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) pw[(4 * g + q) * 16 + r] = acc0[q] + acc1[q];     // D[b = 4g+q][n = r]
+      for (int q = 0; q < 4; ++q) part[wave][hb][4 * g + q][r] = acc0[q] + acc1[q];     // D[b = 4g+q][n = r]
     }
   }
   __syncthreads();
-  if (tid < B * UPB) {
-    const int b = tid / UPB, u = tid % UPB, col = u0 + u;
+  if (own) {
     float pre[4] = {0.f, 0.f, 0.f, 0.f};
-    if (h_prev) {
+    if (hf_prev) {
 #pragma unroll
-      for (int w = 0; w < FWD_WAVES; ++w) {
-        const float* pw = part + ((w * 2 + (b >> 4)) * 16 + (b & 15)) * 16 + u;
+      for (int w = 0; w < FWD_WAVES; ++w)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) pre[k] += pw[4 * k];
-      }
+        for (int k = 0; k < 4; ++k) pre[k] += part[w][ob >> 4][ob & 15][4 * k + ou];
     }
-    const float* x = xw_s + (long long)b * 4 * H + col;
-    const float gi = sigmoidf_(pre[0] + x[0]);
-    const float gf = sigmoidf_(pre[1] + x[H]);
-    const float gg = tanhf(pre[2] + x[2 * H]);
-    const float go = sigmoidf_(pre[3] + x[3 * H]);
-    const float cp = c_prev ? c_prev[(long long)b * H + col] : 0.f;
-    const float c = gf * cp + gi * gg;
+    const float gi = sigmoidf_(pre[0] + xq[0]);
+    const float gf = sigmoidf_(pre[1] + xq[1]);
+    const float gg = tanhf(pre[2] + xq[2]);
+    const float go = sigmoidf_(pre[3] + xq[3]);
+    const float c = gf * cpq + gi * gg;
     const float h = go * tanhf(c);
-    h_out[(long long)b * H + col] = h;
-    c_out[(long long)b * H + col] = c;
-    float* gt = gates_out + (long long)b * 4 * H + col;
+    h_out[(long long)ob * H + ocol] = h;
+    hf_out[frag_off(ob, ocol, KC)] = h;
+    c_out[(long long)ob * H + ocol] = c;
+    float* gt = gates_out + (long long)ob * 4 * H + ocol;
     gt[0] = gi; gt[H] = gf; gt[2 * H] = gg; gt[3 * H] = go;
   }
 }
 
-// backward step s: dh_carry[b][u] = sum_j dG_{s+1}[b][j] W_hh[j][u] -> A = dG_{s+1} (rows b, read
-// straight from L2), B = rows u0..u0+3 of W_hh^T (columns 4..15 of the tile are zero).
+// backward step s: dh_carry[b][u] = sum_j dG_{s+1}[b][j] W_hh[j][u] -> A = dG_{s+1} (rows b),
+// B = rows u0..u0+3 of W_hh^T (columns 4..15 of the tile are zero: lanes r >= 4 load nothing).
 template <int KI>
 __global__ void __launch_bounds__(64 * BWD_WAVES)
-lstm_step_bwd_kernel(const float* __restrict__ dhs_s, const float* __restrict__ dg_next,
-                     const float* __restrict__ w_hh_t, const float* __restrict__ gates_s,
+lstm_step_bwd_kernel(const float* __restrict__ dhs_s, const float* __restrict__ dgf_next,
+                     const float* __restrict__ wb, const float* __restrict__ gates_s,
                      const float* __restrict__ c_s, const float* __restrict__ c_prev,
-                     float* __restrict__ dc_carry, int B, float* __restrict__ dg_s) {
-  constexpr int H = 256 * KI, H4 = 4 * H, JW = H4 / BWD_WAVES, NC = JW / 16, CG = 8;   // CG chunks per group
+                     float* __restrict__ dc_carry, int B, float* __restrict__ dg_s,
+                     float* __restrict__ dgf_out) {
+  constexpr int H = 256 * KI, H4 = 4 * H, JC = H4 / 16, NC = JC / BWD_WAVES, CG = NC < 8 ? NC : 8;
   __shared__ float part[BWD_WAVES][2][16][UPB];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -145,32 +164,39 @@ lstm_step_bwd_kernel(const float* __restrict__ dhs_s, const float* __restrict__ 
   const int u0 = blockIdx.x * UPB;
   const int nh = (B + 15) >> 4;
 
-  if (dg_next) {
+  const bool own = tid < B * UPB;            // point-wise operands first (see the forward kernel)
+  const int ob = tid / UPB, ou = tid % UPB, ocol = u0 + ou;
+  const long long obh = (long long)ob * H + ocol;
+  float q_dh = 0.f, q_gi = 0.f, q_gf = 0.f, q_gg = 0.f, q_go = 0.f, q_c = 0.f, q_cp = 0.f, q_dc = 0.f;
+  if (own) {
+    q_dh = dhs_s[obh];
+    const float* gt = gates_s + (long long)ob * H4 + ocol;
+    q_gi = gt[0]; q_gf = gt[H]; q_gg = gt[2 * H]; q_go = gt[3 * H];
+    q_c = c_s[obh];
+    q_cp = c_prev ? c_prev[obh] : 0.f;
+    q_dc = dc_carry[obh];
+  }
+
+  if (dgf_next) {
     const bool wok = r < UPB;
-    const float* wr = w_hh_t + (long long)(u0 + (wok ? r : 0)) * H4 + wave * JW + 4 * g;
+    const float* wp = wb + (((long long)blockIdx.x * JC + wave * NC) * 16 + g * 4 + (wok ? r : 0)) * 4;
     for (int hb = 0; hb < nh; ++hb) {
-      const int b = hb * 16 + r;
-      const bool aok = b < B;
-      const float* ar = dg_next + (long long)(aok ? b : 0) * H4 + wave * JW + 4 * g;
+      const float* ap = dgf_next + (((long long)hb * JC + wave * NC) * 64 + lane) * 4;
       f32x4v acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
       for (int c0 = 0; c0 < NC; c0 += CG) {
         f32x4 av[CG], wv[CG];
 #pragma unroll
         for (int c = 0; c < CG; ++c) {
-          av[c] = *reinterpret_cast<const f32x4*>(ar + 16 * (c0 + c));
-          wv[c] = *reinterpret_cast<const f32x4*>(wr + 16 * (c0 + c));
+          av[c] = *reinterpret_cast<const f32x4*>(ap + 256 * (c0 + c));
+          wv[c] = wok ? *reinterpret_cast<const f32x4*>(wp + 64 * (c0 + c)) : f32x4{0, 0, 0, 0};
         }
-#pragma unroll
-        for (int c = 0; c < CG; ++c) {
-          if (!aok) av[c] = f32x4{0, 0, 0, 0};
-          if (!wok) wv[c] = f32x4{0, 0, 0, 0};
-        }
+        __builtin_amdgcn_sched_barrier(0);   // the whole group of loads in flight before the first MFMA
 #pragma unroll
         for (int c = 0; c < CG; c += 2)
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][jj], wv[c][jj], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c + 1][jj], wv[c + 1][jj], acc1, 0, 0, 0);
+          for (int e = 0; e < 4; ++e) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][e], wv[c][e], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c + 1][e], wv[c + 1][e], acc1, 0, 0, 0);
           }
       }
       if (r < UPB) {
@@ -180,74 +206,78 @@ lstm_step_bwd_kernel(const float* __restrict__ dhs_s, const float* __restrict__ 
     }
   }
   __syncthreads();
-  if (tid < B * UPB) {
-    const int b = tid / UPB, u = tid % UPB, col = u0 + u;
-    const long long bh = (long long)b * H + col;
+  if (own) {
     float dhc = 0.f;
-    if (dg_next) {
+    if (dgf_next) {
 #pragma unroll
-      for (int w = 0; w < BWD_WAVES; ++w) dhc += part[w][b >> 4][b & 15][u];
+      for (int w = 0; w < BWD_WAVES; ++w) dhc += part[w][ob >> 4][ob & 15][ou];
     }
-    const float dh = dhs_s[bh] + dhc;
-    const float* gt = gates_s + (long long)b * H4 + col;
-    const float gi = gt[0], gf = gt[H], gg = gt[2 * H], go = gt[3 * H];
-    const float tc = tanhf(c_s[bh]);
-    const float cp = c_prev ? c_prev[bh] : 0.f;
-    const float dc = dc_carry[bh] + dh * go * (1.0f - tc * tc);
-    float* d = dg_s + (long long)b * H4 + col;
-    d[0] = dc * gg * gi * (1.0f - gi);
-    d[H] = dc * cp * gf * (1.0f - gf);
-    d[2 * H] = dc * gi * (1.0f - gg * gg);
-    d[3 * H] = dh * tc * go * (1.0f - go);
-    dc_carry[bh] = dc * gf;
+    const float dh = q_dh + dhc;
+    const float gi = q_gi, gf = q_gf, gg = q_gg, go = q_go;
+    const float tc = tanhf(q_c);
+    const float dc = q_dc + dh * go * (1.0f - tc * tc);
+    const float d0 = dc * gg * gi * (1.0f - gi);
+    const float d1 = dc * q_cp * gf * (1.0f - gf);
+    const float d2 = dc * gi * (1.0f - gg * gg);
+    const float d3 = dh * tc * go * (1.0f - go);
+    float* d = dg_s + (long long)ob * H4 + ocol;
+    d[0] = d0; d[H] = d1; d[2 * H] = d2; d[3 * H] = d3;
+    dgf_out[frag_off(ob, ocol, JC)] = d0;
+    dgf_out[frag_off(ob, H + ocol, JC)] = d1;
+    dgf_out[frag_off(ob, 2 * H + ocol, JC)] = d2;
+    dgf_out[frag_off(ob, 3 * H + ocol, JC)] = d3;
+    dc_carry[obh] = dc * gf;
   }
 }
 
-template <typename K>
-int set_smem(K kern, size_t bytes) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-  return e == hipSuccess ? VQF_OK : (int)e;
-}
+// workspace: [ packed W_hh : 4H*H floats ][ fragment image 0 ][ fragment image 1 ]
+size_t frag_floats(int H, bool bwd) { return (size_t)2 * ((bwd ? 4 * H : H) / 16) * 64 * 4; }   // 2 batch halves
+size_t ws_need(int H, bool bwd) { return ((size_t)4 * H * H + 2 * frag_floats(H, bwd)) * sizeof(float); }
 
 template <int KI>
 int run_fwd(const float* xw, const float* w_hh, int S, int B, float* hs, float* cs, float* gates,
-            hipStream_t s) {
+            float* ws, hipStream_t s) {
   constexpr int H = 256 * KI;
-#if VQF_LSTM_DIRECT
-  const size_t smem = (size_t)FWD_WAVES * 2 * 256 * sizeof(float);
-#else
-  const size_t smem = ((size_t)32 * H + (size_t)FWD_WAVES * 2 * 256) * sizeof(float);
-#endif
-  int rc = set_smem(lstm_step_fwd_kernel<KI>, smem);
-  if (rc) return rc;
+  float* wf = ws;
+  float* hf[2] = {ws + (size_t)4 * H * H, ws + (size_t)4 * H * H + frag_floats(H, false)};
+  hipError_t e = hipMemsetAsync(hf[0], 0, 2 * frag_floats(H, false) * sizeof(float), s);   // rows >= B stay 0
+  if (e != hipSuccess) return (int)e;
   const long long bh = (long long)B * H;
   dim3 grid(H / UPB);
   (void)hipGetLastError();
   if (g_vqf_prof_on) { vqf_prof_dims(S, B, H); vqf_prof_begin(KID_LSTM_FWD, s); }   // one bracket per sequence
+  const long long n4 = (long long)(H / UPB) * (H / 16) * 64;
+  hipLaunchKernelGGL(pack_w_fwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, w_hh, H, wf);
   for (int t = 0; t < S; ++t) {
-    const float* hp = t ? hs + (t - 1) * bh : nullptr;
+    const float* hp = t ? hf[(t - 1) & 1] : nullptr;
     const float* cp = t ? cs + (t - 1) * bh : nullptr;
-    hipLaunchKernelGGL(lstm_step_fwd_kernel<KI>, grid, dim3(64 * FWD_WAVES), smem, s, xw + t * 4 * bh, w_hh, hp, cp, B,
-                       hs + t * bh, cs + t * bh, gates + t * 4 * bh);
+    hipLaunchKernelGGL(lstm_step_fwd_kernel<KI>, grid, dim3(64 * FWD_WAVES), 0, s, xw + t * 4 * bh,
+                       (const float*)wf, hp, cp, B, hs + t * bh, cs + t * bh, gates + t * 4 * bh, hf[t & 1]);
   }
   if (g_vqf_prof_on) vqf_prof_end(KID_LSTM_FWD, s);
   return vqf_last_error();
 }
 
 template <int KI>
-int run_bwd(const float* dhs, const float* gates, const float* cs, const float* w_hh_t, int S, int B,
-            float* dgates, float* dc_carry, hipStream_t s) {
+int run_bwd(const float* dhs, const float* gates, const float* cs, const float* w_hh, int S, int B,
+            float* dgates, float* dc_carry, float* ws, hipStream_t s) {
   constexpr int H = 256 * KI;
+  float* wb = ws;
+  float* gf[2] = {ws + (size_t)4 * H * H, ws + (size_t)4 * H * H + frag_floats(H, true)};
+  hipError_t e = hipMemsetAsync(gf[0], 0, 2 * frag_floats(H, true) * sizeof(float), s);
+  if (e != hipSuccess) return (int)e;
   const long long bh = (long long)B * H;
   dim3 grid(H / UPB);
   (void)hipGetLastError();
   if (g_vqf_prof_on) { vqf_prof_dims(S, B, H); vqf_prof_begin(KID_LSTM_BWD, s); }
+  const long long n4 = (long long)(H / UPB) * (4 * H / 16) * 16;
+  hipLaunchKernelGGL(pack_w_bwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, w_hh, H, wb);
   for (int t = S - 1; t >= 0; --t) {
-    const float* dgn = (t + 1 < S) ? dgates + (long long)(t + 1) * 4 * bh : nullptr;
+    const float* dgn = (t + 1 < S) ? gf[(t + 1) & 1] : nullptr;
     const float* cp = t ? cs + (t - 1) * bh : nullptr;
-    hipLaunchKernelGGL(lstm_step_bwd_kernel<KI>, grid, dim3(64 * BWD_WAVES), 0, s, dhs + t * bh, dgn, w_hh_t,
-                       gates + t * 4 * bh, cs + t * bh, cp, dc_carry, B, dgates + t * 4 * bh);
+    hipLaunchKernelGGL(lstm_step_bwd_kernel<KI>, grid, dim3(64 * BWD_WAVES), 0, s, dhs + t * bh, dgn,
+                       (const float*)wb, gates + t * 4 * bh, cs + t * bh, cp, dc_carry, B, dgates + t * 4 * bh,
+                       gf[t & 1]);
   }
   if (g_vqf_prof_on) vqf_prof_end(KID_LSTM_BWD, s);
   return vqf_last_error();
@@ -261,33 +291,39 @@ int vqf_lstm_seq_supported(int B, int H) {
   return (B >= 1 && B <= 32 && (H == 256 || H == 512 || H == 768 || H == 1024)) ? 1 : 0;
 }
 
+size_t vqf_lstm_seq_ws_bytes(int B, int H) {
+  return vqf_lstm_seq_supported(B, H) ? ws_need(H, true) : 0;
+}
+
 int vqf_lstm_seq_fwd(const float* xw, const float* w_hh, int S, int B, int H, float* hs, float* cs,
-                     float* gates, void* stream) {
-  if (!xw || !w_hh || !hs || !cs || !gates || S <= 0) return VQF_E_BADARG;
+                     float* gates, void* ws, size_t ws_bytes, void* stream) {
+  if (!xw || !w_hh || !hs || !cs || !gates || !ws || S <= 0) return VQF_E_BADARG;
   if (!vqf_lstm_seq_supported(B, H)) return VQF_E_UNSUPPORTED;
-  if (!aligned16(xw) || !aligned16(w_hh) || !aligned16(hs)) return VQF_E_ALIGN;
+  if (!aligned16(xw) || !aligned16(w_hh) || !aligned16(hs) || !aligned16(ws)) return VQF_E_ALIGN;
+  if (ws_bytes < ws_need(H, false)) return VQF_E_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   switch (H / 256) {
-    case 1: return run_fwd<1>(xw, w_hh, S, B, hs, cs, gates, s);
-    case 2: return run_fwd<2>(xw, w_hh, S, B, hs, cs, gates, s);
-    case 3: return run_fwd<3>(xw, w_hh, S, B, hs, cs, gates, s);
-    default: return run_fwd<4>(xw, w_hh, S, B, hs, cs, gates, s);
+    case 1: return run_fwd<1>(xw, w_hh, S, B, hs, cs, gates, (float*)ws, s);
+    case 2: return run_fwd<2>(xw, w_hh, S, B, hs, cs, gates, (float*)ws, s);
+    case 3: return run_fwd<3>(xw, w_hh, S, B, hs, cs, gates, (float*)ws, s);
+    default: return run_fwd<4>(xw, w_hh, S, B, hs, cs, gates, (float*)ws, s);
   }
 }
 
-int vqf_lstm_seq_bwd(const float* dhs, const float* gates, const float* cs, const float* w_hh_t, int S,
-                     int B, int H, float* dgates, float* dc_carry, void* stream) {
-  if (!dhs || !gates || !cs || !w_hh_t || !dgates || !dc_carry || S <= 0) return VQF_E_BADARG;
+int vqf_lstm_seq_bwd(const float* dhs, const float* gates, const float* cs, const float* w_hh, int S,
+                     int B, int H, float* dgates, float* dc_carry, void* ws, size_t ws_bytes, void* stream) {
+  if (!dhs || !gates || !cs || !w_hh || !dgates || !dc_carry || !ws || S <= 0) return VQF_E_BADARG;
   if (!vqf_lstm_seq_supported(B, H)) return VQF_E_UNSUPPORTED;
-  if (!aligned16(dgates) || !aligned16(w_hh_t)) return VQF_E_ALIGN;
+  if (!aligned16(dgates) || !aligned16(w_hh) || !aligned16(ws)) return VQF_E_ALIGN;
+  if (ws_bytes < ws_need(H, true)) return VQF_E_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(dc_carry, 0, (size_t)B * H * sizeof(float), s);
   if (e != hipSuccess) return (int)e;
   switch (H / 256) {
-    case 1: return run_bwd<1>(dhs, gates, cs, w_hh_t, S, B, dgates, dc_carry, s);
-    case 2: return run_bwd<2>(dhs, gates, cs, w_hh_t, S, B, dgates, dc_carry, s);
-    case 3: return run_bwd<3>(dhs, gates, cs, w_hh_t, S, B, dgates, dc_carry, s);
-    default: return run_bwd<4>(dhs, gates, cs, w_hh_t, S, B, dgates, dc_carry, s);
+    case 1: return run_bwd<1>(dhs, gates, cs, w_hh, S, B, dgates, dc_carry, (float*)ws, s);
+    case 2: return run_bwd<2>(dhs, gates, cs, w_hh, S, B, dgates, dc_carry, (float*)ws, s);
+    case 3: return run_bwd<3>(dhs, gates, cs, w_hh, S, B, dgates, dc_carry, (float*)ws, s);
+    default: return run_bwd<4>(dhs, gates, cs, w_hh, S, B, dgates, dc_carry, (float*)ws, s);
   }
 }
 

@@ -385,7 +385,7 @@ class LstmSeqFn(torch.autograd.Function):
         if ctx.persist_bwd:
             dg = ops.lstm_seq_bwd_persist(_c(dhs), gates, cs, _c(w_hh))            # (S,B,4H)
         else:
-            dg = ops.lstm_seq_bwd(_c(dhs), gates, cs, w_hh.t().contiguous())
+            dg = ops.lstm_seq_bwd(_c(dhs), gates, cs, _c(w_hh))
         dg2 = dg.view(S * B, 4 * H)
         dx = ops.gemm(dg2, _c(w_ih), tb=True).view(S, B, I) if ctx.needs_input_grad[0] else None
         dw_ih = ops.gemm(dg2, x.view(S * B, I), ta=True, tb=True)

@@ -60,8 +60,9 @@ SIGNATURES = {
     "vqf_mfb_fuse_bwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_u64, ctypes.c_float,
                                c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_p, c_sz, c_p]),
     "vqf_lstm_seq_supported": (c_i, [c_i, c_i]),
-    "vqf_lstm_seq_fwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_p]),
-    "vqf_lstm_seq_bwd": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_p]),
+    "vqf_lstm_seq_ws_bytes": (c_sz, [c_i, c_i]),
+    "vqf_lstm_seq_fwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_p, c_sz, c_p]),
+    "vqf_lstm_seq_bwd": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_p, c_sz, c_p]),
     "vqf_lstm_persist_supported": (c_i, [c_i, c_i]),
     "vqf_lstm_persist_ws_bytes": (c_sz, [c_i, c_i, c_i]),
     "vqf_lstm_seq_fwd_persist": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_p, c_sz, c_p]),

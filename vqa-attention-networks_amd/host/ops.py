@@ -334,26 +334,34 @@ def lstm_seq_supported(B, H):
     return bool(_lib().vqf_lstm_seq_supported(int(B), int(H)))
 
 
+def _lstm_seq_ws(B, H, device):
+    nbytes = int(_lib().vqf_lstm_seq_ws_bytes(int(B), int(H)))
+    return workspace(device, nbytes), nbytes
+
+
 def lstm_seq_fwd(xw, w_hh):
-    """xw (S,B,4H), w_hh (4H,H) -> hs, cs (S,B,H), gates (S,B,4H)."""
+    """xw (S,B,4H) = x W_ih^T + biases, w_hh (4H,H) -> hs (S,B,H), cs (S,B,H), gates (S,B,4H) activated."""
     _chk(xw, w_hh)
     S, B, H4 = xw.shape
     H = H4 // 4
     hs = torch.empty((S, B, H), dtype=torch.float32, device=xw.device)
     cs = torch.empty_like(hs)
     gates = torch.empty_like(xw)
-    _l.check(_lib().vqf_lstm_seq_fwd(_ptr(xw), _ptr(w_hh), S, B, H, _ptr(hs), _ptr(cs), _ptr(gates), _stream()),
-             "vqf_lstm_seq_fwd")
+    ws, nb = _lstm_seq_ws(B, H, xw.device)
+    _l.check(_lib().vqf_lstm_seq_fwd(_ptr(xw), _ptr(w_hh), S, B, H, _ptr(hs), _ptr(cs), _ptr(gates), _ptr(ws), nb,
+                                     _stream()), "vqf_lstm_seq_fwd")
     return hs, cs, gates
 
 
-def lstm_seq_bwd(dhs, gates, cs, w_hh_t):
-    _chk(dhs, gates, cs, w_hh_t)
+def lstm_seq_bwd(dhs, gates, cs, w_hh):
+    """-> dgates (S,B,4H): gradient w.r.t. the gate pre-activations; w_hh (4H,H) as stored."""
+    _chk(dhs, gates, cs, w_hh)
     S, B, H = dhs.shape
     dgates = torch.empty_like(gates)
     carry = torch.empty((B, H), dtype=torch.float32, device=dhs.device)
-    _l.check(_lib().vqf_lstm_seq_bwd(_ptr(dhs), _ptr(gates), _ptr(cs), _ptr(w_hh_t), S, B, H, _ptr(dgates),
-                                     _ptr(carry), _stream()), "vqf_lstm_seq_bwd")
+    ws, nb = _lstm_seq_ws(B, H, dhs.device)
+    _l.check(_lib().vqf_lstm_seq_bwd(_ptr(dhs), _ptr(gates), _ptr(cs), _ptr(w_hh), S, B, H, _ptr(dgates),
+                                     _ptr(carry), _ptr(ws), nb, _stream()), "vqf_lstm_seq_bwd")
     return dgates
 
 
