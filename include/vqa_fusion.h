@@ -211,6 +211,15 @@ int vqf_mfb_fuse_bwd(const float* dY, const float* dzdrop, const float* Y, const
                      int N, int L, int O,
                      float* dP, float* dq, float* dcascade, float* dbiasP,
                      void* ws, size_t ws_bytes, void* stream);
+/* Same, for the image fusion in bf16 mode (no cascade, no dzdrop): dP is written as bf16
+ * (round-to-nearest-even), ready to be the A operand of the weight-gradient vqf_gemm_bf16 -- saves
+ * the 2 GB fp32 round trip and the cast pass.  dq / dbiasP stay fp32 and are accumulated from the
+ * unrounded values. */
+int vqf_mfb_fuse_bwd_bf16dp(const float* dY, const float* Y, const float* inv, const float* coefA,
+                            const float* coefB, const float* P, const float* pbias, const float* q,
+                            const uint8_t* keep, uint64_t seed, float p_drop, int N, int L, int O,
+                            void* dP_bf16, float* dq, float* dbiasP, void* ws, size_t ws_bytes, void* stream);
+
 
 /* --------------------------------------------------------------------------
  * Element-wise stages of HieCoAtten / AttentionNet.  n % 4 == 0, 16-byte aligned pointers.

@@ -35,6 +35,15 @@ __device__ __forceinline__ void store20(float* __restrict__ p, const float (&v)[
   }
 }
 
+// 20 values -> 20 bf16 (round-to-nearest-even), 5 x 8-byte stores (e0 * 2 bytes is a multiple of 8)
+__device__ __forceinline__ void store20(__bf16* __restrict__ p, const float (&v)[CPT]) {
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    __bf16 h[4] = {(__bf16)v[4 * i], (__bf16)v[4 * i + 1], (__bf16)v[4 * i + 2], (__bf16)v[4 * i + 3]};
+    *reinterpret_cast<uint2*>(p + 4 * i) = *reinterpret_cast<const uint2*>(h);
+  }
+}
+
 // scale[i] = keep ? 1/(1-p) : 0 for the 20 elements starting at flat index e0 (e0 % 4 == 0)
 __device__ __forceinline__ void keep_scale20(const uint8_t* __restrict__ keep, uint64_t seed,
                                              uint32_t thr, float inv_keep, long long e0,
@@ -114,7 +123,7 @@ mfb_fuse_fwd_kernel(const float* __restrict__ P, const float* __restrict__ pbias
 }
 
 // grid (N, LS); block 256.  Each block walks rows l = ls, ls+LS, ... of sample n.
-template <bool CASC, bool DBIAS>
+template <bool CASC, bool DBIAS, typename DPT>
 __global__ void __launch_bounds__(256)
 mfb_fuse_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ dzdrop,
                     const float* __restrict__ Y,
@@ -123,7 +132,7 @@ mfb_fuse_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ dzdr
                     const float* __restrict__ pbias,
                     const float* __restrict__ q, const float* __restrict__ cascade,
                     const uint8_t* __restrict__ keep, uint64_t seed, uint32_t thr, float inv_keep,
-                    int L, int O, int LS, float* __restrict__ dP, float* __restrict__ dq_part,
+                    int L, int O, int LS, DPT* __restrict__ dP, float* __restrict__ dq_part,
                     float* __restrict__ dcascade, float* __restrict__ db_part) {
   const int n = blockIdx.x, ls = blockIdx.y;
   const int W5 = KP * O;
@@ -187,6 +196,55 @@ int pick_ls(int N, int L) {
 
 }  // namespace
 
+static int fuse_bwd_impl(const float* dY, const float* dzdrop, const float* Y, const float* inv,
+                     const float* coefA,
+                     const float* coefB, const float* P, const float* pbias, const float* q,
+                     const float* cascade,
+                     const uint8_t* keep, uint64_t seed, float p_drop, int N, int L, int O,
+                     void* dP, int dp_bf16, float* dq, float* dcascade, float* dbiasP, void* ws,
+                     size_t ws_bytes, void* stream) {
+  if (!dY || !Y || !inv || !coefA || !coefB || !P || !q || !dP || !dq || N <= 0 || L <= 0 || O <= 0)
+    return VQF_E_BADARG;
+  if (O % TPT) return VQF_E_UNSUPPORTED;
+  if ((cascade != nullptr) != (dcascade != nullptr)) return VQF_E_BADARG;
+  if (dp_bf16 && cascade) return VQF_E_UNSUPPORTED;
+  if (p_drop < 0.f || p_drop >= 1.f) return VQF_E_BADARG;
+  if (!aligned16(dY) || (dzdrop && !aligned16(dzdrop)) || (pbias && !aligned16(pbias)) || !aligned16(Y) || !aligned16(P) || !aligned16(q) || !aligned16(dP) ||
+      !aligned16(dq) || (cascade && (!aligned16(cascade) || !aligned16(dcascade))) ||
+      (keep && (((uintptr_t)keep) & 3)))
+    return VQF_E_ALIGN;
+  const int LS = pick_ls(N, L);
+  const int W5 = KP * O;
+  const bool direct = (LS == 1);      // dq partial == dq
+  if (!direct || dbiasP) {
+    if (!ws || ws_bytes < vqf_mfb_fuse_bwd_ws_bytes(N, L, O) || !aligned16(ws)) return VQF_E_WORKSPACE;
+  }
+  float* dq_part = direct ? dq : (float*)ws;
+  float* db_part = (float*)ws + (size_t)N * LS * W5;
+  const uint32_t thr = (keep || p_drop == 0.f) ? 0u : drop_threshold_host(p_drop);
+  const float inv_keep = (keep || p_drop > 0.f) ? 1.0f / (1.0f - p_drop) : 1.0f;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(N, LS);
+#define VQF_BWD(C_, D_, T_)                                                                    \
+  VQF_LAUNCH(KID_MFB_FUSE_BWD, (mfb_fuse_bwd_kernel<C_, D_, T_>), grid, dim3(256), 0, s, dY, dzdrop, Y, inv, \
+             coefA, coefB, P, pbias, q, cascade, keep, seed, thr, inv_keep, L, O, LS, (T_*)dP, dq_part, \
+             dcascade, db_part)
+  if (dp_bf16)      { if (dbiasP) VQF_BWD(false, true, __bf16); else VQF_BWD(false, false, __bf16); }
+  else if (cascade) { if (dbiasP) VQF_BWD(true, true, float); else VQF_BWD(true, false, float); }
+  else              { if (dbiasP) VQF_BWD(false, true, float); else VQF_BWD(false, false, float); }
+#undef VQF_BWD
+  int rc = vqf_last_error();
+  if (rc) return rc;
+  if (!direct) {
+    rc = vqf_group_reduce_f32(dq_part, N, LS, W5, dq, stream);
+    if (rc) return rc;
+  }
+  if (dbiasP)
+    rc = vqf_colreduce_2stage(db_part, N * LS, W5, dbiasP, (float*)ws + (size_t)2 * N * LS * W5, s);
+  return rc;
+}
+
+
 extern "C" {
 
 int vqf_mfb_fuse_fwd(const float* P, const float* pbias, const float* q, const float* cascade,
@@ -214,49 +272,19 @@ size_t vqf_mfb_fuse_bwd_ws_bytes(int N, int L, int O) {
 }
 
 int vqf_mfb_fuse_bwd(const float* dY, const float* dzdrop, const float* Y, const float* inv,
-                     const float* coefA,
-                     const float* coefB, const float* P, const float* pbias, const float* q,
-                     const float* cascade,
-                     const uint8_t* keep, uint64_t seed, float p_drop, int N, int L, int O,
-                     float* dP, float* dq, float* dcascade, float* dbiasP, void* ws,
-                     size_t ws_bytes, void* stream) {
-  if (!dY || !Y || !inv || !coefA || !coefB || !P || !q || !dP || !dq || N <= 0 || L <= 0 || O <= 0)
-    return VQF_E_BADARG;
-  if (O % TPT) return VQF_E_UNSUPPORTED;
-  if ((cascade != nullptr) != (dcascade != nullptr)) return VQF_E_BADARG;
-  if (p_drop < 0.f || p_drop >= 1.f) return VQF_E_BADARG;
-  if (!aligned16(dY) || (dzdrop && !aligned16(dzdrop)) || (pbias && !aligned16(pbias)) || !aligned16(Y) || !aligned16(P) || !aligned16(q) || !aligned16(dP) ||
-      !aligned16(dq) || (cascade && (!aligned16(cascade) || !aligned16(dcascade))) ||
-      (keep && (((uintptr_t)keep) & 3)))
-    return VQF_E_ALIGN;
-  const int LS = pick_ls(N, L);
-  const int W5 = KP * O;
-  const bool direct = (LS == 1);      // dq partial == dq
-  if (!direct || dbiasP) {
-    if (!ws || ws_bytes < vqf_mfb_fuse_bwd_ws_bytes(N, L, O) || !aligned16(ws)) return VQF_E_WORKSPACE;
-  }
-  float* dq_part = direct ? dq : (float*)ws;
-  float* db_part = (float*)ws + (size_t)N * LS * W5;
-  const uint32_t thr = (keep || p_drop == 0.f) ? 0u : drop_threshold_host(p_drop);
-  const float inv_keep = (keep || p_drop > 0.f) ? 1.0f / (1.0f - p_drop) : 1.0f;
-  hipStream_t s = (hipStream_t)stream;
-  dim3 grid(N, LS);
-#define VQF_BWD(C_, D_)                                                                        \
-  VQF_LAUNCH(KID_MFB_FUSE_BWD, (mfb_fuse_bwd_kernel<C_, D_>), grid, dim3(256), 0, s, dY, dzdrop, Y, inv, \
-             coefA, coefB, P, pbias, q, cascade, keep, seed, thr, inv_keep, L, O, LS, dP, dq_part, \
-             dcascade, db_part)
-  if (cascade) { if (dbiasP) VQF_BWD(true, true); else VQF_BWD(true, false); }
-  else         { if (dbiasP) VQF_BWD(false, true); else VQF_BWD(false, false); }
-#undef VQF_BWD
-  int rc = vqf_last_error();
-  if (rc) return rc;
-  if (!direct) {
-    rc = vqf_group_reduce_f32(dq_part, N, LS, W5, dq, stream);
-    if (rc) return rc;
-  }
-  if (dbiasP)
-    rc = vqf_colreduce_2stage(db_part, N * LS, W5, dbiasP, (float*)ws + (size_t)2 * N * LS * W5, s);
-  return rc;
+                     const float* coefA, const float* coefB, const float* P, const float* pbias, const float* q,
+                     const float* cascade, const uint8_t* keep, uint64_t seed, float p_drop, int N, int L, int O,
+                     float* dP, float* dq, float* dcascade, float* dbiasP, void* ws, size_t ws_bytes, void* stream) {
+  return fuse_bwd_impl(dY, dzdrop, Y, inv, coefA, coefB, P, pbias, q, cascade, keep, seed, p_drop, N, L, O, dP, 0, dq,
+                       dcascade, dbiasP, ws, ws_bytes, stream);
+}
+
+int vqf_mfb_fuse_bwd_bf16dp(const float* dY, const float* Y, const float* inv, const float* coefA,
+                            const float* coefB, const float* P, const float* pbias, const float* q,
+                            const uint8_t* keep, uint64_t seed, float p_drop, int N, int L, int O, void* dP_bf16,
+                            float* dq, float* dbiasP, void* ws, size_t ws_bytes, void* stream) {
+  return fuse_bwd_impl(dY, nullptr, Y, inv, coefA, coefB, P, pbias, q, nullptr, keep, seed, p_drop, N, L, O, dP_bf16, 1,
+                       dq, nullptr, dbiasP, ws, ws_bytes, stream);
 }
 
 }  // extern "C"

@@ -145,9 +145,9 @@ class ImgFuseFn(torch.autograd.Function):
         img, wi, q, P, Y, norm, inv, keep = ctx.saved_tensors
         N, L, D, O = ctx.dims
         dP, dq, _, dbi = ops.mfb_fuse_bwd(_c(dY), Y, norm, inv, P, q, N, L, O, keep=keep, seed=ctx.seed,
-                                          p_drop=ctx.p_drop, want_dbias=True)
-        if ctx.bf16:
-            dwi = ops.gemm_bf16(ops.cast_bf16(dP), img, ta=True, tb=True).view_as(wi)
+                                          p_drop=ctx.p_drop, want_dbias=True, dp_bf16=ctx.bf16)
+        if ctx.bf16:                  # dP already is the bf16 A operand of the weight-gradient GEMM
+            dwi = ops.gemm_bf16(dP, img, ta=True, tb=True).view_as(wi)
         else:
             dwi = ops.gemm(dP, img.view(N * L, D), ta=True, tb=True).view_as(wi)   # wgrad, K = N*L
         return None, dwi, dbi, dq, None, None, None, None

@@ -59,6 +59,8 @@ SIGNATURES = {
     "vqf_mfb_fuse_bwd_ws_bytes": (c_sz, [c_i, c_i, c_i]),
     "vqf_mfb_fuse_bwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_u64, ctypes.c_float,
                                c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_p, c_sz, c_p]),
+    "vqf_mfb_fuse_bwd_bf16dp": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_u64, ctypes.c_float,
+                                      c_i, c_i, c_i, c_p, c_f, c_f, c_p, c_sz, c_p]),
     "vqf_lstm_seq_supported": (c_i, [c_i, c_i]),
     "vqf_lstm_seq_ws_bytes": (c_sz, [c_i, c_i]),
     "vqf_lstm_seq_fwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_p, c_sz, c_p]),

@@ -106,6 +106,9 @@ class MFB(nn.Module):
         # run img_conv1d (and, through autograd, its weight gradient) on a side stream, concurrently
         # with the question encoder / question attention (and their backward + gradient all-reduce)
         self.overlap_streams = True
+        # bf16 mode: one autograd node for projection + fusion, whose backward writes dP in bf16 for the
+        # weight-gradient GEMM (no 2 GB fp32 round trip, no cast pass); takes precedence over the overlap
+        self.fuse_bf16_dp = True
         self._side = _SideStream()
         self._seeds = _DropSeeds()
 
@@ -122,7 +125,10 @@ class MFB(nn.Module):
         _image_is_data(img_features, self.gemm_dtype)
         bf16_img = self.gemm_dtype in ("bf16", "bf16-img")
         # a5 starts first, on the side stream: it only needs the image and its weights
-        proj = self._side.project(img_features, self.img_conv1d, bf16_img) if self.overlap_streams else None
+        # bf16 mode keeps projection + fusion in one autograd node (ImgFuseFn): its backward hands dP to the
+        # weight-gradient GEMM in bf16 without an fp32 round trip, which is worth more than the stream overlap
+        side = self.overlap_streams and not (bf16_img and self.fuse_bf16_dp)
+        proj = self._side.project(img_features, self.img_conv1d, bf16_img) if side else None
         # a2: question encoder (PyTorch-ROCm)                                mfb.py:68-70
         que_embedded = torch.tanh(self.word_embedding(questions))
         lstm_o, _ = self.lstm(que_embedded)

@@ -40,6 +40,7 @@ class MHBCoAtt(nn.Module):
         # ~35 ms per step on 512 sequential tiny steps); same arithmetic, see csrc/lstm.hip
         self.use_hip_lstm = True
         self.overlap_streams = True       # img_conv1d on a side stream, see MFB.overlap_streams
+        self.fuse_bf16_dp = True          # see MFB.fuse_bf16_dp
         self._side = _SideStream()
         self._seeds = _DropSeeds()
 
@@ -51,7 +52,10 @@ class MHBCoAtt(nn.Module):
         N, L, D = img_features.shape
         keep = self._seeds.keep
         bf16_img = self.gemm_dtype in ("bf16", "bf16-img")
-        proj = self._side.project(img_features, self.img_conv1d, bf16_img) if self.overlap_streams else None
+        # bf16 mode keeps projection + fusion in one autograd node (ImgFuseFn): its backward hands dP to the
+        # weight-gradient GEMM in bf16 without an fp32 round trip, which is worth more than the stream overlap
+        side = self.overlap_streams and not (bf16_img and self.fuse_bf16_dp)
+        proj = self._side.project(img_features, self.img_conv1d, bf16_img) if side else None
         que_embedded = torch.tanh(self.word_embedding(questions))            # (N,T,E)
         if self.cfg.glove:
             assert glove_matrix is not None, 'glove should not be NoneType.'

@@ -308,8 +308,8 @@ def mfb_fuse_fwd(P, q, N, L, O, keep=None, seed=0, p_drop=0.0, cascade=None, wan
 
 
 def mfb_fuse_bwd(dY, Y, norm, inv, P, q, N, L, O, keep=None, seed=0, p_drop=0.0, cascade=None,
-                 want_dbias=False, dzdrop=None, pbias=None):
-    """-> (dP (N*L,5O), dq (N,5O), dcascade or None, dbiasP or None)."""
+                 want_dbias=False, dzdrop=None, pbias=None, dp_bf16=False):
+    """-> (dP (N*L,5O) fp32 | bf16, dq (N,5O), dcascade or None, dbiasP or None)."""
     _chk(dY, Y, norm, inv, P, q, cascade, dzdrop, pbias)
     dev = P.device
     rowdot = torch.empty(N * L, dtype=torch.float32, device=dev)
@@ -318,11 +318,20 @@ def mfb_fuse_bwd(dY, Y, norm, inv, P, q, N, L, O, keep=None, seed=0, p_drop=0.0,
     cB = torch.empty(N, dtype=torch.float32, device=dev)
     _l.check(_lib().vqf_l2_norm_bwd_coef(_ptr(rowdot), _ptr(norm), _ptr(inv), N, L, _ptr(cA), _ptr(cB),
                                          _stream()), "vqf_l2_norm_bwd_coef")
-    dP = torch.empty_like(P)
     dq = torch.empty((N, POOL_K * O), dtype=torch.float32, device=dev)
-    dc = torch.empty_like(P) if cascade is not None else None
     db = torch.empty(POOL_K * O, dtype=torch.float32, device=dev) if want_dbias else None
     ws = workspace(dev, _lib().vqf_mfb_fuse_bwd_ws_bytes(N, L, O))
+    if dp_bf16:                       # bf16 mode of the image fusion: dP goes straight to the wgrad GEMM
+        if cascade is not None or dzdrop is not None:
+            raise _l.VqfError("mfb_fuse_bwd: bf16 dP is only available without cascade / dzdrop")
+        dP = torch.empty(P.shape, dtype=torch.bfloat16, device=dev)
+        _l.check(_lib().vqf_mfb_fuse_bwd_bf16dp(_ptr(dY), _ptr(Y), _ptr(inv), _ptr(cA), _ptr(cB), _ptr(P), _ptr(pbias),
+                                                _ptr(q), _keep_ptr(keep), int(seed), float(p_drop), N, L, O, _ptr(dP),
+                                                _ptr(dq), _ptr(db), _ptr(ws), ws.numel(), _stream()),
+                 "vqf_mfb_fuse_bwd_bf16dp")
+        return dP, dq, None, db
+    dP = torch.empty_like(P)
+    dc = torch.empty_like(P) if cascade is not None else None
     _l.check(_lib().vqf_mfb_fuse_bwd(_ptr(dY), _ptr(dzdrop), _ptr(Y), _ptr(inv), _ptr(cA), _ptr(cB), _ptr(P), _ptr(pbias), _ptr(q),
                                      _ptr(cascade), _keep_ptr(keep), int(seed), float(p_drop), N, L, O,
                                      _ptr(dP), _ptr(dq), _ptr(dc), _ptr(db), _ptr(ws), ws.numel(), _stream()),
