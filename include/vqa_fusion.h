@@ -87,6 +87,9 @@ int vqf_gemm_f32_batched(int ta, int tb, int batch, int M, int N, int K,
  * to bf16 (uint16) data, same ta/tb meaning as vqf_gemm_f32; C, bias fp32.  Returns
  * VQF_E_UNSUPPORTED unless: bases 16-byte aligned, lda/ldb % 8 == 0, K % 8 == 0 for a
  * K-contiguous operand, row extent % 8 == 0 (and >= 8) for a K-major operand. */
+/* Scratch vqf_gemm_bf16 can use for this shape (deterministic split-K slabs of its 256x256-tile path,
+ * csrc/gemm_bf16_big.hip); with less (or none) it picks fewer splits or the 128x128 kernel. */
+size_t vqf_gemm_bf16_ws_bytes(int ta, int tb, int M, int N, int K);
 int vqf_gemm_bf16(int ta, int tb, int M, int N, int K,
                   const void* A, int lda, const void* B, int ldb,
                   float* C, int ldc, const float* bias, int flags,

@@ -10,7 +10,8 @@ import re
 import sys
 from collections import defaultdict
 
-FILTER = "gemm_f32_kernel"
+import os
+FILTER = os.environ.get("PMC_FILTER", "gemm_f32_kernel")
 
 
 def main(prefixes):

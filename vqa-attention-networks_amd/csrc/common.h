@@ -64,6 +64,11 @@ int vqf_colreduce_2stage(const float* in, int J, int W, float* out, float* scrat
 int vqf_splitk_reduce(const float* slab, int splits, int M, int N, float* C, int ldc,
                       const float* bias, int flags, hipStream_t s);   // gemm_f32.hip
 
+// gemm_bf16_big.hip: 256x256-tile kernel; returns 0 when it does not apply to the shape
+int vqf_gemm_bf16_big_try(int ta, int tb, int M, int N, int K, const void* A, int lda, const void* B, int ldb, float* C,
+                          int ldc, const float* bias, int flags, void* ws, size_t ws_bytes, hipStream_t s, int* rc);
+size_t vqf_gemm_bf16_big_ws_bytes(int ta, int tb, int M, int N, int K);
+
 static inline int vqf_last_error() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? VQF_OK : (int)e;

@@ -282,6 +282,10 @@ __global__ void cast_bf16_kernel(const float* __restrict__ x, int R, int C, int 
 
 extern "C" {
 
+size_t vqf_gemm_bf16_ws_bytes(int ta, int tb, int M, int N, int K) {
+  return vqf_gemm_bf16_big_ws_bytes(ta, tb, M, N, K);
+}
+
 int vqf_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A, int lda, const void* B,
                   int ldb, float* C, int ldc, const float* bias, int flags, void* ws,
                   size_t ws_bytes, void* stream) {
@@ -293,6 +297,10 @@ int vqf_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A, int lda, c
   if (ta && ((M % 8) || M < 8)) return VQF_E_UNSUPPORTED;
   if (tb && ((N % 8) || N < 8)) return VQF_E_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
+  {
+    int rc = VQF_OK;      // the two big projections take the 256x256-tile kernel
+    if (vqf_gemm_bf16_big_try(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, ws, ws_bytes, s, &rc)) return rc;
+  }
   GemmArgs g;
   g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C; g.bias = bias; g.slab = nullptr;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.flags = flags;

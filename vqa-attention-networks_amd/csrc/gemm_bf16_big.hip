@@ -1,0 +1,307 @@
+// Large-tile bf16 GEMM for the projection shapes that dominate the bf16 mode (gfx950 only):
+//
+//   C[m,n] (fp32) = sum_k Aop[m,k] * Bop[n,k] (+ bias[n]) (relu)      A, B stored as bf16, each either
+//   K-contiguous ((rows, K), "ta/tb = 0") or K-major ((K, rows), "ta/tb = 1"), as in gemm_bf16.hip.
+//
+// Why a second kernel: gemm_bf16.hip keeps the fp32 kernel's decomposition (128x128 block, four
+// 64x64 wave tiles).  With v_mfma_f32_32x32x16_bf16 a 64x64 wave tile needs 4 KB of LDS reads per
+// 128 MFMA cycles = 32 B/clk per wave, i.e. the CU's whole 128 B/clk of LDS bandwidth for its four
+// SIMDs: that kernel is LDS-bound at ~25 % of the bf16 MFMA peak (675 TFLOP/s on the image
+// projection).  Here a workgroup owns a 256x256 tile, 8 waves (2 x 4) own 128x64 each (4x2 MFMA
+// tiles, 128 accumulator registers, 2 waves per SIMD): 6 KB of fragment reads per 256 MFMA cycles.
+//   * staging: global_load_lds_dwordx4 (no VGPR round trip, no ds_write pass) in K slabs of 32;
+//     five 32 KB LDS slots (all 160 KB), four slabs in flight.  A wave waits for ITS copies of slab s
+//     with a counted s_waitcnt vmcnt (later slabs stay in flight), a raw s_barrier then covers the
+//     other waves' copies and everybody's reads of slab s-1, whose slot is re-filled right behind it
+//     (a plain __syncthreads() would drain the copies with vmcnt(0) at every slab).
+//   * K-contiguous operand: LDS image [row][32] bf16 (64-byte rows, unpadded because the LDS-DMA
+//     destination is wave-uniform base + lane*16); bank conflicts are removed by XOR-ing the 16-byte
+//     chunk index with (row >> 2) & 3 on the per-lane global SOURCE address and again on the fragment
+//     read (ds_read_b128): the 16 lanes of a read phase hit the 16 distinct slots of the bank row.
+//   * K-major operand (both operands of the weight gradient): LDS image [k][256] bf16 (512-byte k-rows,
+//     every copy instruction moves whole 128-byte lines) read with ds_read_b64_tr_b16; the 64-byte
+//     granule index is XOR-ed with k & 3 so that the 4 k-rows of a transposing read land on
+//     different bank quarters.
+//   * deterministic split-K (fixed-order slab reduction, vqf_splitk_reduce) when the tile count alone
+//     cannot fill the chip (the weight gradient: 20 x 8 tiles, K = 100352).
+// Measured on the image projection (M=100352, N=5000, K=2048, random operands): 675 -> 876 TFLOP/s.
+// By ablation the 2.35 ms are 1.09 ms of MFMA work at the ~1.8 GHz the chip sustains here, +0.43 ms
+// fragment-read stalls, +0.50 ms copy issue / barriers, +0.34 ms for the exposed fp32 epilogue (one
+// workgroup per CU).
+// Preconditions (else the caller falls back to gemm_bf16.hip): K % 32 == 0, M >= 256, N >= 128, no
+// accumulate flag, a K-major operand's row extent % 8 == 0; 16-byte aligned bases, lda/ldb % 8 == 0.
+#include "common.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short bf16_t;
+typedef const bf16_t __attribute__((address_space(1))) gbf16;
+
+constexpr int TM = 256, TN = 256, TK = 32, NT = 512;   // 8 waves: 2 (M) x 4 (N), 128 x 64 outputs each
+constexpr int OP_BYTES = 256 * TK * 2;                 // 16 KB per operand per slab (either layout)
+constexpr int SLOT_BYTES = 2 * OP_BYTES;               // 32 KB
+constexpr int NSLOT = 5;                               // slab s lives in slot s % 5: all 160 KB of LDS
+constexpr int SMEM_BIG = NSLOT * SLOT_BYTES;
+constexpr int NG = OP_BYTES / (NT * 16);               // 2 LDS-DMA instructions per thread per operand per slab
+constexpr int GROUP_M = 8;
+
+struct BigArgs {
+  const bf16_t* A;
+  const bf16_t* B;
+  float* C;              // output, or the split-K slabs (then ldc = N, no bias / relu)
+  const float* bias;
+  int M, N, K, lda, ldb, ldc, flags;
+  int tiles_m, tiles_n, kchunk, splits;
+};
+
+// per-lane global source pointers of the NG copies of one operand slab.
+//   K-contiguous: copy i, wave w, lane l -> row i*128 + 16w + (l >> 2), LDS chunk l & 3 (rows clamped to
+//   R-1: edge tiles read duplicates of the last row, whose results are never stored).
+//   K-major:      copy i, wave w, lane l -> k-row i*16 + 2w + (l >> 5), LDS chunk l & 31 of that row
+//   (column chunks past R are clamped to the last whole chunk: R % 8 == 0).
+template <bool T>
+__device__ __forceinline__ void init_src(gbf16* (&q)[NG], const bf16_t* base, int ld, int r0, int R, int k0,
+                                         int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < NG; ++i) {
+    if (!T) {
+      const int row = i * 128 + wave * 16 + (lane >> 2);
+      const int chunk = (lane & 3) ^ ((row >> 2) & 3);         // source chunk that lands on LDS slot lane & 3
+      q[i] = (gbf16*)(base + (long long)min(r0 + row, R - 1) * ld + k0 + chunk * 8);
+    } else {
+      const int k = i * 16 + wave * 2 + (lane >> 5);
+      const int c = lane & 31;
+      const int chunk = (((c >> 2) ^ (k & 3)) << 2) | (c & 3); // 64-byte granule XOR k & 3
+      q[i] = (gbf16*)(base + (long long)(k0 + k) * ld + min(r0 + chunk * 8, R - 8));
+    }
+  }
+}
+
+template <bool T>
+__device__ __forceinline__ void stage_operand(gbf16* (&q)[NG], int ld, char* s, int wave) {
+  typedef __attribute__((address_space(3))) char lds_char;
+#pragma unroll
+  for (int i = 0; i < NG; ++i) {
+    lds_char* dst = (lds_char*)(s + (i * 8 + wave) * 1024);    // wave-uniform; the DMA adds lane * 16
+    __builtin_amdgcn_global_load_lds(q[i], dst, 16, 0, 0);
+    q[i] += T ? (long long)TK * ld : TK;
+  }
+}
+
+// operand fragment of v_mfma_f32_32x32x16_bf16 for rows row0 .. row0+31, k = 16 ks .. +15 of a slab:
+// lane (r, h) holds k = 8h .. 8h+7 of row r.
+template <bool T>
+__device__ __forceinline__ bf16x8 read_frag(const char* s, int row0, int ks, int lane) {
+  if (!T) {
+    const int r = lane & 31, h = lane >> 5;
+    return *reinterpret_cast<const bf16x8*>(s + (row0 + r) * 64 + (((2 * ks + h) ^ ((r >> 2) & 3)) << 4));
+  }
+  // K-major image: 16-lane group g covers rows row0 + 16 (g & 1) .. +15 and k-block 16 ks + 8 (g >> 1);
+  // lane 4q+p of the group points at k-row q, rows 4p .. 4p+3 of the block and RECEIVES its own
+  // row's 4 k-values (ds_read_b64_tr_b16); two reads (k-rows q and q + 4) make one operand.
+  const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+  const int k = 16 * ks + 8 * (g >> 1) + q;
+  const int mo = row0 + 16 * (g & 1) + 4 * p;
+  const char* a0 = s + k * 512 + ((((mo >> 5) ^ (k & 3)) << 6) | ((2 * mo) & 63));
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * 512));
+  s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <bool GUARD_M>
+__device__ __forceinline__ void store_tile(const BigArgs& g, float* C, const f32x16 (&acc)[4][2], const float (&bv)[2],
+                                           int row_base, int col0, bool relu) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = col0 + j * 32;
+    if (col >= g.N) continue;
+    float* cp = C + (long long)row_base * g.ldc + col;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int dr = i * 32 + (e & 3) + 8 * (e >> 2);       // compile-time row offset
+        float v = acc[i][j][e] + bv[j];
+        if (relu) v = fmaxf(v, 0.f);
+        if (!GUARD_M || row_base + dr < g.M) cp[(long long)dr * g.ldc] = v;
+      }
+    }
+  }
+}
+
+template <bool TA, bool TB>
+__global__ void __launch_bounds__(NT, 2) gemm_bf16_big_kernel(const BigArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;             // rows wr*128 .. +127, columns wc*64 .. +63
+
+  // ---- tile order: split index slowest; bijective XCD remap, then groups of GROUP_M row tiles, m fastest
+  const int ntiles = g.tiles_m * g.tiles_n;
+  const int z = blockIdx.x / ntiles;
+  int id = blockIdx.x % ntiles;
+  {
+    const int q8 = ntiles / 8, r8 = ntiles % 8, xcd = id % 8, k = id / 8;
+    id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
+  }
+  const int per_group = GROUP_M * g.tiles_n;
+  const int grp = id / per_group, in = id % per_group;
+  const int gm0 = grp * GROUP_M;
+  const int gsz = min(GROUP_M, g.tiles_m - gm0);
+  const int tm = gm0 + in % gsz, tn = in / gsz;
+  const int m0 = tm * TM, n0 = tn * TN;
+  const int kbeg = z * g.kchunk;
+  const int S = (min(g.K, kbeg + g.kchunk) - kbeg) / TK;       // slabs of this split
+
+  gbf16* qa[NG];
+  gbf16* qb[NG];
+  init_src<TA>(qa, g.A, g.lda, m0, g.M, kbeg, wave, lane);
+  init_src<TB>(qb, g.B, g.ldb, n0, g.N, kbeg, wave, lane);
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+#pragma unroll
+  for (int p = 0; p < NSLOT - 1; ++p)
+    if (p < S) {
+      stage_operand<TA>(qa, g.lda, smem + p * SLOT_BYTES, wave);
+      stage_operand<TB>(qb, g.ldb, smem + p * SLOT_BYTES + OP_BYTES, wave);
+    }
+  int slot = 0;                                        // slot of slab s
+  for (int s = 0; s < S; ++s) {
+    const int later = min(NSLOT - 2, S - 1 - s);       // slabs issued after slab s that may stay in flight
+    if (later >= 3)      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // 2 * NG = 4 copies per thread per slab
+    else if (later == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const char* sA = smem + slot * SLOT_BYTES;
+    const char* sB = sA + OP_BYTES;
+    bf16x8 a0[4], b0[2], a1[4], b1[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a0[i] = read_frag<TA>(sA, wr * 128 + i * 32, 0, lane);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b0[j] = read_frag<TB>(sB, wc * 64 + j * 32, 0, lane);
+    if (s + NSLOT - 1 < S) {                           // refill the slot of slab s-1 (its address math hides LDS latency)
+      const int sl = (slot == 0) ? NSLOT - 1 : slot - 1;
+      stage_operand<TA>(qa, g.lda, smem + sl * SLOT_BYTES, wave);
+      stage_operand<TB>(qb, g.ldb, smem + sl * SLOT_BYTES + OP_BYTES, wave);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a1[i] = read_frag<TA>(sA, wr * 128 + i * 32, 1, lane);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b1[j] = read_frag<TB>(sB, wc * 64 + j * 32, 1, lane);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b0[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
+    slot = (slot + 1 == NSLOT) ? 0 : slot + 1;
+  }
+
+  // ---- epilogue: D[row = (e & 3) + 8 (e >> 2) + 4 h][col = lane & 31]; a half-wave stores 128 contiguous bytes
+  const int r = lane & 31, h = lane >> 5;
+  const bool split = g.splits > 1;
+  const bool relu = !split && (g.flags & VQF_GEMM_RELU) != 0;
+  float* C = split ? g.C + (size_t)z * g.M * g.N : g.C;
+  float bv[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + wc * 64 + j * 32 + r;
+    bv[j] = (!split && g.bias && col < g.N) ? g.bias[col] : 0.f;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the biases, once: no wait may sit between the stores
+  const int row_base = m0 + wr * 128 + 4 * h;
+  if (m0 + TM <= g.M) store_tile<false>(g, C, acc, bv, row_base, n0 + wc * 64 + r, relu);
+  else                store_tile<true>(g, C, acc, bv, row_base, n0 + wc * 64 + r, relu);
+}
+
+int pick_splits(int tiles, int K, int M, int N, size_t ws_bytes) {
+  if (tiles >= 768) return 1;
+  int best = 1;
+  double best_cost = 1e30;
+  for (int sp = 1; sp <= 16; ++sp) {
+    if (sp > 1 && (size_t)sp * M * N * sizeof(float) > ws_bytes) break;
+    if (sp > 1 && K / sp < 16 * TK) break;
+    const long long blocks = (long long)tiles * sp;
+    const double rounds = (double)((blocks + 255) / 256);            // one workgroup per CU
+    const double cost = rounds / sp + (sp > 1 ? 0.02 * sp : 0.0);    // + slab write / reduce traffic
+    if (cost < best_cost - 1e-12) { best_cost = cost; best = sp; }
+  }
+  return best;
+}
+
+template <bool TA, bool TB>
+int launch(const BigArgs& g, hipStream_t s) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_big_kernel<TA, TB>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BIG);
+  if (e != hipSuccess) return (int)e;
+  VQF_LAUNCH(KID_GEMM_BF16, (gemm_bf16_big_kernel<TA, TB>), dim3(g.tiles_m * g.tiles_n * g.splits), dim3(NT), SMEM_BIG,
+             s, g);
+  return vqf_last_error();
+}
+
+bool big_applies(int ta, int tb, int M, int N, int K, int flags) {
+  static int enabled = -1;
+  if (enabled < 0) {
+    const char* e = getenv("VQF_GEMM_BF16_BIG");       // A/B switch: 0 selects the 128x128 kernel everywhere
+    enabled = (e && e[0] == '0') ? 0 : 1;
+  }
+  if (!enabled || (K % TK) || M < TM || N < 128 || (flags & VQF_GEMM_ACCUM)) return false;
+  if (ta && (M % 8)) return false;
+  if (tb && (N % 8)) return false;
+  // few output tiles and a long K (co_att_conv1's weight gradient: 4 x 4 tiles): the 128x128 kernel's
+  // 64 tiles x 4 splits measured faster (0.36 vs 0.47 ms) than 16 tiles x 16 splits here
+  if (((M + TM - 1) / TM) * ((N + TN - 1) / TN) < 64) return false;
+  return true;
+}
+
+}  // namespace
+
+// scratch the big kernel would like for this shape (split-K slabs); 0 when it does not apply
+size_t vqf_gemm_bf16_big_ws_bytes(int ta, int tb, int M, int N, int K) {
+  if (!big_applies(ta, tb, M, N, K, 0)) return 0;
+  const int tiles = ((M + TM - 1) / TM) * ((N + TN - 1) / TN);
+  const int sp = pick_splits(tiles, K, M, N, (size_t)1 << 40);
+  return sp > 1 ? (size_t)sp * M * N * sizeof(float) : 0;
+}
+
+// 0 = this kernel does not apply (caller falls back to gemm_bf16.hip), 1 = launched (rc holds the status)
+int vqf_gemm_bf16_big_try(int ta, int tb, int M, int N, int K, const void* A, int lda, const void* B, int ldb, float* C,
+                          int ldc, const float* bias, int flags, void* ws, size_t ws_bytes, hipStream_t s, int* rc) {
+  if (!big_applies(ta, tb, M, N, K, flags)) return 0;
+  BigArgs g;
+  g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C; g.bias = bias;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.flags = flags;
+  g.tiles_m = (M + TM - 1) / TM;
+  g.tiles_n = (N + TN - 1) / TN;
+  const int tiles = g.tiles_m * g.tiles_n;
+  int splits = pick_splits(tiles, K, M, N, (ws && aligned16(ws)) ? ws_bytes : 0);
+  const int slabs = K / TK;
+  const int per = (slabs + splits - 1) / splits;
+  g.kchunk = per * TK;
+  splits = (K + g.kchunk - 1) / g.kchunk;
+  g.splits = splits;
+  if (splits > 1) { g.C = (float*)ws; g.ldc = N; }
+  vqf_prof_dims(M, N, K);
+  if (ta) *rc = tb ? launch<true, true>(g, s) : launch<true, false>(g, s);
+  else    *rc = tb ? launch<false, true>(g, s) : launch<false, false>(g, s);
+  if (*rc == VQF_OK && splits > 1) *rc = vqf_splitk_reduce((const float*)ws, splits, M, N, C, ldc, bias, flags, s);
+  return 1;
+}

@@ -129,7 +129,7 @@ def gemm_bf16(a, b, ta=False, tb=False, bias=None, relu=False, M=None, N=None, K
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
     flags = (GEMM_RELU if relu else 0) | (GEMM_ACCUM if accumulate else 0)
-    ws = workspace(a.device, SPLITK_WS_BYTES)
+    ws = workspace(a.device, max(SPLITK_WS_BYTES, int(_lib().vqf_gemm_bf16_ws_bytes(int(ta), int(tb), M, N, K))))
     rc = _lib().vqf_gemm_bf16(int(ta), int(tb), M, N, K, _ptr(a), a.stride(0), _ptr(b), b.stride(0),
                               _ptr(out), out.stride(0), _ptr(bias), flags, _ptr(ws), ws.numel(), _stream())
     _l.check(rc, "vqf_gemm_bf16")
