@@ -53,8 +53,10 @@ def _worker(rank, world, port, bucket_bytes, q):
         loss = torch.nn.functional.cross_entropy(model(X[lo:hi]), Y[lo:hi])
         loss.backward()
         red.finish()
-        outs.append([None if p.grad is None else p.grad.clone() for p in model.parameters()])
-    q.put((rank, [p.detach().clone() for p in model.parameters()], outs, len(red.buckets)))
+        outs.append([None if p.grad is None else p.grad.clone().numpy() for p in model.parameters()])
+    # numpy, not torch tensors: a tensor travels through the queue as a shared-memory handle that can be
+    # gone by the time the parent unpickles it if this process has already exited (seen as a flaky None)
+    q.put((rank, [p.detach().clone().numpy() for p in model.parameters()], outs, len(red.buckets)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -101,13 +103,13 @@ def test_allreduce_equals_full_batch_gradient(bucket_bytes):
     for rank in range(world):
         params, outs, _ = res[rank]
         for a, b in zip(params, model.parameters()):
-            assert torch.equal(a, b.detach())             # broadcast made the replicas identical
+            assert torch.equal(torch.from_numpy(a), b.detach())   # broadcast made the replicas identical
         for step in range(2):
             for gavg, gref in zip(outs[step], ref):
                 if gref is None:
-                    assert gavg is None or float(gavg.abs().max()) == 0.0
+                    assert gavg is None or float(abs(gavg).max()) == 0.0
                 else:
-                    assert torch.allclose(gavg, gref, rtol=1e-5, atol=1e-7)
+                    assert torch.allclose(torch.from_numpy(gavg), gref, rtol=1e-5, atol=1e-7)
 
 
 def test_shard_rows_partitions_the_batch():
