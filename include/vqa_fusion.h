@@ -256,10 +256,12 @@ int vqf_softmax_rows_bwd(const float* dy, const float* y, int R, int W, float* d
  * Supported: B <= 32, H in {256,512,768,1024} (vqf_lstm_seq_supported); else VQF_E_UNSUPPORTED. */
 int vqf_lstm_seq_supported(int B, int H);
 size_t vqf_lstm_seq_ws_bytes(int B, int H);
+#define VQF_LSTM_BF16 1   /* flags: W_hh and the recurrent operand (h / dG) enter the MFMA as bf16 (bf16 mode);
+                             accumulation, gates, cell state and all stored tensors stay fp32 */
 int vqf_lstm_seq_fwd(const float* xw, const float* w_hh, int S, int B, int H,
-                     float* hs, float* cs, float* gates, void* ws, size_t ws_bytes, void* stream);
+                     float* hs, float* cs, float* gates, int flags, void* ws, size_t ws_bytes, void* stream);
 int vqf_lstm_seq_bwd(const float* dhs, const float* gates, const float* cs, const float* w_hh,
-                     int S, int B, int H, float* dgates, float* dc_carry, void* ws, size_t ws_bytes,
+                     int S, int B, int H, float* dgates, float* dc_carry, int flags, void* ws, size_t ws_bytes,
                      void* stream);
 
 /* The same recursion as ONE launch for the whole sequence (csrc/lstm_persist.hip): W_hh stays in

@@ -364,15 +364,19 @@ class LstmSeqFn(torch.autograd.Function):
     ops.LSTM_PERSISTENT), else one fused kernel launch per step (vqf_lstm_seq_fwd / _bwd)."""
 
     @staticmethod
-    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh):
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, bf16=False):
         x = _c(x)
         S, B, I = x.shape
         H = w_hh.shape[1]
         bias = (b_ih + b_hh) if b_ih is not None else None
         xw = ops.gemm(x.view(S * B, I), _c(w_ih), bias=bias).view(S, B, 4 * H)
-        persist = bool(ops.LSTM_PERSISTENT) and ops.lstm_persist_supported(B, H)
+        ctx.bf16 = bool(bf16)          # bf16 operands in the recurrent product (bf16 mode), fp32 everywhere else
+        persist = (not ctx.bf16) and bool(ops.LSTM_PERSISTENT) and ops.lstm_persist_supported(B, H)
         ctx.persist_bwd = persist and ops.LSTM_PERSISTENT != "fwd"
-        hs, cs, gates = (ops.lstm_seq_fwd_persist if persist else ops.lstm_seq_fwd)(xw, _c(w_hh))
+        if persist:
+            hs, cs, gates = ops.lstm_seq_fwd_persist(xw, _c(w_hh))
+        else:
+            hs, cs, gates = ops.lstm_seq_fwd(xw, _c(w_hh), bf16=ctx.bf16)
         ctx.save_for_backward(x, w_ih, w_hh, hs, cs, gates)
         ctx.has_bias = b_ih is not None
         return hs
@@ -385,7 +389,7 @@ class LstmSeqFn(torch.autograd.Function):
         if ctx.persist_bwd:
             dg = ops.lstm_seq_bwd_persist(_c(dhs), gates, cs, _c(w_hh))            # (S,B,4H)
         else:
-            dg = ops.lstm_seq_bwd(_c(dhs), gates, cs, _c(w_hh))
+            dg = ops.lstm_seq_bwd(_c(dhs), gates, cs, _c(w_hh), bf16=ctx.bf16)
         dg2 = dg.view(S * B, 4 * H)
         dx = ops.gemm(dg2, _c(w_ih), tb=True).view(S, B, I) if ctx.needs_input_grad[0] else None
         dw_ih = ops.gemm(dg2, x.view(S * B, I), ta=True, tb=True)
@@ -394,4 +398,4 @@ class LstmSeqFn(torch.autograd.Function):
         else:
             dw_hh = torch.zeros_like(w_hh)
         db = ops.colsum(dg2) if ctx.has_bias else None
-        return dx, dw_ih, dw_hh, db, (db.clone() if db is not None else None)
+        return dx, dw_ih, dw_hh, db, (db.clone() if db is not None else None), None

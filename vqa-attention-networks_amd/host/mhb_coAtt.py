@@ -69,7 +69,8 @@ class MHBCoAtt(nn.Module):
             # (N,T,.) is already (S,B,.) for the sequence kernel and its output (N,T,H) is the
             # reference's lstm_o.permute(1,0,2).
             hs = LstmSeqFn.apply(que_embedded, self.lstm.weight_ih_l0, self.lstm.weight_hh_l0,
-                                 self.lstm.bias_ih_l0, self.lstm.bias_hh_l0)
+                                 self.lstm.bias_ih_l0, self.lstm.bias_hh_l0,
+                                 self.gemm_dtype == "bf16")     # bf16 mode: bf16 operands in the recurrent product
             ques_feature = self.dropout_l(hs).contiguous()
         else:
             lstm_o, _ = self.lstm(que_embedded.permute(1, 0, 2))             # (T,N,H), recurs over N

@@ -348,8 +348,9 @@ def _lstm_seq_ws(B, H, device):
     return workspace(device, nbytes), nbytes
 
 
-def lstm_seq_fwd(xw, w_hh):
-    """xw (S,B,4H) = x W_ih^T + biases, w_hh (4H,H) -> hs (S,B,H), cs (S,B,H), gates (S,B,4H) activated."""
+def lstm_seq_fwd(xw, w_hh, bf16=False):
+    """xw (S,B,4H) = x W_ih^T + biases, w_hh (4H,H) -> hs (S,B,H), cs (S,B,H), gates (S,B,4H) activated.
+    bf16: the recurrent product takes bf16 operands (fp32 accumulate; bf16 mode)."""
     _chk(xw, w_hh)
     S, B, H4 = xw.shape
     H = H4 // 4
@@ -357,12 +358,12 @@ def lstm_seq_fwd(xw, w_hh):
     cs = torch.empty_like(hs)
     gates = torch.empty_like(xw)
     ws, nb = _lstm_seq_ws(B, H, xw.device)
-    _l.check(_lib().vqf_lstm_seq_fwd(_ptr(xw), _ptr(w_hh), S, B, H, _ptr(hs), _ptr(cs), _ptr(gates), _ptr(ws), nb,
-                                     _stream()), "vqf_lstm_seq_fwd")
+    _l.check(_lib().vqf_lstm_seq_fwd(_ptr(xw), _ptr(w_hh), S, B, H, _ptr(hs), _ptr(cs), _ptr(gates),
+                                     1 if bf16 else 0, _ptr(ws), nb, _stream()), "vqf_lstm_seq_fwd")
     return hs, cs, gates
 
 
-def lstm_seq_bwd(dhs, gates, cs, w_hh):
+def lstm_seq_bwd(dhs, gates, cs, w_hh, bf16=False):
     """-> dgates (S,B,4H): gradient w.r.t. the gate pre-activations; w_hh (4H,H) as stored."""
     _chk(dhs, gates, cs, w_hh)
     S, B, H = dhs.shape
@@ -370,7 +371,7 @@ def lstm_seq_bwd(dhs, gates, cs, w_hh):
     carry = torch.empty((B, H), dtype=torch.float32, device=dhs.device)
     ws, nb = _lstm_seq_ws(B, H, dhs.device)
     _l.check(_lib().vqf_lstm_seq_bwd(_ptr(dhs), _ptr(gates), _ptr(cs), _ptr(w_hh), S, B, H, _ptr(dgates),
-                                     _ptr(carry), _ptr(ws), nb, _stream()), "vqf_lstm_seq_bwd")
+                                     _ptr(carry), 1 if bf16 else 0, _ptr(ws), nb, _stream()), "vqf_lstm_seq_bwd")
     return dgates
 
 
