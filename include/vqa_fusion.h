@@ -69,6 +69,9 @@ const char* vqf_build_info(void);
  * Vector (16-byte) loads are used when pointers and leading dimensions allow
  * it; any shape/alignment is accepted.
  */
+/* Scratch vqf_gemm_f32 can use for this shape (deterministic split-K slabs); with less it picks fewer
+ * splits.  Never more than 16 * M * N * 4 bytes. */
+size_t vqf_gemm_f32_ws_bytes(int ta, int tb, int M, int N, int K);
 int vqf_gemm_f32(int ta, int tb, int M, int N, int K,
                  const float* A, int lda, const float* B, int ldb,
                  float* C, int ldc, const float* bias, int flags,

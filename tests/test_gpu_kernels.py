@@ -36,7 +36,9 @@ def _rel(a, b):
 
 
 GEMM_SHAPES = [(1, 1, 1), (5, 7, 3), (33, 65, 31), (130, 257, 70), (128, 128, 32), (256, 384, 1000),
-               (100, 5000, 64), (3, 2, 4096), (300, 200, 4100)]
+               (100, 5000, 64), (3, 2, 4096), (300, 200, 4100),
+               # >= 64 tiles of 256x256 with ragged edges: the large-tile LDS-DMA kernel (gemm_f32_big.hip)
+               (2100, 2300, 528), (2048, 2052, 48)]
 
 
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
@@ -239,3 +241,18 @@ def test_errors_are_loud(ops):
         ops.mfb_fuse_fwd(torch.zeros(2, 35, device="cuda"), torch.zeros(2, 35, device="cuda"), 2, 1, 7)
     with pytest.raises(vqa_amd.VqfError):
         ops.glimpse_pool_fwd(torch.zeros(1, 2000, 4, device="cuda"), torch.zeros(2000, 2, device="cuda"), False)
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0)])
+def test_gemm_large_tile_kernel_splitk_relu_bias(ops, ta, tb):
+    """256x256-tile kernel with split-K (64 tiles, K = 8192 -> several splits through the slab reducer),
+    bias and ReLU; fp64 reference, 2e-5 (K = 8192 fp32 accumulation)."""
+    M, N, K = 2048, 2048, 8192
+    A = _rand((K, M) if ta else (M, K), 21, 0.5)
+    B = _rand((K, N) if tb else (N, K), 22, 0.5)
+    bias = _rand((N,), 23)
+    ref = torch.relu((A.t() if ta else A) @ (B if tb else B.t()) + bias)
+    out = ops.gemm(A.float().cuda(), B.float().cuda(), ta=bool(ta), tb=bool(tb), bias=bias.float().cuda(), relu=True)
+    assert _rel(out, ref) <= 2e-5
+    out2 = ops.gemm(A.float().cuda(), B.float().cuda(), ta=bool(ta), tb=bool(tb), bias=bias.float().cuda(), relu=True)
+    assert torch.equal(out, out2)                       # fixed-order slab reduction: run-to-run identical

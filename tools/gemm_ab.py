@@ -33,7 +33,7 @@ else:
     ta, tb, m, n, k = 0, 0, M, 1024, 1000
     A, Bm = rnd(M, 1000), rnd(1024, 1000)
 C = torch.empty(m, n, device=dev)
-ws = torch.empty(192 << 20, dtype=torch.uint8, device=dev)
+ws = torch.empty(400 << 20, dtype=torch.uint8, device=dev)
 bias = rnd(n)
 libs = []
 for p in args.libs:

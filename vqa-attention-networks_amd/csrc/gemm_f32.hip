@@ -501,12 +501,20 @@ int vqf_splitk_reduce(const float* slab, int splits, int M, int N, float* C, int
   return vqf_last_error();
 }
 
+extern "C" size_t vqf_gemm_f32_ws_bytes(int ta, int tb, int M, int N, int K) {
+  return vqf_gemm_f32_big_ws_bytes(ta, tb, M, N, K);
+}
+
 extern "C" int vqf_gemm_f32(int ta, int tb, int M, int N, int K, const float* A, int lda,
                             const float* B, int ldb, float* C, int ldc, const float* bias,
                             int flags, void* ws, size_t ws_bytes, void* stream) {
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || lda <= 0 || ldb <= 0 || ldc < N)
     return VQF_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
+  if (aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0)) {
+    int rc = VQF_OK;      // large shapes take the 256x256-tile LDS-DMA kernel (gemm_f32_big.hip)
+    if (vqf_gemm_f32_big_try(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, ws, ws_bytes, s, &rc)) return rc;
+  }
   GemmArgs g;
   g.A = A; g.B = B; g.C = C; g.bias = bias; g.slab = nullptr;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.flags = flags;

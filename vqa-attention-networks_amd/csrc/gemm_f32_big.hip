@@ -1,0 +1,293 @@
+// Large-tile fp32 GEMM (gfx950 only): the structure of gemm_bf16_big.hip with fp32 operands and
+// v_mfma_f32_32x32x2_f32.
+//
+//   C[m,n] = sum_k Aop[m,k] * Bop[n,k] (+ bias[n]) (relu)      each operand K-contiguous ((rows, K)) or
+//   K-major ((K, rows)), as in gemm_f32.hip.
+//
+// 256x256 workgroup tile, 8 waves of 128x64 (4x2 MFMA tiles, 128 accumulator registers, 2 waves per
+// SIMD), operands staged by LDS-DMA (global_load_lds_dwordx4) in K slabs of 16 into five 32 KB slots
+// with four slabs in flight (counted s_waitcnt vmcnt + raw s_barrier).  A slab costs a wave 64 MFMAs
+// of 64 cycles, so the copy / barrier / fragment-read overheads that limit the bf16 kernel are a few
+// per cent here, and there is no VGPR staging, no ds_write pass and one barrier per 16 k.
+//   * K-contiguous operand: [row][16] floats (64-byte rows, byte-identical to the bf16 image), chunk
+//     XOR (row >> 2) & 3 on the copy's source address and on the ds_read_b128; a lane's 4 floats feed
+//     4 MFMAs: lane (r, h) holds k = 8h + 4ks + e of row r for MFMA (ks, e).
+//   * K-major operand: [k][256] floats (1 KB k-rows, a wave copy = one k-row, whole lines); fragments are
+//     ds_read_b32 (32 lanes = 128 contiguous bytes, conflict-free without a swizzle), same k mapping.
+//   * deterministic split-K for few-tile / long-K shapes (the weight gradient).
+// Preconditions (else the caller uses gemm_f32.hip): K % 16 == 0, M >= 256, N >= 128, >= 64 tiles, no
+// accumulate flag, 16-byte aligned bases, lda/ldb % 4 == 0, a K-major operand's row extent % 4 == 0.
+#include "common.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef const float __attribute__((address_space(1))) gfloat;
+
+#ifndef VQF_F32BIG_TK
+#define VQF_F32BIG_TK 16
+#endif
+#ifndef VQF_F32BIG_NSLOT
+#define VQF_F32BIG_NSLOT (VQF_F32BIG_TK == 16 ? 5 : 2)
+#endif
+constexpr int TM = 256, TN = 256, TK = VQF_F32BIG_TK, NT = 512;   // 8 waves: 2 (M) x 4 (N), 128 x 64 outputs each
+constexpr int ROW_B = TK * 4, CH = ROW_B / 16;         // K-contiguous image: bytes per row, 16-byte chunks per row
+constexpr int OP_BYTES = 256 * ROW_B;                  // per operand per slab (either layout)
+constexpr int SLOT_BYTES = 2 * OP_BYTES;
+constexpr int NSLOT = VQF_F32BIG_NSLOT;                // slab s lives in slot s % NSLOT
+constexpr int SMEM_BIG = NSLOT * SLOT_BYTES;
+constexpr int NG = OP_BYTES / (NT * 16);               // 2 LDS-DMA instructions per thread per operand per slab
+constexpr int GROUP_M = 8;
+
+struct BigArgs {
+  const float* A;
+  const float* B;
+  float* C;              // output, or the split-K slabs (then ldc = N, no bias / relu)
+  const float* bias;
+  int M, N, K, lda, ldb, ldc, flags;
+  int tiles_m, tiles_n, kchunk, splits;
+};
+
+// per-lane global source pointers of the NG copies of one operand slab.
+//   K-contiguous: copy i, wave w, lane l -> row i*128 + 16w + (l >> 2), LDS chunk l & 3 (rows clamped to
+//   R-1: edge tiles read duplicates of the last row, whose results are never stored).
+//   K-major:      copy i, wave w, lane l -> k-row i*8 + w, floats 4l .. 4l+3 of that row (column chunks
+//   past R are clamped to the last whole chunk: R % 4 == 0).
+// chunk XOR of row r: the 16 lanes of a ds_read_b128 phase must hit 16 distinct 16-byte slots of the 256-byte bank row
+__device__ __forceinline__ int swz(int r) { return CH == 4 ? ((r >> 2) & 3) : ((r >> 1) & 7); }
+
+template <bool T>
+__device__ __forceinline__ void init_src(gfloat* (&q)[NG], const float* base, int ld, int r0, int R, int k0,
+                                         int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < NG; ++i) {
+    if (!T) {
+      constexpr int RPW = 1024 / ROW_B;                        // rows per wave copy (1 KB)
+      const int row = i * (8 * RPW) + wave * RPW + lane / CH;
+      const int chunk = (lane % CH) ^ swz(row);                // source chunk that lands on LDS slot lane % CH
+      q[i] = (gfloat*)(base + (long long)min(r0 + row, R - 1) * ld + k0 + chunk * 4);
+    } else {
+      const int k = i * 8 + wave;
+      q[i] = (gfloat*)(base + (long long)(k0 + k) * ld + min(r0 + lane * 4, R - 4));
+    }
+  }
+}
+
+template <bool T>
+__device__ __forceinline__ void stage_operand(gfloat* (&q)[NG], int ld, char* s, int wave) {
+  typedef __attribute__((address_space(3))) char lds_char;
+#pragma unroll
+  for (int i = 0; i < NG; ++i) {
+    lds_char* dst = (lds_char*)(s + (i * 8 + wave) * 1024);    // wave-uniform; the DMA adds lane * 16
+    __builtin_amdgcn_global_load_lds(q[i], dst, 16, 0, 0);
+    q[i] += T ? (long long)TK * ld : TK;
+  }
+}
+
+// 4 operand values of rows row0 .. row0+31 for the MFMAs (ks, e = 0..3) of a slab: lane (r, h) holds
+// k = 8ks + 4h + e of row r (v_mfma_f32_32x32x2_f32 takes k = 0 from lanes 0-31 and k = 1 from lanes 32-63;
+// any fixed pairing of the slab's 16 k works as long as both operands use the same one).
+template <bool T>
+__device__ __forceinline__ f32x4 read_frag(const char* s, int row0, int ks, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  if (!T) return *reinterpret_cast<const f32x4*>(s + (row0 + r) * ROW_B + (((2 * ks + h) ^ swz(r)) << 4));
+  const float* p = reinterpret_cast<const float*>(s) + (8 * ks + 4 * h) * 256 + row0 + r;
+  return f32x4{p[0], p[256], p[512], p[768]};
+}
+
+template <bool GUARD_M>
+__device__ __forceinline__ void store_tile(const BigArgs& g, float* C, const f32x16 (&acc)[4][2], const float (&bv)[2],
+                                           int row_base, int col0, bool relu) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = col0 + j * 32;
+    if (col >= g.N) continue;
+    float* cp = C + (long long)row_base * g.ldc + col;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int dr = i * 32 + (e & 3) + 8 * (e >> 2);       // compile-time row offset
+        float v = acc[i][j][e] + bv[j];
+        if (relu) v = fmaxf(v, 0.f);
+        if (!GUARD_M || row_base + dr < g.M) cp[(long long)dr * g.ldc] = v;
+      }
+    }
+  }
+}
+
+template <bool TA, bool TB>
+__global__ void __launch_bounds__(NT, 2) gemm_f32_big_kernel(const BigArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;             // rows wr*128 .. +127, columns wc*64 .. +63
+
+  // ---- tile order: split index slowest; bijective XCD remap, then groups of GROUP_M row tiles, m fastest
+  const int ntiles = g.tiles_m * g.tiles_n;
+  const int z = blockIdx.x / ntiles;
+  int id = blockIdx.x % ntiles;
+  {
+    const int q8 = ntiles / 8, r8 = ntiles % 8, xcd = id % 8, k = id / 8;
+    id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
+  }
+  const int per_group = GROUP_M * g.tiles_n;
+  const int grp = id / per_group, in = id % per_group;
+  const int gm0 = grp * GROUP_M;
+  const int gsz = min(GROUP_M, g.tiles_m - gm0);
+  const int tm = gm0 + in % gsz, tn = in / gsz;
+  const int m0 = tm * TM, n0 = tn * TN;
+  const int kbeg = z * g.kchunk;
+  const int S = (min(g.K, kbeg + g.kchunk) - kbeg) / TK;       // slabs of this split
+
+  gfloat* qa[NG];
+  gfloat* qb[NG];
+  init_src<TA>(qa, g.A, g.lda, m0, g.M, kbeg, wave, lane);
+  init_src<TB>(qb, g.B, g.ldb, n0, g.N, kbeg, wave, lane);
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+#pragma unroll
+  for (int p = 0; p < NSLOT - 1; ++p)
+    if (p < S) {
+      stage_operand<TA>(qa, g.lda, smem + p * SLOT_BYTES, wave);
+      stage_operand<TB>(qb, g.ldb, smem + p * SLOT_BYTES + OP_BYTES, wave);
+    }
+  int slot = 0;                                        // slot of slab s
+  for (int s = 0; s < S; ++s) {
+    const int later = min(NSLOT - 2, S - 1 - s);       // slabs issued after slab s that may stay in flight
+    static_assert(2 * NG == 4 || NSLOT == 2, "the vmcnt immediates below assume 4 copies per thread per slab");
+    if (later >= 3)      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (later == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const char* sA = smem + slot * SLOT_BYTES;
+    const char* sB = sA + OP_BYTES;
+    f32x4 fa[2][4], fb[2][2];                            // fragment double buffer: reads run one k-step ahead
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[0][i] = read_frag<TA>(sA, wr * 128 + i * 32, 0, lane);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) fb[0][j] = read_frag<TB>(sB, wc * 64 + j * 32, 0, lane);
+    if (s + NSLOT - 1 < S) {                           // refill the slot of slab s-1 (its address math hides LDS latency)
+      const int sl = (slot == 0) ? NSLOT - 1 : slot - 1;
+      stage_operand<TA>(qa, g.lda, smem + sl * SLOT_BYTES, wave);
+      stage_operand<TB>(qb, g.ldb, smem + sl * SLOT_BYTES + OP_BYTES, wave);
+    }
+#pragma unroll
+    for (int ks = 0; ks < TK / 8; ++ks) {
+      if (ks + 1 < TK / 8) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[(ks + 1) & 1][i] = read_frag<TA>(sA, wr * 128 + i * 32, ks + 1, lane);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[(ks + 1) & 1][j] = read_frag<TB>(sB, wc * 64 + j * 32, ks + 1, lane);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ks & 1][i][e], fb[ks & 1][j][e], acc[i][j], 0, 0, 0);
+    }
+    slot = (slot + 1 == NSLOT) ? 0 : slot + 1;
+  }
+
+  // ---- epilogue: D[row = (e & 3) + 8 (e >> 2) + 4 h][col = lane & 31]; a half-wave stores 128 contiguous bytes
+  const int r = lane & 31, h = lane >> 5;
+  const bool split = g.splits > 1;
+  const bool relu = !split && (g.flags & VQF_GEMM_RELU) != 0;
+  float* C = split ? g.C + (size_t)z * g.M * g.N : g.C;
+  float bv[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + wc * 64 + j * 32 + r;
+    bv[j] = (!split && g.bias && col < g.N) ? g.bias[col] : 0.f;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the biases, once: no wait may sit between the stores
+  const int row_base = m0 + wr * 128 + 4 * h;
+  if (m0 + TM <= g.M) store_tile<false>(g, C, acc, bv, row_base, n0 + wc * 64 + r, relu);
+  else                store_tile<true>(g, C, acc, bv, row_base, n0 + wc * 64 + r, relu);
+}
+
+int pick_splits(int tiles, int K, int M, int N, size_t ws_bytes) {
+  if (tiles >= 768) return 1;
+  int best = 1;
+  double best_cost = 1e30;
+  for (int sp = 1; sp <= 16; ++sp) {
+    if (sp > 1 && (size_t)sp * M * N * sizeof(float) > ws_bytes) break;
+    if (sp > 1 && K / sp < 16 * TK) break;
+    const long long blocks = (long long)tiles * sp;
+    const double rounds = (double)((blocks + 255) / 256);            // one workgroup per CU
+    const double cost = rounds / sp + (sp > 1 ? 0.02 * sp : 0.0);    // + slab write / reduce traffic
+    if (cost < best_cost - 1e-12) { best_cost = cost; best = sp; }
+  }
+  return best;
+}
+
+template <bool TA, bool TB>
+int launch(const BigArgs& g, hipStream_t s) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_big_kernel<TA, TB>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BIG);
+  if (e != hipSuccess) return (int)e;
+  VQF_LAUNCH(KID_GEMM_A0B0 + 2 * (TA ? 1 : 0) + (TB ? 1 : 0), (gemm_f32_big_kernel<TA, TB>), dim3(g.tiles_m * g.tiles_n * g.splits), dim3(NT), SMEM_BIG,
+             s, g);
+  return vqf_last_error();
+}
+
+bool big_applies(int ta, int tb, int M, int N, int K, int flags) {
+  static int enabled = -1;
+  if (enabled < 0) {
+    const char* e = getenv("VQF_GEMM_F32_BIG");        // A/B switch: 0 selects the 128x128 kernel everywhere
+    enabled = (e && e[0] == '0') ? 0 : 1;
+  }
+  if (!enabled || (K % TK) || M < TM || N < 128 || (flags & VQF_GEMM_ACCUM)) return false;
+  if (ta && (M % 4)) return false;
+  if (tb && (N % 4)) return false;
+  // both operands K-major (the weight gradients): every fragment is 4 ds_read_b32 + address math, and the
+  // 128x128 kernel measured faster on img_conv1d's wgrad (15.1-15.9 vs 15.8-16.0 ms)
+  if (ta && tb) return false;
+  // few output tiles: the 128x128 kernel fills the chip better
+  if (((M + TM - 1) / TM) * ((N + TN - 1) / TN) < 64) return false;
+  return true;
+}
+
+}  // namespace
+
+// scratch the big kernel would like for this shape (split-K slabs); 0 when it does not apply
+size_t vqf_gemm_f32_big_ws_bytes(int ta, int tb, int M, int N, int K) {
+  if (!big_applies(ta, tb, M, N, K, 0)) return 0;
+  const int tiles = ((M + TM - 1) / TM) * ((N + TN - 1) / TN);
+  const int sp = pick_splits(tiles, K, M, N, (size_t)1 << 40);
+  return sp > 1 ? (size_t)sp * M * N * sizeof(float) : 0;
+}
+
+// 0 = this kernel does not apply (caller falls back to gemm_f32.hip), 1 = launched (rc holds the status)
+int vqf_gemm_f32_big_try(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
+                          int ldc, const float* bias, int flags, void* ws, size_t ws_bytes, hipStream_t s, int* rc) {
+  if (!big_applies(ta, tb, M, N, K, flags)) return 0;
+  BigArgs g;
+  g.A = A; g.B = B; g.C = C; g.bias = bias;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.flags = flags;
+  g.tiles_m = (M + TM - 1) / TM;
+  g.tiles_n = (N + TN - 1) / TN;
+  const int tiles = g.tiles_m * g.tiles_n;
+  int splits = pick_splits(tiles, K, M, N, (ws && aligned16(ws)) ? ws_bytes : 0);
+  const int slabs = K / TK;
+  const int per = (slabs + splits - 1) / splits;
+  g.kchunk = per * TK;
+  splits = (K + g.kchunk - 1) / g.kchunk;
+  g.splits = splits;
+  if (splits > 1) { g.C = (float*)ws; g.ldc = N; }
+  vqf_prof_dims(M, N, K);
+  if (ta) *rc = tb ? launch<true, true>(g, s) : launch<true, false>(g, s);
+  else    *rc = tb ? launch<false, true>(g, s) : launch<false, false>(g, s);
+  if (*rc == VQF_OK && splits > 1) *rc = vqf_splitk_reduce((const float*)ws, splits, M, N, C, ldc, bias, flags, s);
+  return 1;
+}

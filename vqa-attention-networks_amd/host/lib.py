@@ -30,6 +30,7 @@ c_p = ctypes.c_void_p
 SIGNATURES = {
     "vqf_abi_version": (c_i, []),
     "vqf_build_info": (ctypes.c_char_p, []),
+    "vqf_gemm_f32_ws_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i]),
     "vqf_gemm_f32": (c_i, [c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_i, c_f, c_i, c_f, c_i, c_p, c_sz, c_p]),
     "vqf_gemm_f32_batched": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, ctypes.c_longlong,
                                    c_f, c_i, ctypes.c_longlong, c_f, c_i, ctypes.c_longlong, c_i, c_p]),

@@ -91,7 +91,9 @@ def gemm(a, b, ta=False, tb=False, bias=None, relu=False, out=None, accumulate=F
             raise _l.VqfError("gemm: accumulate needs out")
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
     flags = (GEMM_RELU if relu else 0) | (GEMM_ACCUM if accumulate else 0)
-    ws = workspace(a.device, SPLITK_WS_BYTES) if splitk else None
+    ws = None
+    if splitk:
+        ws = workspace(a.device, max(SPLITK_WS_BYTES, int(_lib().vqf_gemm_f32_ws_bytes(int(ta), int(tb), M, N, K))))
     rc = _lib().vqf_gemm_f32(int(ta), int(tb), M, N, K, _ptr(a), a.stride(0), _ptr(b), b.stride(0),
                              _ptr(out), out.stride(0), _ptr(bias), flags,
                              _ptr(ws), ws.numel() if ws is not None else 0, _stream())
