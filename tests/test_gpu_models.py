@@ -269,3 +269,35 @@ def test_config3_mhbcoatt_full_batch_512_prefix_causality():
     sd = recipe_sd(O.mfb_shapes(cfg, mhb=True), case["salt"])
     ref = O.mhbcoatt_forward(sd, cfg, img[:4], q[:4])
     assert rel_err(out[:4].detach().cpu().numpy(), ref.numpy()) <= OUT_TOL
+
+
+@pytest.mark.parametrize("mhb,dtype", [(False, "fp32"), (True, "fp32"), (True, "bf16")])
+def test_training_step_is_bitwise_reproducible(mhb, dtype):
+    """No atomics on data anywhere on the path (split-K slabs, two-stage column reductions, fixed-order
+    sums in the LSTM / glimpse / loss kernels) and Philox dropout keyed by torch's CPU generator: the same
+    seed gives bit-identical logits and gradients, run after run, with dropout ACTIVE (full dims, N = 6)."""
+    import vqa_amd
+    case = dict((MHBCOATT_CASES if mhb else MFB_CASES)[-1 if mhb else -2], N=6, salt=77)
+    cfg, img, q, glove, hard, soft = mfb_inputs(case, "cuda")
+    model = (vqa_amd.MHBCoAtt if mhb else vqa_amd.MFB)(cfg)
+    model.load_state_dict({k: torch.from_numpy(recipe.weight_for(k, tuple(v.shape), case["salt"]))
+                           for k, v in model.state_dict().items()})
+    model = model.cuda().train()
+    model.gemm_dtype = dtype
+    for m in model.modules():                  # nn.Dropout after the LSTM is torch's (seeded below too)
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.1
+    crit = vqa_amd.KLDivLoss() if mhb else vqa_amd.CrossEntropyLoss()
+    runs = []
+    for _ in range(2):
+        torch.manual_seed(1234)
+        torch.cuda.manual_seed(1234)
+        model.zero_grad(set_to_none=True)
+        out = model.forward(img, q)
+        loss = crit(out, soft if mhb else hard)
+        loss.backward()
+        torch.cuda.synchronize()
+        runs.append((out.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}))
+    assert torch.equal(runs[0][0], runs[1][0])
+    for k in runs[0][1]:
+        assert torch.equal(runs[0][1][k], runs[1][1][k]), k
