@@ -132,6 +132,7 @@ def main():
     ap.add_argument("--batch", type=int, default=512, help="QA pairs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="A/B: image projection on the main stream")
+    ap.add_argument("--miopen-lstm", action="store_true", help="A/B: question-encoder LSTM on nn.LSTM (MIOpen)")
     ap.add_argument("--model", default="mfb", choices=["mfb", "mhb_coAtt", "hieCoAtten"],
                     help="mfb = the headline (BASELINE config 2/5); the others time configs 3 and 4")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
@@ -168,6 +169,8 @@ def main():
     model = model.to(dev).train()
     if args.model != "hieCoAtten":
         model.gemm_dtype = "bf16" if args.dtype == "bf16" else "fp32"
+    if args.miopen_lstm and hasattr(model, "use_hip_lstm"):
+        model.use_hip_lstm = False
     if args.no_overlap and hasattr(model, "overlap_streams"):
         model.overlap_streams = False
     reducer = parallel.GradientAllReducer(model)        # broadcasts rank 0's weights; no-op at world 1

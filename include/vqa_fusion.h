@@ -267,6 +267,17 @@ int vqf_lstm_seq_bwd(const float* dhs, const float* gates, const float* cs, cons
                      int S, int B, int H, float* dgates, float* dc_carry, int flags, void* ws, size_t ws_bytes,
                      void* stream);
 
+/* Point-wise cell stages for LARGE per-step batches (the question encoder in its regular orientation,
+ * mfb.py:68-70: T = 14 steps of an N-row batch; MHB, mhb_coAtt.py:182-183): the recurrent product is
+ * a vqf_gemm_f32 with VQF_GEMM_ACCUM into the input projection, these do the rest of a step in one pass.
+ *   fwd: gates (B,4H) pre-activations in -> ACTIVATED i,f,g,o out (in place);  c_out = f c_prev + i g;
+ *        h_out = o tanh(c_out).  c_prev = NULL at t = 0.
+ *   bwd: dh = dhs_t (+ dh_carry);  dG (B,4H) = pre-activation gradients;  dc_carry updated in place
+ *        (first != 0 at the last time step: the carry is not read).  c_prev = NULL at t = 0. */
+int vqf_lstm_cell_fwd(float* gates, const float* c_prev, int B, int H, float* c_out, float* h_out, void* stream);
+int vqf_lstm_cell_bwd(const float* dhs_t, const float* dh_carry, const float* gates, const float* c_t,
+                      const float* c_prev, int first, int B, int H, float* dc_carry, float* dG, void* stream);
+
 /* The same recursion as ONE launch for the whole sequence (csrc/lstm_persist.hip): W_hh stays in
  * registers, the H/4 workgroups hand the recurrent state to each other through HBM with
  * write-through stores + per-step arrival counters (forward: all-gather of h_s; backward:

@@ -40,6 +40,8 @@ enum VqfKernelId {
   KID_KLDIV_LOSS,
   KID_ADAM,
   KID_FEAT_TRANSPOSE,
+  KID_LSTM_CELL_FWD,
+  KID_LSTM_CELL_BWD,
   KID_COUNT
 };
 

@@ -21,7 +21,8 @@ const char* const kNames[KID_COUNT] = {
     "dropout", "tanh_dropout_fwd", "tanh_dropout_bwd", "softmax_rows_fwd", "softmax_rows_bwd",
     "gemm_bf16", "cast_f32_bf16",
     "lstm_seq_fwd(all steps)", "lstm_seq_bwd(all steps)",
-    "ce_loss", "kldiv_loss", "adam_step", "feat_transpose"};
+    "ce_loss", "kldiv_loss", "adam_step", "feat_transpose",
+    "lstm_cell_fwd", "lstm_cell_bwd"};
 
 hipEvent_t get_event() {
   std::lock_guard<std::mutex> lk(g_mu);

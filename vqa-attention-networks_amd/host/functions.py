@@ -399,3 +399,58 @@ class LstmSeqFn(torch.autograd.Function):
             dw_hh = torch.zeros_like(w_hh)
         db = ops.colsum(dg2) if ctx.has_bias else None
         return dx, dw_ih, dw_hh, db, (db.clone() if db is not None else None), None
+
+
+class LstmBatchFn(torch.autograd.Function):
+    """Single-layer LSTM over dim 0 of x (T,B,I) -> hs (T,B,H), zero initial state, for LARGE per-step
+    batches (the question encoder in its regular orientation, mfb.py:68-70: T = 14 steps of the N-row
+    minibatch).  Input projection, the T recurrent products (accumulating into the projection) and all weight
+    gradients are MFMA GEMMs; one point-wise kernel per step does the rest (vqf_lstm_cell_fwd / _bwd).
+    bf16=True (bf16 mode): the recurrent products take bf16 operands (W_hh cast once, h_t / dG_t per step),
+    fp32 accumulation; gates, cell state and every stored tensor stay fp32."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, bf16=False):
+        x = _c(x)
+        T, B, I = x.shape
+        H = w_hh.shape[1]
+        bias = (b_ih + b_hh) if b_ih is not None else None
+        ctx.bf16 = bool(bf16) and H % 8 == 0
+        whh = ops.cast_bf16(_c(w_hh)) if ctx.bf16 else _c(w_hh)
+        gates = ops.gemm(x.view(T * B, I), _c(w_ih), bias=bias).view(T, B, 4 * H)   # pre-activations -> activated in place
+        hs = torch.empty((T, B, H), dtype=torch.float32, device=x.device)
+        cs = torch.empty_like(hs)
+        for t in range(T):
+            if t > 0:                                                               # += h_{t-1} W_hh^T
+                if ctx.bf16:
+                    ops.gemm_bf16(ops.cast_bf16(hs[t - 1]), whh, out=gates[t], accumulate=True)
+                else:
+                    ops.gemm(hs[t - 1], whh, out=gates[t], accumulate=True)
+            ops.lstm_cell_fwd(gates[t], cs[t - 1] if t else None, cs[t], hs[t])
+        ctx.save_for_backward(x, w_ih, w_hh, hs, cs, gates)
+        ctx.has_bias = b_ih is not None
+        return hs
+
+    @staticmethod
+    def backward(ctx, dhs):
+        x, w_ih, w_hh, hs, cs, gates = ctx.saved_tensors
+        T, B, I = x.shape
+        H = w_hh.shape[1]
+        dhs = _c(dhs)
+        whh = ops.cast_bf16(_c(w_hh)) if ctx.bf16 else _c(w_hh)
+        dG = torch.empty_like(gates)
+        dc = torch.empty((B, H), dtype=torch.float32, device=x.device)
+        dh = None
+        for t in range(T - 1, -1, -1):
+            ops.lstm_cell_bwd(dhs[t], dh, gates[t], cs[t], cs[t - 1] if t else None, t == T - 1, dc, dG[t])
+            if t > 0:                                                               # dG_t W_hh  (B,H)
+                dh = ops.gemm_bf16(ops.cast_bf16(dG[t]), whh, tb=True) if ctx.bf16 else ops.gemm(dG[t], whh, tb=True)
+        dG2 = dG.view(T * B, 4 * H)
+        dx = ops.gemm(dG2, _c(w_ih), tb=True).view(T, B, I) if ctx.needs_input_grad[0] else None
+        dw_ih = ops.gemm(dG2, x.view(T * B, I), ta=True, tb=True)
+        if T > 1:
+            dw_hh = ops.gemm(dG[1:].reshape((T - 1) * B, 4 * H), hs[:-1].reshape((T - 1) * B, H), ta=True, tb=True)
+        else:
+            dw_hh = torch.zeros_like(w_hh)
+        db = ops.colsum(dG2) if ctx.has_bias else None
+        return dx, dw_ih, dw_hh, db, (db.clone() if db is not None else None), None

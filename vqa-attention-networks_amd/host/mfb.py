@@ -3,14 +3,15 @@
 Mirrors the reference interface (mfb.py:6-140): `MFB(cfg)`,
 `forward(img_features, questions, is_training=True) -> logits (N, a_vocab_size)`,
 identical state_dict keys/shapes, so it drops into solver.py / train_models.py.
-The question encoder (embedding, tanh, LSTM, dropout_l; mfb.py:68-70) stays on
-PyTorch-ROCm (MIOpen); everything from the question attention to the logits
-runs in libvqa_fusion.so.
+Embedding lookup, tanh and dropout_l of the question encoder (mfb.py:68-70) are
+PyTorch-ROCm element-wise ops; its LSTM recursion and everything from the question
+attention to the logits run in libvqa_fusion.so (`use_hip_lstm = False` puts the LSTM
+back on nn.LSTM / MIOpen).
 """
 import torch
 import torch.nn as nn
 
-from .functions import LinearFn, AttHeadFn, ImgFuseFn, ImgProjFn, MfbFuseFn, FinalMfbFn
+from .functions import LinearFn, AttHeadFn, ImgFuseFn, ImgProjFn, MfbFuseFn, FinalMfbFn, LstmBatchFn
 
 
 def _image_is_data(img, gemm_dtype="fp32"):
@@ -31,6 +32,20 @@ def _image_is_data(img, gemm_dtype="fp32"):
     if img.requires_grad:
         raise VqfError("img_features.requires_grad=True: the HIP fusion path treats the image tensor as "
                        "data and does not produce its gradient")
+
+
+def batch_first_lstm(lstm, x, use_hip=True, bf16=False):
+    """nn.LSTM(batch_first=True) forward of x (N,T,E) -> (N,T,H) with zero initial state (mfb.py:69).  The
+    recursion runs on the HIP path (MFMA GEMMs + one point-wise kernel per step, functions.LstmBatchFn) with
+    the nn.LSTM module's own parameters; anything it does not cover (several layers, bidirectional,
+    projections) stays on nn.LSTM."""
+    if (use_hip and x.is_cuda and lstm.num_layers == 1 and not lstm.bidirectional and lstm.proj_size == 0
+            and lstm.hidden_size % 4 == 0 and x.dtype == torch.float32):
+        hs = LstmBatchFn.apply(x.transpose(0, 1).contiguous(), lstm.weight_ih_l0, lstm.weight_hh_l0,
+                               lstm.bias_ih_l0 if lstm.bias else None, lstm.bias_hh_l0 if lstm.bias else None, bf16)
+        return hs.transpose(0, 1)
+    out, _ = lstm(x)
+    return out
 
 
 class _SideStream:
@@ -106,6 +121,8 @@ class MFB(nn.Module):
         # run img_conv1d (and, through autograd, its weight gradient) on a side stream, concurrently
         # with the question encoder / question attention (and their backward + gradient all-reduce)
         self.overlap_streams = True
+        # question encoder's LSTM recursion on the HIP path instead of nn.LSTM / MIOpen (same parameters)
+        self.use_hip_lstm = True
         # bf16 mode: one autograd node for projection + fusion, whose backward writes dP in bf16 for the
         # weight-gradient GEMM (no 2 GB fp32 round trip, no cast pass); takes precedence over the overlap
         self.fuse_bf16_dp = True
@@ -129,9 +146,9 @@ class MFB(nn.Module):
         # weight-gradient GEMM in bf16 without an fp32 round trip, which is worth more than the stream overlap
         side = self.overlap_streams and not (bf16_img and self.fuse_bf16_dp)
         proj = self._side.project(img_features, self.img_conv1d, bf16_img) if side else None
-        # a2: question encoder (PyTorch-ROCm)                                mfb.py:68-70
+        # a2: question encoder                                               mfb.py:68-70
         que_embedded = torch.tanh(self.word_embedding(questions))
-        lstm_o, _ = self.lstm(que_embedded)
+        lstm_o = batch_first_lstm(self.lstm, que_embedded, self.use_hip_lstm, self.gemm_dtype == "bf16")
         ques_feature = self.dropout_l(lstm_o).contiguous()                 # (N,T,H)
         N, T, H = ques_feature.shape
         L = img_features.shape[1]

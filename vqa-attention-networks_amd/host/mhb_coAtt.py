@@ -9,8 +9,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .functions import LinearFn, AttHeadFn, ImgFuseFn, MfbFuseFn, FinalMfbFn, LstmSeqFn
-from .mfb import _DropSeeds, _image_is_data, _SideStream
+from .functions import LinearFn, AttHeadFn, ImgFuseFn, MfbFuseFn, FinalMfbFn, LstmSeqFn, LstmBatchFn
+from .mfb import _DropSeeds, _image_is_data, _SideStream, batch_first_lstm
 
 
 class MHBCoAtt(nn.Module):
@@ -61,7 +61,7 @@ class MHBCoAtt(nn.Module):
             assert glove_matrix is not None, 'glove should not be NoneType.'
             que_embedded = torch.cat((que_embedded, glove_matrix), dim=2)
         if self.fix_lstm_orientation:
-            lstm_o, _ = self.lstm(que_embedded)                              # (N,T,H)
+            lstm_o = batch_first_lstm(self.lstm, que_embedded, self.use_hip_lstm, self.gemm_dtype == "bf16")   # (N,T,H)
             ques_feature = self.dropout_l(lstm_o).contiguous()
         elif (self.use_hip_lstm and self.lstm.num_layers == 1 and que_embedded.is_cuda
               and ops.lstm_seq_supported(que_embedded.shape[1], self.cfg.hidden_dim)):
@@ -127,6 +127,7 @@ class MHB(nn.Module):
         self.lstm_dropout = nn.Dropout(0.3)
         self.mfb_dropout = nn.Dropout(0.1)
         self.linear_out = nn.Linear(2000, cfg.a_vocab_size)
+        self.use_hip_lstm = True          # LSTM recursion on the HIP path (functions.LstmBatchFn) instead of MIOpen
         self._seeds = _DropSeeds()
 
     def set_keep_masks(self, **masks):
@@ -144,7 +145,12 @@ class MHB(nn.Module):
         _, i_sum = ops.glimpse_pool_fwd(img3, torch.zeros((batch_size * L, 1), device=img3.device), True)
         i_mean = i_sum * (1.0 / L)
         q_embedded = self.Embedding(questions).permute(1, 0, 2)              # (T,N,E)  :181-182
-        lstm_outs, _ = self.LSTM(q_embedded)                                 # (T,N,H)
+        if (self.use_hip_lstm and q_embedded.is_cuda and self.LSTM.num_layers == 1 and not self.LSTM.bidirectional
+                and self.LSTM.hidden_size % 4 == 0):
+            lstm_outs = LstmBatchFn.apply(q_embedded.contiguous(), self.LSTM.weight_ih_l0, self.LSTM.weight_hh_l0,
+                                          self.LSTM.bias_ih_l0, self.LSTM.bias_hh_l0)       # (T,N,H)
+        else:
+            lstm_outs, _ = self.LSTM(q_embedded)                             # (T,N,H)
         idx = (q_length.to(torch.long) - 1).to(lstm_outs.device)
         lstm_out = lstm_outs[idx, torch.arange(batch_size, device=lstm_outs.device)]   # :185-186
         lstm_out = self.lstm_dropout(lstm_out)

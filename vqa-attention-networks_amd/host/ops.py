@@ -377,6 +377,21 @@ def lstm_seq_bwd(dhs, gates, cs, w_hh, bf16=False):
     return dgates
 
 
+def lstm_cell_fwd(gates, c_prev, c_out, h_out):
+    """gates (B,4H) pre-activations -> activated in place; writes c_out, h_out (B,H)."""
+    _chk(gates, c_prev, c_out, h_out)
+    B, H4 = gates.shape
+    _l.check(_lib().vqf_lstm_cell_fwd(_ptr(gates), _ptr(c_prev), B, H4 // 4, _ptr(c_out), _ptr(h_out), _stream()),
+             "vqf_lstm_cell_fwd")
+
+
+def lstm_cell_bwd(dhs_t, dh_carry, gates, c_t, c_prev, first, dc_carry, dG):
+    _chk(dhs_t, dh_carry, gates, c_t, c_prev, dc_carry, dG)
+    B, H = dhs_t.shape
+    _l.check(_lib().vqf_lstm_cell_bwd(_ptr(dhs_t), _ptr(dh_carry), _ptr(gates), _ptr(c_t), _ptr(c_prev), int(bool(first)),
+                                      B, H, _ptr(dc_carry), _ptr(dG), _stream()), "vqf_lstm_cell_bwd")
+
+
 # whole-sequence ("persistent") LSTM: one launch for all steps (csrc/lstm_persist.hip)
 # module-level switch (A/B and tests): True / "both" = forward and backward, "fwd" = forward only,
 # False = the per-step kernels.  Env VQF_LSTM_PERSIST=0|fwd|both overrides the default.
