@@ -133,6 +133,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="A/B: image projection on the main stream")
     ap.add_argument("--miopen-lstm", action="store_true", help="A/B: question-encoder LSTM on nn.LSTM (MIOpen)")
+    ap.add_argument("--forward-only", action="store_true",
+                    help="BASELINE config 1 shape of work: forward pass only (eval mode, no_grad); not the headline")
     ap.add_argument("--model", default="mfb", choices=["mfb", "mhb_coAtt", "hieCoAtten"],
                     help="mfb = the headline (BASELINE config 2/5); the others time configs 3 and 4")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
@@ -171,6 +173,8 @@ def main():
         model.gemm_dtype = "bf16" if args.dtype == "bf16" else "fp32"
     if args.miopen_lstm and hasattr(model, "use_hip_lstm"):
         model.use_hip_lstm = False
+    if args.forward_only:
+        model.eval()
     if args.no_overlap and hasattr(model, "overlap_streams"):
         model.overlap_streams = False
     reducer = parallel.GradientAllReducer(model)        # broadcasts rank 0's weights; no-op at world 1
@@ -184,7 +188,14 @@ def main():
         img = ops.cast_bf16(img.view(-1, img.shape[-1])).view(img.shape)
     soft = torch.softmax(torch.randn((B, 1000), generator=torch.Generator().manual_seed(1236 + rank)), 1).to(dev)
 
+    def fwd_step():
+        with torch.no_grad():
+            out = model.forward(img, q)
+            return (out[0] if args.model == "hieCoAtten" else out).sum()
+
     def step():
+        if args.forward_only:
+            return fwd_step()
         opt.zero_grad(set_to_none=True)
         out = model.forward(img, q)
         if args.model == "hieCoAtten":
@@ -264,14 +275,17 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "QA-pairs/sec fwd+bwd, MFB-baseline batch 512" if args.model == "mfb"
-                      else "QA-pairs/sec fwd+bwd, %s batch %d" % (args.model, B),
+            "metric": ("QA-pairs/sec fwd+bwd, MFB-baseline batch 512" if (args.model == "mfb" and B == 512)
+                       else "QA-pairs/sec fwd+bwd, %s batch %d" % (args.model, B)) if not args.forward_only
+                      else "QA-pairs/sec forward only, %s batch %d" % (args.model, B),
             "value": round(value, 2), "unit": "QA-pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "MFB-baseline train step (fwd+loss+bwd+grad all-reduce+Adam), "
-                                   "batch %d per GPU, 196x2048 image grid, 14 tokens, fp32, mode=faithful"
-                                   % B if args.model == "mfb" else "%s train step, batch %d per GPU" % (args.model, B),
+            "config": {"workload": ("forward pass only (eval), " if args.forward_only else "") + (
+                                   "MFB-baseline train step (fwd+loss+bwd+grad all-reduce+Adam), "
+                                   "batch %d per GPU, 196x2048 image grid, 14 tokens, %s, mode=faithful"
+                                   % (B, "fp32" if args.dtype == "f32" else "bf16 operands / fp32 accumulate")
+                                   if args.model == "mfb" else "%s train step, batch %d per GPU, %s" % (args.model, B, args.dtype)),
                        "global_batch": B * world, "parallelism": "dp%d" % world,
                        "grad_allreduce_bytes": reducer.gradient_bytes()},
             "loss": round(float(loss.item()), 5),
