@@ -132,6 +132,10 @@ def main():
     ap.add_argument("--batch", type=int, default=512, help="QA pairs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="A/B: image projection on the main stream")
+    ap.add_argument("--overlap", action="store_true",
+                    help="two-stream step also at N=1 (default there: one stream, it is time-neutral on one GPU "
+                         "and keeps per-kernel timings clean; with N>1 the side stream is always on, it overlaps "
+                         "the weight-gradient GEMM with the gradient all-reduce)")
     ap.add_argument("--miopen-lstm", action="store_true", help="A/B: question-encoder LSTM on nn.LSTM (MIOpen)")
     ap.add_argument("--forward-only", action="store_true",
                     help="BASELINE config 1 shape of work: forward pass only (eval mode, no_grad); not the headline")
@@ -175,7 +179,7 @@ def main():
         model.use_hip_lstm = False
     if args.forward_only:
         model.eval()
-    if args.no_overlap and hasattr(model, "overlap_streams"):
+    if hasattr(model, "overlap_streams") and (args.no_overlap or (world == 1 and not args.overlap)):
         model.overlap_streams = False
     reducer = parallel.GradientAllReducer(model)        # broadcasts rank 0's weights; no-op at world 1
     # solver.py:25-29: criterion + Adam, both on the HIP path (host/train_step.py)
