@@ -233,9 +233,13 @@ int pick_splits(int tiles, int K, int M, int N, size_t ws_bytes) {
 
 template <bool TA, bool TB>
 int launch(const BigArgs& g, hipStream_t s) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_big_kernel<TA, TB>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BIG);
-  if (e != hipSuccess) return (int)e;
+  static bool attr_done = false;   // per instantiation; idempotent, a race only repeats the same call
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_big_kernel<TA, TB>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BIG);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
   VQF_LAUNCH(KID_GEMM_A0B0 + 2 * (TA ? 1 : 0) + (TB ? 1 : 0), (gemm_f32_big_kernel<TA, TB>), dim3(g.tiles_m * g.tiles_n * g.splits), dim3(NT), SMEM_BIG,
              s, g);
   return vqf_last_error();
