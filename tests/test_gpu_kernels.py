@@ -37,8 +37,8 @@ def _rel(a, b):
 
 GEMM_SHAPES = [(1, 1, 1), (5, 7, 3), (33, 65, 31), (130, 257, 70), (128, 128, 32), (256, 384, 1000),
                (100, 5000, 64), (3, 2, 4096), (300, 200, 4100),
-               # >= 64 tiles of 256x256 with ragged edges: the large-tile LDS-DMA kernel (gemm_f32_big.hip)
-               (2100, 2300, 528), (2048, 2052, 48)]
+               # >= 1024 tiles of 256x256 with ragged edges: the large-tile LDS-DMA kernel (gemm_f32_big.hip)
+               (8200, 8100, 48), (16400, 4100, 32)]
 
 
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
@@ -245,9 +245,8 @@ def test_errors_are_loud(ops):
 
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0)])
 def test_gemm_large_tile_kernel_splitk_relu_bias(ops, ta, tb):
-    """256x256-tile kernel with split-K (64 tiles, K = 8192 -> several splits through the slab reducer),
-    bias and ReLU; fp64 reference, 2e-5 (K = 8192 fp32 accumulation)."""
-    M, N, K = 2048, 2048, 8192
+    """256x256-tile kernel (1024 tiles), bias and ReLU, K = 2048; fp64 reference, 2e-5."""
+    M, N, K = 8192, 8192, 2048
     A = _rand((K, M) if ta else (M, K), 21, 0.5)
     B = _rand((K, N) if tb else (N, K), 22, 0.5)
     bias = _rand((N,), 23)

@@ -15,7 +15,7 @@
 //   * K-major operand: [k][256] floats (1 KB k-rows, a wave copy = one k-row, whole lines); fragments are
 //     ds_read_b32 (32 lanes = 128 contiguous bytes, conflict-free without a swizzle), same k mapping.
 //   * deterministic split-K for few-tile / long-K shapes (the weight gradient).
-// Preconditions (else the caller uses gemm_f32.hip): K % 16 == 0, M >= 256, N >= 128, >= 64 tiles, no
+// Preconditions (else the caller uses gemm_f32.hip): K % 16 == 0, M >= 256, N >= 128, >= 1024 tiles, no
 // accumulate flag, 16-byte aligned bases, lda/ldb % 4 == 0, a K-major operand's row extent % 4 == 0.
 #include "common.h"
 #include <stdlib.h>
@@ -257,8 +257,9 @@ bool big_applies(int ta, int tb, int M, int N, int K, int flags) {
   // both operands K-major (the weight gradients): every fragment is 4 ds_read_b32 + address math, and the
   // 128x128 kernel measured faster on img_conv1d's wgrad (15.1-15.9 vs 15.8-16.0 ms)
   if (ta && tb) return false;
-  // few output tiles: the 128x128 kernel fills the chip better
-  if (((M + TM - 1) / TM) * ((N + TN - 1) / TN) < 64) return false;
+  // Only the large projections: a workgroup that needs a whole CU's LDS starts when the CU has drained, which
+  // costs mid-size launches more than the kernel gains (HieCoAtten, 392-tile GEMMs: step 5.57 -> 5.77 ms)
+  if (((M + TM - 1) / TM) * ((N + TN - 1) / TN) < 1024) return false;
   return true;
 }
 
