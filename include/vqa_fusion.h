@@ -179,6 +179,7 @@ int vqf_glimpse_pool_bwd_bf16(const float* dpooled, const float* dwts_extra, con
  *  R    (N*L, O)    signed sqrt of the pooled sums (un-normalised)
  *  rowssq (N*L)     per-row sum of R^2 (= sum |pooled|)
  *  zdrop (N*L,5*O) or NULL: the dropped-out product itself (only MHB needs it)
+ *  O % 4 == 0 and O <= 1024 (mfb.py:42-43 hard-codes O = 1000); else VQF_E_UNSUPPORTED.
  */
 int vqf_mfb_fuse_fwd(const float* P, const float* pbias, const float* q, const float* cascade,
                      const uint8_t* keep, uint64_t seed, float p_drop,

@@ -71,55 +71,67 @@ __device__ __forceinline__ void keep_scale20(const uint8_t* __restrict__ keep, u
   }
 }
 
-// grid = N*L rows; block = 256
+// grid (N, LS); block 256.  Each block walks rows l = ls, ls+LS, ... of sample n with the sample's
+// 20 q values and the 20 projection biases of its columns held in registers (one row per block re-read
+// both for every row: 3x the load instructions); the next row's P chunk is fetched before the current
+// row is reduced.  Dropout keys on the flat element index, so the masks do not depend on this mapping.
 __global__ void __launch_bounds__(256)
 mfb_fuse_fwd_kernel(const float* __restrict__ P, const float* __restrict__ pbias,
                     const float* __restrict__ q,
                     const float* __restrict__ cascade, const uint8_t* __restrict__ keep,
-                    uint64_t seed, uint32_t thr, float inv_keep, int L, int O,
+                    uint64_t seed, uint32_t thr, float inv_keep, int L, int O, int LS,
                     float* __restrict__ R, float* __restrict__ rowssq, float* __restrict__ zdrop) {
-  __shared__ float red[4];
-  const long long row = blockIdx.x;
-  const int n = (int)(row / L);
+  __shared__ float red[2][4];
+  const int n = blockIdx.x, ls = blockIdx.y;
   const int W5 = KP * O;
   const int tid = threadIdx.x;
-  float ssq = 0.f;
-  for (int t = tid; t < O / TPT; t += 256) {
-    const long long e0 = row * W5 + (long long)CPT * t;
-    float p[CPT], qq[CPT], sc[CPT];
-    load20(P + e0, p);
-    if (pbias) {                       // projection bias folded in here (P then comes without it)
-      load20(pbias + CPT * t, qq);
+  const int nt = O / TPT;                       // active threads (250 at O = 1000); O / TPT <= 256
+  const bool act = tid < nt;
+  float qq[CPT], pb[CPT], p[CPT], pn[CPT];
 #pragma unroll
-      for (int i = 0; i < CPT; ++i) p[i] += qq[i];
-    }
-    load20(q + (long long)n * W5 + CPT * t, qq);
-    keep_scale20(keep, seed, thr, inv_keep, e0, sc);
-#pragma unroll
-    for (int i = 0; i < CPT; ++i) p[i] *= qq[i];
-    if (cascade) {
-      load20(cascade + e0, qq);
-#pragma unroll
-      for (int i = 0; i < CPT; ++i) p[i] *= qq[i];
-    }
-#pragma unroll
-    for (int i = 0; i < CPT; ++i) p[i] *= sc[i];
-    if (zdrop) store20(zdrop + e0, p);
-    f32x4 r;
-#pragma unroll
-    for (int j = 0; j < TPT; ++j) {
-      const float s = (((p[5 * j] + p[5 * j + 1]) + p[5 * j + 2]) + p[5 * j + 3]) + p[5 * j + 4];
-      const float a = fabsf(s);
-      ssq += a;                                  // (sign(s) sqrt|s|)^2 == |s|
-      const float rt = sqrtf(a);
-      r[j] = s < 0.f ? -rt : rt;                 // sqrt(relu(s)) - sqrt(relu(-s))
-    }
-    *reinterpret_cast<f32x4*>(R + row * O + TPT * t) = r;
+  for (int i = 0; i < CPT; ++i) { qq[i] = 0.f; pb[i] = 0.f; pn[i] = 0.f; }
+  if (act) {
+    load20(q + (long long)n * W5 + CPT * tid, qq);
+    if (pbias) load20(pbias + CPT * tid, pb);
+    if (ls < L) load20(P + ((long long)n * L + ls) * W5 + CPT * tid, pn);
   }
-  ssq = wave_sum(ssq);
-  if ((tid & 63) == 0) red[tid >> 6] = ssq;
-  __syncthreads();
-  if (tid == 0) rowssq[row] = (red[0] + red[1]) + (red[2] + red[3]);
+  int it = 0;
+  for (int l = ls; l < L; l += LS, ++it) {
+    const long long row = (long long)n * L + l;
+    const long long e0 = row * W5 + (long long)CPT * tid;
+    float ssq = 0.f;
+    if (act) {
+#pragma unroll
+      for (int i = 0; i < CPT; ++i) p[i] = pn[i];
+      if (l + LS < L) load20(P + (row + LS) * W5 + CPT * tid, pn);      // prefetch the next row of this block
+      float sc[CPT], cc[CPT];
+      keep_scale20(keep, seed, thr, inv_keep, e0, sc);
+#pragma unroll
+      for (int i = 0; i < CPT; ++i) p[i] = (p[i] + pb[i]) * qq[i];
+      if (cascade) {
+        load20(cascade + e0, cc);
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) p[i] *= cc[i];
+      }
+#pragma unroll
+      for (int i = 0; i < CPT; ++i) p[i] *= sc[i];
+      if (zdrop) store20(zdrop + e0, p);
+      f32x4 r;
+#pragma unroll
+      for (int j = 0; j < TPT; ++j) {
+        const float s = (((p[5 * j] + p[5 * j + 1]) + p[5 * j + 2]) + p[5 * j + 3]) + p[5 * j + 4];
+        const float a = fabsf(s);
+        ssq += a;                                  // (sign(s) sqrt|s|)^2 == |s|
+        const float rt = sqrtf(a);
+        r[j] = s < 0.f ? -rt : rt;                 // sqrt(relu(s)) - sqrt(relu(-s))
+      }
+      *reinterpret_cast<f32x4*>(R + row * O + TPT * tid) = r;
+    }
+    ssq = wave_sum(ssq);
+    if ((tid & 63) == 0) red[it & 1][tid >> 6] = ssq;
+    __syncthreads();                               // red[] is double-buffered: one barrier per row
+    if (tid == 0) rowssq[row] = (red[it & 1][0] + red[it & 1][1]) + (red[it & 1][2] + red[it & 1][3]);
+  }
 }
 
 // grid (N, LS); block 256.  Each block walks rows l = ls, ls+LS, ... of sample n.
@@ -187,6 +199,13 @@ mfb_fuse_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ dzdr
   }
 }
 
+int pick_ls_fwd(int N, int L) {
+  // forward: 8 blocks per CU worth of (sample, row-subset) pairs, at least ~8 rows per block
+  int ls = 1;
+  while ((long long)N * ls < 4096 && ls * 16 <= L) ls *= 2;
+  return ls;
+}
+
 int pick_ls(int N, int L) {
   // enough blocks to cover 256 CUs x 4, but never more splits than rows
   int ls = 1;
@@ -252,7 +271,7 @@ int vqf_mfb_fuse_fwd(const float* P, const float* pbias, const float* q, const f
                      uint64_t seed, float p_drop, int N, int L, int O, float* R, float* rowssq,
                      float* zdrop, void* stream) {
   if (!P || !q || !R || !rowssq || N <= 0 || L <= 0 || O <= 0) return VQF_E_BADARG;
-  if (O % TPT) return VQF_E_UNSUPPORTED;
+  if ((O % TPT) || O / TPT > 256) return VQF_E_UNSUPPORTED;     // one thread per 4 pooled outputs: O <= 1024 (the reference's 1000)
   if (p_drop < 0.f || p_drop >= 1.f) return VQF_E_BADARG;
   if (!aligned16(P) || (pbias && !aligned16(pbias)) || !aligned16(q) || !aligned16(R) ||
       (cascade && !aligned16(cascade)) ||
@@ -260,9 +279,9 @@ int vqf_mfb_fuse_fwd(const float* P, const float* pbias, const float* q, const f
     return VQF_E_ALIGN;
   const uint32_t thr = (keep || p_drop == 0.f) ? 0u : drop_threshold_host(p_drop);
   const float inv_keep = (keep || p_drop > 0.f) ? 1.0f / (1.0f - p_drop) : 1.0f;
-  const long long rows = (long long)N * L;
-  VQF_LAUNCH(KID_MFB_FUSE_FWD, mfb_fuse_fwd_kernel, dim3((unsigned)rows), dim3(256), 0,
-             (hipStream_t)stream, P, pbias, q, cascade, keep, seed, thr, inv_keep, L, O, R, rowssq, zdrop);
+  const int LS = pick_ls_fwd(N, L);
+  VQF_LAUNCH(KID_MFB_FUSE_FWD, mfb_fuse_fwd_kernel, dim3(N, LS), dim3(256), 0,
+             (hipStream_t)stream, P, pbias, q, cascade, keep, seed, thr, inv_keep, L, O, LS, R, rowssq, zdrop);
   return vqf_last_error();
 }
 
