@@ -248,7 +248,7 @@ def main():
                 traffic, traffic_note = pmc["traffic_bytes"], pmc["note"] + "; " + pmc["formula"]
         except Exception:
             pass
-        roofline = {"bound": "mfma", "kernel": "gemm_f32_a0b0 img_conv1d forward (M=%d,N=%d,K=%d)" % (M, N, K),
+        roofline = {"bound": "mfma", "kernel": "img_conv1d forward GEMM (M=%d,N=%d,K=%d; gemm_f32_big.hip, 256x256 tiles; profiler id gemm_f32_a0b0)" % (M, N, K),
                     "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                     "traffic_note": traffic_note,
