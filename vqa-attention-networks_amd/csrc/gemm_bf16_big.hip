@@ -25,7 +25,10 @@
 //   * deterministic split-K (fixed-order slab reduction, vqf_splitk_reduce) when the tile count alone
 //     cannot fill the chip (the weight gradient: 20 x 8 tiles, K = 100352).
 // Measured on the image projection (M=100352, N=5000, K=2048, random operands): 675 -> 876 TFLOP/s
-// (s_setprio(1) around the MFMA blocks: 860; the weight gradient 887 -> 780: not used).
+// (s_setprio(1) around the MFMA blocks: 860; the weight gradient 887 -> 780: not used.  Two wave groups one
+// phase apart -- waves 0-3 read slab s while waves 4-7 multiply slab s-1, two raw barriers per slab -- 859 / 746:
+// not used either.  LDS moves 96 KB of fragment reads + 32 KB of DMA writes per slab and CU = 1024 clk at
+// 128 B/clk, exactly the 1024 MFMA cycles a SIMD spends on a slab: the kernel sits on the LDS roofline.)
 // By ablation the 2.35 ms are 1.09 ms of MFMA work at the ~1.8 GHz the chip sustains here, +0.43 ms
 // fragment-read stalls, +0.50 ms copy issue / barriers, +0.34 ms for the exposed fp32 epilogue (one
 // workgroup per CU).
