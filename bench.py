@@ -137,6 +137,9 @@ def main():
                          "and keeps per-kernel timings clean; with N>1 the side stream is always on, it overlaps "
                          "the weight-gradient GEMM with the gradient all-reduce)")
     ap.add_argument("--miopen-lstm", action="store_true", help="A/B: question-encoder LSTM on nn.LSTM (MIOpen)")
+    ap.add_argument("--pruned", action="store_true",
+                    help="MFB.pruned: skip the work that is provably dead under the reference's singleton-axis softmaxes "
+                         "(bit-identical results).  NOT the headline: the default executes everything the reference does")
     ap.add_argument("--forward-only", action="store_true",
                     help="BASELINE config 1 shape of work: forward pass only (eval mode, no_grad); not the headline")
     ap.add_argument("--model", default="mfb", choices=["mfb", "mhb_coAtt", "hieCoAtten"],
@@ -177,6 +180,8 @@ def main():
         model.gemm_dtype = "bf16" if args.dtype == "bf16" else "fp32"
     if args.miopen_lstm and hasattr(model, "use_hip_lstm"):
         model.use_hip_lstm = False
+    if args.pruned and hasattr(model, "pruned"):
+        model.pruned = True
     if args.forward_only:
         model.eval()
     if hasattr(model, "overlap_streams") and (args.no_overlap or (world == 1 and not args.overlap)):
@@ -287,8 +292,9 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": ("forward pass only (eval), " if args.forward_only else "") + (
                                    "MFB-baseline train step (fwd+loss+bwd+grad all-reduce+Adam), "
-                                   "batch %d per GPU, 196x2048 image grid, 14 tokens, %s, mode=faithful"
-                                   % (B, "fp32" if args.dtype == "f32" else "bf16 operands / fp32 accumulate")
+                                   "batch %d per GPU, 196x2048 image grid, 14 tokens, %s, mode=%s"
+                                   % (B, "fp32" if args.dtype == "f32" else "bf16 operands / fp32 accumulate",
+                                      "pruned (NOT the headline: provably dead work skipped)" if args.pruned else "faithful")
                                    if args.model == "mfb" else "%s train step, batch %d per GPU, %s" % (args.model, B, args.dtype)),
                        "global_batch": B * world, "parallelism": "dp%d" % world,
                        "grad_allreduce_bytes": reducer.gradient_bytes()},

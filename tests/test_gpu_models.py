@@ -301,3 +301,33 @@ def test_training_step_is_bitwise_reproducible(mhb, dtype):
     assert torch.equal(runs[0][0], runs[1][0])
     for k in runs[0][1]:
         assert torch.equal(runs[0][1][k], runs[1][1][k]), k
+
+
+@pytest.mark.parametrize("multilayer", [False, True])
+def test_pruned_mode_is_bit_identical_to_faithful(multilayer):
+    """MFB.pruned skips the provably dead work under the singleton-axis softmaxes (mfb.py:84,118): logits and
+    every gradient must be BIT-identical to the faithful execution, the 12 (16) dead tensors exactly zero --
+    with dropout active and the same seed (the regions' dropout draw is still consumed)."""
+    import vqa_amd
+    case = dict(MFB_CASES[-1 if multilayer else -2], N=5, salt=55)
+    cfg, img, q, glove, hard, soft = mfb_inputs(case, "cuda")
+    model = vqa_amd.MFB(cfg)
+    model.load_state_dict({k: torch.from_numpy(recipe.weight_for(k, tuple(v.shape), case["salt"]))
+                           for k, v in model.state_dict().items()})
+    model = model.cuda().train()
+    model.dropout_l.p = 0.0                     # torch's own dropout would draw differently placed randoms
+    res = {}
+    for pruned in (False, True):
+        model.pruned = pruned
+        torch.manual_seed(99)
+        model.zero_grad(set_to_none=True)
+        out = model.forward(img, q)
+        torch.nn.CrossEntropyLoss()(out, hard).backward()
+        res[pruned] = (out.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters()})
+    assert torch.equal(res[True][0], res[False][0])
+    dead = ("ques_att_conv", "ques_att_multiconv", "ques_proj1", "img_conv1d", "co_att_conv", "co_att_multiconv")
+    for k, g in res[False][1].items():
+        assert torch.equal(res[True][1][k], g), k
+        if k.startswith(dead):
+            assert float(g.abs().max()) == 0.0, k
+    assert any(float(g.abs().max()) > 0 for k, g in res[True][1].items() if not k.startswith(dead))

@@ -454,3 +454,39 @@ class LstmBatchFn(torch.autograd.Function):
             dw_hh = torch.zeros_like(w_hh)
         db = ops.colsum(dG2) if ctx.has_bias else None
         return dx, dw_ih, dw_hh, db, (db.clone() if db is not None else None), None
+
+
+class UnitPoolFn(torch.autograd.Function):
+    """pooled[n, g*C + c] = sum_s feat[n, s, c] for g < G: the glimpse sums under mfb.py:84,118's
+    singleton-axis softmax (weights == 1), without the attention MLP in front (MFB's `pruned` mode)."""
+
+    @staticmethod
+    def forward(ctx, feat, G):
+        feat = _c(feat)
+        N, S, C = feat.shape
+        logits = torch.zeros((N * S, G), dtype=torch.float32, device=feat.device)     # ignored under unit weights
+        wts, pooled = ops.glimpse_pool_fwd(feat, logits, True)
+        ctx.save_for_backward(feat, wts)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        feat, wts = ctx.saved_tensors
+        if not ctx.needs_input_grad[0]:
+            return None, None
+        _, dfeat = ops.glimpse_pool_bwd(_c(dpooled), feat, wts, True, True)
+        return dfeat, None
+
+
+class DeadParamsFn(torch.autograd.Function):
+    """Identity on `out` that hands EXACT-ZERO gradients to parameters whose contribution is provably
+    dead (what the reference's autograd computes for them, the long way round)."""
+
+    @staticmethod
+    def forward(ctx, out, *params):
+        ctx.meta = [(p.shape, p.dtype, p.device) for p in params]
+        return out.view_as(out)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g,) + tuple(torch.zeros(sh, dtype=dt, device=dv) for sh, dt, dv in ctx.meta)

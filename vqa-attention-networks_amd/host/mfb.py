@@ -11,7 +11,8 @@ back on nn.LSTM / MIOpen).
 import torch
 import torch.nn as nn
 
-from .functions import LinearFn, AttHeadFn, ImgFuseFn, ImgProjFn, MfbFuseFn, FinalMfbFn, LstmBatchFn
+from .functions import (LinearFn, AttHeadFn, ImgFuseFn, ImgProjFn, MfbFuseFn, FinalMfbFn, LstmBatchFn, UnitPoolFn,
+                        DeadParamsFn)
 
 
 def _image_is_data(img, gemm_dtype="fp32"):
@@ -115,6 +116,12 @@ class MFB(nn.Module):
         self.linear_pred = nn.Linear(1000, cfg.a_vocab_size)
         # reference_compat: mfb.py:84,118 run both softmaxes over a singleton axis (weights == 1)
         self.unit_softmax = True
+        # Execution mode under unit_softmax.  False ("faithful", default and the benchmarked one): every op
+        # the reference's autograd executes is executed.  True ("pruned"): with attention weights == 1 the
+        # glimpses are plain sums, so both attention MLPs, ques_proj1, img_conv1d and the fusion over the
+        # regions cannot influence the logits and their 12 parameter tensors get exactly-zero gradients;
+        # the pruned mode skips that work (96 % of the FLOPs) and returns bit-identical logits and gradients.
+        self.pruned = False
         # "fp32" (default, parity 1e-4) or "bf16": bf16 operands / fp32 accumulate for the two large
         # GEMM families (img_conv1d and co_att_conv1, 96 % of the FLOPs); everything else stays fp32
         self.gemm_dtype = "fp32"
@@ -138,13 +145,31 @@ class MFB(nn.Module):
         """Test hook: explicit uint8 keep-masks 'm1' (N*L,5000), 'm2' (N,5000) instead of Philox."""
         self._seeds.keep = masks
 
+    def _forward_pruned(self, img_features, ques_feature, keep):
+        """The live part of the reference graph when both softmaxes are over a singleton axis."""
+        pm = self.dropout_m.p
+        qa = UnitPoolFn.apply(ques_feature, 2)                             # (N, 2H)   mfb.py:85-89 with weights 1
+        self._seeds.next(self.training, pm)                                # the regions' dropout draw (unused, keeps the stream)
+        va = UnitPoolFn.apply(img_features, 2)                             # (N, 2D)   mfb.py:119-123 with weights 1
+        seed, p = self._seeds.next(self.training, pm)
+        k2 = keep.get('m2')
+        y = FinalMfbFn.apply(qa, va, self.ques_proj2.weight, self.ques_proj2.bias,
+                             self.img_proj2.weight, self.img_proj2.bias, k2, seed, pm if k2 is not None else p)
+        out = LinearFn.apply(y, self.linear_pred.weight, self.linear_pred.bias)
+        dead = [self.ques_att_conv1, self.ques_att_conv2, self.ques_proj1, self.img_conv1d, self.co_att_conv1,
+                self.co_att_conv2]
+        if self.multilayer:
+            dead += [self.ques_att_multiconv, self.co_att_multiconv]
+        params = [t for m in dead for t in (m.weight, m.bias) if t.requires_grad]
+        return DeadParamsFn.apply(out, *params) if params and torch.is_grad_enabled() else out
+
     def forward(self, img_features, questions, is_training=True):
         _image_is_data(img_features, self.gemm_dtype)
         bf16_img = self.gemm_dtype in ("bf16", "bf16-img")
         # a5 starts first, on the side stream: it only needs the image and its weights
         # bf16 mode keeps projection + fusion in one autograd node (ImgFuseFn): its backward hands dP to the
         # weight-gradient GEMM in bf16 without an fp32 round trip, which is worth more than the stream overlap
-        side = self.overlap_streams and not (bf16_img and self.fuse_bf16_dp)
+        side = self.overlap_streams and not (bf16_img and self.fuse_bf16_dp) and not (self.pruned and self.unit_softmax)
         proj = self._side.project(img_features, self.img_conv1d, bf16_img) if side else None
         # a2: question encoder                                               mfb.py:68-70
         que_embedded = torch.tanh(self.word_embedding(questions))
@@ -153,6 +178,8 @@ class MFB(nn.Module):
         N, T, H = ques_feature.shape
         L = img_features.shape[1]
         keep = self._seeds.keep
+        if self.pruned and self.unit_softmax:
+            return self._forward_pruned(img_features, ques_feature, keep)
 
         # a3: question attention                                             mfb.py:73-89
         wm, bm = self._mc('ques_att_multiconv')
