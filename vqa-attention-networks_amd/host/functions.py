@@ -394,7 +394,11 @@ class LstmSeqFn(torch.autograd.Function):
         dx = ops.gemm(dg2, _c(w_ih), tb=True).view(S, B, I) if ctx.needs_input_grad[0] else None
         dw_ih = ops.gemm(dg2, x.view(S * B, I), ta=True, tb=True)
         if S > 1:
-            dw_hh = ops.gemm(dg[1:].reshape((S - 1) * B, 4 * H), hs[:-1].reshape((S - 1) * B, H), ta=True, tb=True)
+            if ctx.bf16 and H % 8 == 0:      # bf16 mode: the 60-GFLOP recurrent weight gradient takes bf16 operands too
+                dw_hh = ops.gemm_bf16(ops.cast_bf16(dg[1:].reshape((S - 1) * B, 4 * H)),
+                                      ops.cast_bf16(hs[:-1].reshape((S - 1) * B, H)), ta=True, tb=True)
+            else:
+                dw_hh = ops.gemm(dg[1:].reshape((S - 1) * B, 4 * H), hs[:-1].reshape((S - 1) * B, H), ta=True, tb=True)
         else:
             dw_hh = torch.zeros_like(w_hh)
         db = ops.colsum(dg2) if ctx.has_bias else None
