@@ -4,6 +4,10 @@ Projections, attention pooling and dropout run in libvqa_fusion.so; embedding lo
 BatchNorm1d, ReLU/add glue and the cat/view reshapes stay torch ops (they are not part of the
 fusion arithmetic).  Functional dropout is always on in the reference (networks.py:22,24,55,57);
 `drop_p` is its rate here.
+
+Parameter names (and therefore state_dict keys) are the reference's:
+  iBOWIMG       img_emb.*, img_bn.*, que_emb.weight, fc.*
+  AttentionNet  img_emb.*, que_emb.weight, att{0..att_num-1}.att_layer.fc.*, fc.*, batchnorm.*
 """
 import torch
 import torch.nn as nn
@@ -13,69 +17,87 @@ from .modules import Attention_layer
 from .mfb import _DropSeeds
 
 
+def _linear(layer, x, relu=False):
+    """nn.Linear parameters, HIP GEMM (+ fused ReLU)."""
+    return LinearFn.apply(x, layer.weight, layer.bias, relu)
+
+
 class _AlwaysDropout:
+    """F.dropout(x) with training left at its default True: active in eval() too (reference behaviour).
+    Masks come from the in-kernel Philox stream; tests may inject explicit keep-masks by tag."""
+
+    drop_p = 0.5
+
+    def _init_dropout(self):
+        self._seeds = _DropSeeds()
+
     def _drop(self, x, tag):
-        k = self._seeds.keep.get(tag)
-        if k is None and self.drop_p <= 0.0:
+        explicit = self._seeds.keep.get(tag)
+        if explicit is None and self.drop_p <= 0.0:
             return x
-        seed, p = self._seeds.next(True, self.drop_p)
-        return DropoutFn.apply(x, k, seed, self.drop_p if k is not None else p)
+        seed, rate = self._seeds.next(True, self.drop_p)
+        return DropoutFn.apply(x, explicit, seed, self.drop_p if explicit is not None else rate)
+
+    def _drop_tokens(self, emb, tag):
+        """dropout over a (N, T, E) embedding, applied on its flat (N*T, E) view."""
+        n, t, e = emb.shape
+        return self._drop(emb.reshape(n * t, e), tag).view(n, t, e)
 
     def set_keep_masks(self, **masks):
         self._seeds.keep = masks
 
 
 class iBOWIMG(nn.Module, _AlwaysDropout):
+    """Bag-of-words baseline (networks.py:7-28): BN(ReLU-less Linear(img)) -> ReLU -> dropout, summed word
+    embeddings -> dropout, concat, Linear."""
+
     def __init__(self, img_size, vocab_size, embed_size, output_size):
-        super(iBOWIMG, self).__init__()
-        self.img_emb = nn.Linear(img_size, embed_size, bias=True)
-        self.img_bn = nn.BatchNorm1d(embed_size)
-        self.que_emb = nn.Embedding(vocab_size, embed_size)
-        self.fc = nn.Linear(2 * embed_size, output_size)
-        self.drop_p = 0.5
-        self._seeds = _DropSeeds()
+        nn.Module.__init__(self)
+        self._init_dropout()
+        self.img_emb = nn.Linear(img_size, embed_size, bias=True)        # networks.py:10
+        self.img_bn = nn.BatchNorm1d(embed_size)                         # :11
+        self.que_emb = nn.Embedding(vocab_size, embed_size)              # :12
+        self.fc = nn.Linear(embed_size * 2, output_size)                 # :13
 
     def forward(self, img_features, que_features):
-        img = self.img_bn(LinearFn.apply(img_features, self.img_emb.weight, self.img_emb.bias))
-        img = self._drop(torch.relu(img), 'img')
-        que = self.que_emb(que_features)
-        N, T, E = que.shape
-        que = self._drop(que.reshape(N * T, E), 'que').view(N, T, E)
-        que = torch.sum(que, 1)
-        x = torch.cat((img, que), 1)
-        return LinearFn.apply(x, self.fc.weight, self.fc.bias)
+        image = torch.relu(self.img_bn(_linear(self.img_emb, img_features)))      # :17-21
+        image = self._drop(image, 'img')                                          # :22
+        words = self._drop_tokens(self.que_emb(que_features), 'que')              # :23-24
+        bag = words.sum(dim=1)                                                    # :25
+        return _linear(self.fc, torch.cat((image, bag), dim=1))                   # :26-28
 
 
 class AttentionNet(nn.Module, _AlwaysDropout):
+    """att_num alternating Attention_layer(type 1) blocks over (image regions, question tokens), then the
+    reference's cat(.., 0).view(N, -1) of the last two attention maps (it pairs rows ACROSS samples,
+    networks.py:64-65 -- reproduced), Linear and BatchNorm1d."""
+
     def __init__(self, block_num=196, word_num=22, img_size=1024, vocab_size=15881, embed_size=512,
                  att_num=6, output_size=3000):
-        super(AttentionNet, self).__init__()
-        self.img_emb = nn.Linear(img_size, embed_size, bias=True)
-        self.que_emb = nn.Embedding(vocab_size, embed_size)
-        for i in range(att_num):
-            self.add_module("att{}".format(i), Attention_layer(embed_size, 1))   # both branches use type 1 (:37-41)
-        self.fc = nn.Linear(2 * block_num * word_num, output_size)
-        self.batchnorm = nn.BatchNorm1d(output_size)
+        nn.Module.__init__(self)
+        self._init_dropout()
         self.att_num = att_num
-        self.drop_p = 0.5
-        self._seeds = _DropSeeds()
+        self.img_emb = nn.Linear(img_size, embed_size, bias=True)        # networks.py:34
+        self.que_emb = nn.Embedding(vocab_size, embed_size)              # :35
+        for idx in range(att_num):                                       # :36-41: both branches build type 1
+            self.add_module("att%d" % idx, Attention_layer(embed_size, 1))
+        self.fc = nn.Linear(block_num * word_num * 2, output_size)       # :42
+        self.batchnorm = nn.BatchNorm1d(output_size)                     # :43
+
+    def _block(self, idx):
+        return self._modules["att%d" % idx]
 
     def forward(self, img_features, que_features):
-        N, L, D = img_features.shape
-        img = LinearFn.apply(img_features.reshape(N * L, D), self.img_emb.weight, self.img_emb.bias, True)
-        E = img.shape[1]
-        img = self._drop(img, 'img').view(N, L, E)                                # :54-55
-        que = self.que_emb(que_features)                                          # :56
-        T = que.shape[1]
-        que = self._drop(que.reshape(N * T, E), 'que').view(N, T, E)              # :57
+        n, regions, channels = img_features.shape
+        image = _linear(self.img_emb, img_features.reshape(n * regions, channels), relu=True)   # :51-54
+        image = self._drop(image, 'img').view(n, regions, -1)                                   # :55
+        words = self._drop_tokens(self.que_emb(que_features), 'que')                            # :56-57
         que_att = img_att = None
-        for i in range(self.att_num):                                             # :58-62
-            if i % 2 == 0:
-                img, que, que_att = self._modules['att{}'.format(i)](img, que)
+        for idx in range(self.att_num):                                                         # :58-62
+            if idx % 2 == 0:
+                image, words, que_att = self._block(idx)(image, words)
             else:
-                que, img, img_att = self._modules['att{}'.format(i)](que, img)
-        x = torch.cat((que_att, img_att.transpose(1, 2)), 0)                      # :64
-        x = x.reshape(N, -1)                                                      # :65
-        x = LinearFn.apply(x, self.fc.weight, self.fc.bias)                       # :66
-        x = self.batchnorm(x)                                                     # :68
-        return x, que_att, img_att
+                words, image, img_att = self._block(idx)(words, image)
+        mixed = torch.cat((que_att, img_att.transpose(1, 2)), 0).reshape(n, -1)                 # :64-65
+        out = self.batchnorm(_linear(self.fc, mixed))                                           # :66-68
+        return out, que_att, img_att
