@@ -47,6 +47,8 @@ extern "C" {
 /* GEMM epilogue flags */
 #define VQF_GEMM_RELU 1        /* C = max(C, 0)                              */
 #define VQF_GEMM_ACCUM 2       /* C += result (dgrad accumulation)           */
+#define VQF_GEMM_OUT_BF16 4    /* vqf_gemm_bf16 only: C points to bf16 storage (ldc in elements), result rounded
+                                  to nearest even; VQF_E_UNSUPPORTED unless the 256x256-tile kernel applies */
 
 /* ABI version and build information ("gfx950;fp32-mfma-32x32x2;...") */
 int vqf_abi_version(void);
@@ -226,6 +228,15 @@ int vqf_mfb_fuse_bwd_bf16dp(const float* dY, const float* Y, const float* inv, c
                             const float* coefB, const float* P, const float* pbias, const float* q,
                             const uint8_t* keep, uint64_t seed, float p_drop, int N, int L, int O,
                             void* dP_bf16, float* dq, float* dbiasP, void* ws, size_t ws_bytes, void* stream);
+/* The image fusion with the projection itself stored in bf16 (P written by vqf_gemm_bf16 with
+ * VQF_GEMM_OUT_BF16: half the bytes of the largest tensor of the step in all three passes over it). */
+int vqf_mfb_fuse_fwd_pbf16(const void* P_bf16, const float* pbias, const float* q, const uint8_t* keep, uint64_t seed,
+                           float p_drop, int N, int L, int O, float* R, float* rowssq, void* stream);
+int vqf_mfb_fuse_bwd_pbf16(const float* dY, const float* Y, const float* inv, const float* coefA,
+                           const float* coefB, const void* P_bf16, const float* pbias, const float* q,
+                           const uint8_t* keep, uint64_t seed, float p_drop, int N, int L, int O, void* dP_bf16,
+                           float* dq, float* dbiasP, void* ws, size_t ws_bytes, void* stream);
+
 
 
 /* --------------------------------------------------------------------------

@@ -195,3 +195,29 @@ def test_mhb_mean_pool_accepts_bf16_features():
         a = m.forward(img, q, ql)
         b = m.forward(img.float(), q, ql)
     assert torch.equal(a, b)
+
+
+def test_bf16_projection_storage_is_exact_rounding_and_fuse_kernels_agree(ops):
+    """VQF_GEMM_OUT_BF16: the large-tile kernel's bf16 output is the rounding of its fp32 result (within one bf16 ulp of
+    the fp32-output launch, which may use split-K and therefore another summation order; > 99 % bit-identical to its
+    RNE); the fusion kernels fed the bf16 P give bit-identical results to the fp32-P kernels fed the same values."""
+    N, L, O = 8, 196, 1000
+    M, K = N * L, 2048
+    X = _r((M, K), 31).to(torch.bfloat16).cuda()
+    W = (_r((5 * O, K), 32) * 0.05).to(torch.bfloat16).cuda()
+    bias = _r((5 * O,), 33).cuda()
+    Pf = ops.gemm_bf16(X, W, bias=bias)
+    Pb = ops.gemm_bf16(X, W, bias=bias, out_bf16=True)
+    assert Pb is not None and Pb.dtype == torch.bfloat16          # 7 x 20 tiles of 256x256 >= 64: the large-tile kernel
+    assert bool(((Pb.float() - Pf).abs() <= Pf.abs() * 2.0 ** -8 + 1e-6).all())
+    assert float((Pb.view(torch.int16) == Pf.to(torch.bfloat16).view(torch.int16)).float().mean()) > 0.99
+    assert ops.gemm_bf16(X[:300], W, bias=bias, out_bf16=True) is None       # too few tiles: caller falls back
+    q = _r((N, 5 * O), 34).cuda()
+    Pr = Pb.float()
+    Yb, nb, ib, _ = ops.mfb_fuse_fwd(Pb, q, N, L, O, seed=77, p_drop=0.1)
+    Yf, nf, i_f, _ = ops.mfb_fuse_fwd(Pr, q, N, L, O, seed=77, p_drop=0.1)
+    assert torch.equal(Yb, Yf) and torch.equal(nb, nf)
+    dY = _r((N * L, O), 35).cuda()
+    dPb, dqb, _, dbb = ops.mfb_fuse_bwd(dY, Yb, nb, ib, Pb, q, N, L, O, seed=77, p_drop=0.1, want_dbias=True, dp_bf16=True)
+    dPf, dqf, _, dbf = ops.mfb_fuse_bwd(dY, Yf, nf, i_f, Pr, q, N, L, O, seed=77, p_drop=0.1, want_dbias=True, dp_bf16=True)
+    assert torch.equal(dPb.view(torch.int16), dPf.view(torch.int16)) and torch.equal(dqb, dqf) and torch.equal(dbb, dbf)

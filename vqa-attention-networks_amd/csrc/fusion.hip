@@ -27,6 +27,15 @@ __device__ __forceinline__ void load20(const float* __restrict__ p, float (&v)[C
     v[4 * i] = x[0]; v[4 * i + 1] = x[1]; v[4 * i + 2] = x[2]; v[4 * i + 3] = x[3];
   }
 }
+// 20 bf16 (40 bytes, 8-byte aligned) -> 20 floats
+__device__ __forceinline__ void load20(const __bf16* __restrict__ p, float (&v)[CPT]) {
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const uint2 x = *reinterpret_cast<const uint2*>(p + 4 * i);
+    v[4 * i] = __uint_as_float(x.x << 16); v[4 * i + 1] = __uint_as_float(x.x & 0xffff0000u);
+    v[4 * i + 2] = __uint_as_float(x.y << 16); v[4 * i + 3] = __uint_as_float(x.y & 0xffff0000u);
+  }
+}
 __device__ __forceinline__ void store20(float* __restrict__ p, const float (&v)[CPT]) {
 #pragma unroll
   for (int i = 0; i < 5; ++i) {
@@ -75,8 +84,9 @@ __device__ __forceinline__ void keep_scale20(const uint8_t* __restrict__ keep, u
 // 20 q values and the 20 projection biases of its columns held in registers (one row per block re-read
 // both for every row: 3x the load instructions); the next row's P chunk is fetched before the current
 // row is reduced.  Dropout keys on the flat element index, so the masks do not depend on this mapping.
+template <typename PT>
 __global__ void __launch_bounds__(256)
-mfb_fuse_fwd_kernel(const float* __restrict__ P, const float* __restrict__ pbias,
+mfb_fuse_fwd_kernel(const PT* __restrict__ P, const float* __restrict__ pbias,
                     const float* __restrict__ q,
                     const float* __restrict__ cascade, const uint8_t* __restrict__ keep,
                     uint64_t seed, uint32_t thr, float inv_keep, int L, int O, int LS,
@@ -135,12 +145,12 @@ mfb_fuse_fwd_kernel(const float* __restrict__ P, const float* __restrict__ pbias
 }
 
 // grid (N, LS); block 256.  Each block walks rows l = ls, ls+LS, ... of sample n.
-template <bool CASC, bool DBIAS, typename DPT>
+template <bool CASC, bool DBIAS, typename DPT, typename PT>
 __global__ void __launch_bounds__(256)
 mfb_fuse_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ dzdrop,
                     const float* __restrict__ Y,
                     const float* __restrict__ inv, const float* __restrict__ coefA,
-                    const float* __restrict__ coefB, const float* __restrict__ P,
+                    const float* __restrict__ coefB, const PT* __restrict__ P,
                     const float* __restrict__ pbias,
                     const float* __restrict__ q, const float* __restrict__ cascade,
                     const uint8_t* __restrict__ keep, uint64_t seed, uint32_t thr, float inv_keep,
@@ -217,7 +227,7 @@ int pick_ls(int N, int L) {
 
 static int fuse_bwd_impl(const float* dY, const float* dzdrop, const float* Y, const float* inv,
                      const float* coefA,
-                     const float* coefB, const float* P, const float* pbias, const float* q,
+                     const float* coefB, const void* P, int p_bf16, const float* pbias, const float* q,
                      const float* cascade,
                      const uint8_t* keep, uint64_t seed, float p_drop, int N, int L, int O,
                      void* dP, int dp_bf16, float* dq, float* dcascade, float* dbiasP, void* ws,
@@ -227,6 +237,7 @@ static int fuse_bwd_impl(const float* dY, const float* dzdrop, const float* Y, c
   if (O % TPT) return VQF_E_UNSUPPORTED;
   if ((cascade != nullptr) != (dcascade != nullptr)) return VQF_E_BADARG;
   if (dp_bf16 && cascade) return VQF_E_UNSUPPORTED;
+  if (p_bf16 && !dp_bf16) return VQF_E_UNSUPPORTED;          // bf16 P only in the all-bf16 image fusion
   if (p_drop < 0.f || p_drop >= 1.f) return VQF_E_BADARG;
   if (!aligned16(dY) || (dzdrop && !aligned16(dzdrop)) || (pbias && !aligned16(pbias)) || !aligned16(Y) || !aligned16(P) || !aligned16(q) || !aligned16(dP) ||
       !aligned16(dq) || (cascade && (!aligned16(cascade) || !aligned16(dcascade))) ||
@@ -244,13 +255,14 @@ static int fuse_bwd_impl(const float* dY, const float* dzdrop, const float* Y, c
   const float inv_keep = (keep || p_drop > 0.f) ? 1.0f / (1.0f - p_drop) : 1.0f;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(N, LS);
-#define VQF_BWD(C_, D_, T_)                                                                    \
-  VQF_LAUNCH(KID_MFB_FUSE_BWD, (mfb_fuse_bwd_kernel<C_, D_, T_>), grid, dim3(256), 0, s, dY, dzdrop, Y, inv, \
-             coefA, coefB, P, pbias, q, cascade, keep, seed, thr, inv_keep, L, O, LS, (T_*)dP, dq_part, \
+#define VQF_BWD(C_, D_, T_, PT_)                                                               \
+  VQF_LAUNCH(KID_MFB_FUSE_BWD, (mfb_fuse_bwd_kernel<C_, D_, T_, PT_>), grid, dim3(256), 0, s, dY, dzdrop, Y, inv, \
+             coefA, coefB, (const PT_*)P, pbias, q, cascade, keep, seed, thr, inv_keep, L, O, LS, (T_*)dP, dq_part, \
              dcascade, db_part)
-  if (dp_bf16)      { if (dbiasP) VQF_BWD(false, true, __bf16); else VQF_BWD(false, false, __bf16); }
-  else if (cascade) { if (dbiasP) VQF_BWD(true, true, float); else VQF_BWD(true, false, float); }
-  else              { if (dbiasP) VQF_BWD(false, true, float); else VQF_BWD(false, false, float); }
+  if (p_bf16)       { if (dbiasP) VQF_BWD(false, true, __bf16, __bf16); else VQF_BWD(false, false, __bf16, __bf16); }
+  else if (dp_bf16) { if (dbiasP) VQF_BWD(false, true, __bf16, float); else VQF_BWD(false, false, __bf16, float); }
+  else if (cascade) { if (dbiasP) VQF_BWD(true, true, float, float); else VQF_BWD(true, false, float, float); }
+  else              { if (dbiasP) VQF_BWD(false, true, float, float); else VQF_BWD(false, false, float, float); }
 #undef VQF_BWD
   int rc = vqf_last_error();
   if (rc) return rc;
@@ -264,12 +276,10 @@ static int fuse_bwd_impl(const float* dY, const float* dzdrop, const float* Y, c
 }
 
 
-extern "C" {
 
-int vqf_mfb_fuse_fwd(const float* P, const float* pbias, const float* q, const float* cascade,
-                     const uint8_t* keep,
-                     uint64_t seed, float p_drop, int N, int L, int O, float* R, float* rowssq,
-                     float* zdrop, void* stream) {
+static int fuse_fwd_impl(const void* P, int p_bf16, const float* pbias, const float* q, const float* cascade,
+                         const uint8_t* keep, uint64_t seed, float p_drop, int N, int L, int O, float* R,
+                         float* rowssq, float* zdrop, void* stream) {
   if (!P || !q || !R || !rowssq || N <= 0 || L <= 0 || O <= 0) return VQF_E_BADARG;
   if ((O % TPT) || O / TPT > 256) return VQF_E_UNSUPPORTED;     // one thread per 4 pooled outputs: O <= 1024 (the reference's 1000)
   if (p_drop < 0.f || p_drop >= 1.f) return VQF_E_BADARG;
@@ -280,9 +290,27 @@ int vqf_mfb_fuse_fwd(const float* P, const float* pbias, const float* q, const f
   const uint32_t thr = (keep || p_drop == 0.f) ? 0u : drop_threshold_host(p_drop);
   const float inv_keep = (keep || p_drop > 0.f) ? 1.0f / (1.0f - p_drop) : 1.0f;
   const int LS = pick_ls_fwd(N, L);
-  VQF_LAUNCH(KID_MFB_FUSE_FWD, mfb_fuse_fwd_kernel, dim3(N, LS), dim3(256), 0,
-             (hipStream_t)stream, P, pbias, q, cascade, keep, seed, thr, inv_keep, L, O, LS, R, rowssq, zdrop);
+  if (p_bf16)
+    VQF_LAUNCH(KID_MFB_FUSE_FWD, mfb_fuse_fwd_kernel<__bf16>, dim3(N, LS), dim3(256), 0, (hipStream_t)stream,
+               (const __bf16*)P, pbias, q, cascade, keep, seed, thr, inv_keep, L, O, LS, R, rowssq, zdrop);
+  else
+    VQF_LAUNCH(KID_MFB_FUSE_FWD, mfb_fuse_fwd_kernel<float>, dim3(N, LS), dim3(256), 0, (hipStream_t)stream,
+               (const float*)P, pbias, q, cascade, keep, seed, thr, inv_keep, L, O, LS, R, rowssq, zdrop);
   return vqf_last_error();
+}
+
+extern "C" {
+
+int vqf_mfb_fuse_fwd(const float* P, const float* pbias, const float* q, const float* cascade,
+                     const uint8_t* keep,
+                     uint64_t seed, float p_drop, int N, int L, int O, float* R, float* rowssq,
+                     float* zdrop, void* stream) {
+  return fuse_fwd_impl(P, 0, pbias, q, cascade, keep, seed, p_drop, N, L, O, R, rowssq, zdrop, stream);
+}
+
+int vqf_mfb_fuse_fwd_pbf16(const void* P_bf16, const float* pbias, const float* q, const uint8_t* keep, uint64_t seed,
+                           float p_drop, int N, int L, int O, float* R, float* rowssq, void* stream) {
+  return fuse_fwd_impl(P_bf16, 1, pbias, q, nullptr, keep, seed, p_drop, N, L, O, R, rowssq, nullptr, stream);
 }
 
 size_t vqf_mfb_fuse_bwd_ws_bytes(int N, int L, int O) {
@@ -294,15 +322,23 @@ int vqf_mfb_fuse_bwd(const float* dY, const float* dzdrop, const float* Y, const
                      const float* coefA, const float* coefB, const float* P, const float* pbias, const float* q,
                      const float* cascade, const uint8_t* keep, uint64_t seed, float p_drop, int N, int L, int O,
                      float* dP, float* dq, float* dcascade, float* dbiasP, void* ws, size_t ws_bytes, void* stream) {
-  return fuse_bwd_impl(dY, dzdrop, Y, inv, coefA, coefB, P, pbias, q, cascade, keep, seed, p_drop, N, L, O, dP, 0, dq,
+  return fuse_bwd_impl(dY, dzdrop, Y, inv, coefA, coefB, P, 0, pbias, q, cascade, keep, seed, p_drop, N, L, O, dP, 0, dq,
                        dcascade, dbiasP, ws, ws_bytes, stream);
+}
+
+int vqf_mfb_fuse_bwd_pbf16(const float* dY, const float* Y, const float* inv, const float* coefA,
+                           const float* coefB, const void* P_bf16, const float* pbias, const float* q,
+                           const uint8_t* keep, uint64_t seed, float p_drop, int N, int L, int O, void* dP_bf16,
+                           float* dq, float* dbiasP, void* ws, size_t ws_bytes, void* stream) {
+  return fuse_bwd_impl(dY, nullptr, Y, inv, coefA, coefB, P_bf16, 1, pbias, q, nullptr, keep, seed, p_drop, N, L, O,
+                       dP_bf16, 1, dq, nullptr, dbiasP, ws, ws_bytes, stream);
 }
 
 int vqf_mfb_fuse_bwd_bf16dp(const float* dY, const float* Y, const float* inv, const float* coefA,
                             const float* coefB, const float* P, const float* pbias, const float* q,
                             const uint8_t* keep, uint64_t seed, float p_drop, int N, int L, int O, void* dP_bf16,
                             float* dq, float* dbiasP, void* ws, size_t ws_bytes, void* stream) {
-  return fuse_bwd_impl(dY, nullptr, Y, inv, coefA, coefB, P, pbias, q, nullptr, keep, seed, p_drop, N, L, O, dP_bf16, 1,
+  return fuse_bwd_impl(dY, nullptr, Y, inv, coefA, coefB, P, 0, pbias, q, nullptr, keep, seed, p_drop, N, L, O, dP_bf16, 1,
                        dq, nullptr, dbiasP, ws, ws_bytes, stream);
 }
 

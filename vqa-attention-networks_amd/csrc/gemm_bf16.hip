@@ -300,6 +300,7 @@ int vqf_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A, int lda, c
   {
     int rc = VQF_OK;      // the two big projections take the 256x256-tile kernel
     if (vqf_gemm_bf16_big_try(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, ws, ws_bytes, s, &rc)) return rc;
+    if (flags & VQF_GEMM_OUT_BF16) return VQF_E_UNSUPPORTED;   // bf16 output exists in the large-tile kernel only
   }
   GemmArgs g;
   g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C; g.bias = bias; g.slab = nullptr;

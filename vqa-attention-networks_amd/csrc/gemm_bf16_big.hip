@@ -118,14 +118,14 @@ __device__ __forceinline__ bf16x8 read_frag(const char* s, int row0, int ks, int
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <bool GUARD_M>
-__device__ __forceinline__ void store_tile(const BigArgs& g, float* C, const f32x16 (&acc)[4][2], const float (&bv)[2],
+template <bool GUARD_M, typename OT>
+__device__ __forceinline__ void store_tile(const BigArgs& g, OT* C, const f32x16 (&acc)[4][2], const float (&bv)[2],
                                            int row_base, int col0, bool relu) {
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int col = col0 + j * 32;
     if (col >= g.N) continue;
-    float* cp = C + (long long)row_base * g.ldc + col;
+    OT* cp = C + (long long)row_base * g.ldc + col;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -133,7 +133,7 @@ __device__ __forceinline__ void store_tile(const BigArgs& g, float* C, const f32
         const int dr = i * 32 + (e & 3) + 8 * (e >> 2);       // compile-time row offset
         float v = acc[i][j][e] + bv[j];
         if (relu) v = fmaxf(v, 0.f);
-        if (!GUARD_M || row_base + dr < g.M) cp[(long long)dr * g.ldc] = v;
+        if (!GUARD_M || row_base + dr < g.M) cp[(long long)dr * g.ldc] = (OT)v;
       }
     }
   }
@@ -232,8 +232,14 @@ __global__ void __launch_bounds__(NT, 2) gemm_bf16_big_kernel(const BigArgs g) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the biases, once: no wait may sit between the stores
   const int row_base = m0 + wr * 128 + 4 * h;
-  if (m0 + TM <= g.M) store_tile<false>(g, C, acc, bv, row_base, n0 + wc * 64 + r, relu);
-  else                store_tile<true>(g, C, acc, bv, row_base, n0 + wc * 64 + r, relu);
+  if (g.flags & VQF_GEMM_OUT_BF16) {                 // bf16 storage of the result (round-to-nearest-even), never with split-K
+    __bf16* Cb = reinterpret_cast<__bf16*>(g.C);
+    if (m0 + TM <= g.M) store_tile<false>(g, Cb, acc, bv, row_base, n0 + wc * 64 + r, relu);
+    else                store_tile<true>(g, Cb, acc, bv, row_base, n0 + wc * 64 + r, relu);
+  } else {
+    if (m0 + TM <= g.M) store_tile<false>(g, C, acc, bv, row_base, n0 + wc * 64 + r, relu);
+    else                store_tile<true>(g, C, acc, bv, row_base, n0 + wc * 64 + r, relu);
+  }
 }
 
 int pick_splits(int tiles, int K, int M, int N, size_t ws_bytes) {
@@ -304,7 +310,7 @@ int vqf_gemm_bf16_big_try(int ta, int tb, int M, int N, int K, const void* A, in
   g.tiles_m = (M + TM - 1) / TM;
   g.tiles_n = (N + TN - 1) / TN;
   const int tiles = g.tiles_m * g.tiles_n;
-  int splits = pick_splits(tiles, K, M, N, (ws && aligned16(ws)) ? ws_bytes : 0);
+  int splits = (flags & VQF_GEMM_OUT_BF16) ? 1 : pick_splits(tiles, K, M, N, (ws && aligned16(ws)) ? ws_bytes : 0);
   const int slabs = K / TK;
   const int per = (slabs + splits - 1) / splits;
   g.kchunk = per * TK;

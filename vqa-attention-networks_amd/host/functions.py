@@ -121,6 +121,8 @@ class ImgFuseFn(torch.autograd.Function):
     (N,1000,L,1) permutation of the same values, mfb.py:103-106).
     """
 
+    BF16_P = True      # bf16 mode: store P in bf16 when the large-tile GEMM applies (A/B switch)
+
     @staticmethod
     def forward(ctx, img, wi, bi, q, keep, seed, p_drop, bf16=False):
         img = _c(img)
@@ -132,7 +134,12 @@ class ImgFuseFn(torch.autograd.Function):
         if ctx.bf16:
             # bf16 storage of the image tensor and the projection weight, fp32 accumulation
             img = img.view(N * L, D) if img.dtype == torch.bfloat16 else ops.cast_bf16(img.view(N * L, D))
-            P = ops.gemm_bf16(img, ops.cast_bf16(wi2), bias=bi)
+            wb = ops.cast_bf16(wi2)
+            # the projection is STORED in bf16 when the large-tile kernel applies (half the bytes of the largest
+            # tensor of the step in the GEMM epilogue, the fusion forward and the fusion backward)
+            P = ops.gemm_bf16(img, wb, bias=bi, out_bf16=True) if ImgFuseFn.BF16_P else None
+            if P is None:
+                P = ops.gemm_bf16(img, wb, bias=bi)
         else:
             P = ops.gemm(img.view(N * L, D), wi2, bias=bi)
         Y, norm, inv, _ = ops.mfb_fuse_fwd(P, q, N, L, O, keep=keep, seed=seed, p_drop=p_drop)

@@ -117,11 +117,17 @@ def cast_bf16(x, pad_to=8):
     return y
 
 
+GEMM_OUT_BF16 = 4
+
+
 def gemm_bf16(a, b, ta=False, tb=False, bias=None, relu=False, M=None, N=None, K=None, out=None,
-              accumulate=False):
-    """C fp32 = Aop @ Bop^T with bf16 operands (row strides may exceed the logical widths)."""
+              accumulate=False, out_bf16=False):
+    """C fp32 = Aop @ Bop^T with bf16 operands (row strides may exceed the logical widths).
+    out_bf16: store C as bf16 (large-tile kernel only); returns None when that kernel does not apply."""
     _chk_bf16(a, b)
-    _chk(bias, out)
+    _chk(bias)
+    if out is not None:
+        (_chk_bf16 if out_bf16 else _chk)(out)
     if M is None:
         M = a.shape[1] if ta else a.shape[0]
     if K is None:
@@ -129,11 +135,13 @@ def gemm_bf16(a, b, ta=False, tb=False, bias=None, relu=False, M=None, N=None, K
     if N is None:
         N = b.shape[1] if tb else b.shape[0]
     if out is None:
-        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
-    flags = (GEMM_RELU if relu else 0) | (GEMM_ACCUM if accumulate else 0)
+        out = torch.empty((M, N), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=a.device)
+    flags = (GEMM_RELU if relu else 0) | (GEMM_ACCUM if accumulate else 0) | (GEMM_OUT_BF16 if out_bf16 else 0)
     ws = workspace(a.device, max(SPLITK_WS_BYTES, int(_lib().vqf_gemm_bf16_ws_bytes(int(ta), int(tb), M, N, K))))
     rc = _lib().vqf_gemm_bf16(int(ta), int(tb), M, N, K, _ptr(a), a.stride(0), _ptr(b), b.stride(0),
                               _ptr(out), out.stride(0), _ptr(bias), flags, _ptr(ws), ws.numel(), _stream())
+    if out_bf16 and rc == -3:          # VQF_E_UNSUPPORTED: shape outside the large-tile kernel -> caller uses fp32 output
+        return None
     _l.check(rc, "vqf_gemm_bf16")
     return out
 
@@ -292,15 +300,23 @@ def _keep_ptr(keep):
 
 
 def mfb_fuse_fwd(P, q, N, L, O, keep=None, seed=0, p_drop=0.0, cascade=None, want_zdrop=False, pbias=None):
-    """-> (Y normalised (N*L,O), norm (N), inv (N), zdrop or None).  pbias: projection bias added on load."""
-    _chk(P, q, cascade, pbias)
+    """-> (Y normalised (N*L,O), norm (N), inv (N), zdrop or None).  pbias: projection bias added on load.
+    P may be bf16 (written by gemm_bf16(out_bf16=True))."""
+    (_chk_bf16 if P.dtype == torch.bfloat16 else _chk)(P)
+    _chk(q, cascade, pbias)
     dev = P.device
     R = torch.empty((N * L, O), dtype=torch.float32, device=dev)
     rowssq = torch.empty(N * L, dtype=torch.float32, device=dev)
     zdrop = torch.empty_like(P) if want_zdrop else None
-    _l.check(_lib().vqf_mfb_fuse_fwd(_ptr(P), _ptr(pbias), _ptr(q), _ptr(cascade), _keep_ptr(keep), int(seed),
-                                     float(p_drop), N, L, O, _ptr(R), _ptr(rowssq), _ptr(zdrop), _stream()),
-             "vqf_mfb_fuse_fwd")
+    if P.dtype == torch.bfloat16:      # the projection itself stored in bf16 (bf16 mode of the image fusion)
+        if cascade is not None or want_zdrop:
+            raise _l.VqfError("mfb_fuse_fwd: a bf16 P is only available without cascade / zdrop")
+        _l.check(_lib().vqf_mfb_fuse_fwd_pbf16(_ptr(P), _ptr(pbias), _ptr(q), _keep_ptr(keep), int(seed), float(p_drop),
+                                               N, L, O, _ptr(R), _ptr(rowssq), _stream()), "vqf_mfb_fuse_fwd_pbf16")
+    else:
+        _l.check(_lib().vqf_mfb_fuse_fwd(_ptr(P), _ptr(pbias), _ptr(q), _ptr(cascade), _keep_ptr(keep), int(seed),
+                                         float(p_drop), N, L, O, _ptr(R), _ptr(rowssq), _ptr(zdrop), _stream()),
+                 "vqf_mfb_fuse_fwd")
     norm = torch.empty(N, dtype=torch.float32, device=dev)
     inv = torch.empty(N, dtype=torch.float32, device=dev)
     _l.check(_lib().vqf_l2_group_norm(_ptr(rowssq), N, L, _ptr(norm), _ptr(inv), _stream()),
@@ -312,7 +328,10 @@ def mfb_fuse_fwd(P, q, N, L, O, keep=None, seed=0, p_drop=0.0, cascade=None, wan
 def mfb_fuse_bwd(dY, Y, norm, inv, P, q, N, L, O, keep=None, seed=0, p_drop=0.0, cascade=None,
                  want_dbias=False, dzdrop=None, pbias=None, dp_bf16=False):
     """-> (dP (N*L,5O) fp32 | bf16, dq (N,5O), dcascade or None, dbiasP or None)."""
-    _chk(dY, Y, norm, inv, P, q, cascade, dzdrop, pbias)
+    (_chk_bf16 if P.dtype == torch.bfloat16 else _chk)(P)
+    _chk(dY, Y, norm, inv, q, cascade, dzdrop, pbias)
+    if P.dtype == torch.bfloat16 and not dp_bf16:
+        raise _l.VqfError("mfb_fuse_bwd: a bf16 P comes with a bf16 dP")
     dev = P.device
     rowdot = torch.empty(N * L, dtype=torch.float32, device=dev)
     _l.check(_lib().vqf_rowdot(_ptr(Y), _ptr(dY), N * L, O, _ptr(rowdot), _stream()), "vqf_rowdot")
@@ -327,6 +346,12 @@ def mfb_fuse_bwd(dY, Y, norm, inv, P, q, N, L, O, keep=None, seed=0, p_drop=0.0,
         if cascade is not None or dzdrop is not None:
             raise _l.VqfError("mfb_fuse_bwd: bf16 dP is only available without cascade / dzdrop")
         dP = torch.empty(P.shape, dtype=torch.bfloat16, device=dev)
+        if P.dtype == torch.bfloat16:
+            _l.check(_lib().vqf_mfb_fuse_bwd_pbf16(_ptr(dY), _ptr(Y), _ptr(inv), _ptr(cA), _ptr(cB), _ptr(P), _ptr(pbias),
+                                                   _ptr(q), _keep_ptr(keep), int(seed), float(p_drop), N, L, O, _ptr(dP),
+                                                   _ptr(dq), _ptr(db), _ptr(ws), ws.numel(), _stream()),
+                     "vqf_mfb_fuse_bwd_pbf16")
+            return dP, dq, None, db
         _l.check(_lib().vqf_mfb_fuse_bwd_bf16dp(_ptr(dY), _ptr(Y), _ptr(inv), _ptr(cA), _ptr(cB), _ptr(P), _ptr(pbias),
                                                 _ptr(q), _keep_ptr(keep), int(seed), float(p_drop), N, L, O, _ptr(dP),
                                                 _ptr(dq), _ptr(db), _ptr(ws), ws.numel(), _stream()),
