@@ -50,7 +50,8 @@ extern "C" {
 #define VQF_GEMM_OUT_BF16 4    /* vqf_gemm_bf16 only: C points to bf16 storage (ldc in elements), result rounded
                                   to nearest even; VQF_E_UNSUPPORTED unless the 256x256-tile kernel applies */
 
-/* ABI version and build information ("gfx950;fp32-mfma-32x32x2;...") */
+/* ABI version (2: LSTM entry points take a workspace and flags, large-tile GEMMs, solver tail, staging) and build
+ * information ("libvqa_fusion gfx950 fp32-mfma(...) tiles ...") */
 int vqf_abi_version(void);
 const char* vqf_build_info(void);
 

@@ -147,7 +147,7 @@ def load():
             fn = getattr(lib, name)        # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if lib.vqf_abi_version() != 1:
+        if lib.vqf_abi_version() != 2:
             raise VqfError("libvqa_fusion.so ABI version mismatch")
         _lib = lib
         return _lib
