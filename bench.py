@@ -72,11 +72,11 @@ def host_cores():
     return n
 
 
-def cpu_baseline(budget_s=20.0):
-    """The oracle (CPU restatement, PyTorch CPU ops) on the host cores: same step contents.
-
-    Bounded sample: one probe step at B=16 sizes the sample so that 1 warm-up + 2 timed steps
-    take about `budget_s` seconds (B in [16,128]); per-sample CPU cost is flat in B."""
+def cpu_baseline(batch=512, timed=3, config1_timed=5):
+    """The oracle (CPU restatement, PyTorch CPU ops) on the host cores, on the metric's own configuration
+    (BASELINE.md section 3): the MFB train step (fwd + loss + bwd + Adam, dropout masks supplied) at B=512,
+    1 warm-up + `timed` steps, median; plus BASELINE config 1 (MFB forward, eval, B=32) as `config1`.
+    About 45 s on the 16 cores of a GPU box; `--cpu-batch` shrinks the sample for quick runs."""
     from oracle import ref_torch as O
     cores = host_cores()
     torch.set_num_threads(cores)
@@ -106,22 +106,56 @@ def cpu_baseline(budget_s=20.0):
         opt.step()
         return time.perf_counter() - t0
 
-    img, q, a = synth_batch(128, 0, "cpu")
+    def fwd_only(img, q):
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            O.mfb_forward(sd, cfg, img, q)              # eval: no dropout (BASELINE config 1)
+        return time.perf_counter() - t0
+
+    img, q, a = synth_batch(batch, 0, "cpu")
     one_step(img[:16], q[:16], a[:16])                      # page-in / thread-pool warm-up
-    probe = one_step(img[:16], q[:16], a[:16])
-    per_sample = probe / 16.0
-    Bs = int(max(16, min(128, (budget_s / 3.0) / max(per_sample, 1e-6))))
-    Bs -= Bs % 8
-    times = [one_step(img[:Bs], q[:Bs], a[:Bs]) for _ in range(3)]
-    t = sorted(times[1:])[0] if len(times) == 2 else sorted(times[1:])[len(times[1:]) // 2]
+    one_step(img, q, a)                                     # 1 warm-up at the full batch
+    times = sorted(one_step(img, q, a) for _ in range(timed))
+    t = times[len(times) // 2]
+    fwd_only(img[:32], q[:32])
+    t1s = sorted(fwd_only(img[:32], q[:32]) for _ in range(config1_timed))
+    t1 = t1s[len(t1s) // 2]
     try:
         model = [l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
     except Exception:
         model = "unknown"
-    return {"value": round(Bs / t, 3), "unit": "QA-pairs/s", "cores": cores, "kind": "port",
+    return {"value": round(batch / t, 3), "unit": "QA-pairs/s", "cores": cores, "kind": "port",
             "sample": "oracle MFB train step (fwd+loss+bwd+Adam, dropout masks supplied), B=%d, "
-                      "1 warm-up + 2 timed steps, median %.2f s/step, %d threads; CPU: %s"
-                      % (Bs, t, cores, model)}
+                      "1 warm-up + %d timed steps, median %.2f s/step, %d threads; CPU: %s"
+                      % (batch, timed, t, cores, model),
+            "config1": {"value": round(32 / t1, 3), "unit": "QA-pairs/s",
+                        "sample": "BASELINE config 1: oracle MFB forward, eval, B=32, 1 warm-up + %d timed, "
+                                  "median %.3f s, %d threads" % (config1_timed, t1, cores)}}
+
+
+def live_wgrad_probe(ops, B, dev, reps=6):
+    """The weight-gradient launch of the image projection on LIVE operands.  In faithful MFB the singleton-axis
+    softmax makes dP exactly zero, and MFMA loops hold a higher clock on zeros (MI355X_MICROARCH.md, DVFS
+    give-back), so the in-step timing of that launch is no evidence for real data.  Same shape, same entry
+    point (ops.gemm(dP, X, ta, tb)), uniform random dP and a relu(N(0,1)) image; hipEvent-timed by the library's
+    profiler on the launch stream.  Returns (launches, total_ms, splitk_reduce_ms)."""
+    M, N, K = 5000, 2048, B * 196
+    g = torch.Generator(device="cpu").manual_seed(4321)
+    X = torch.relu(torch.randn((K, N), generator=g)).to(dev)
+    dP = ((torch.rand((K, M), generator=g) - 0.5) * 0.1).to(dev)
+    for _ in range(2):
+        ops.gemm(dP, X, ta=True, tb=True)
+    torch.cuda.synchronize()
+    ops.prof_reset()
+    ops.prof_enable(True)
+    for _ in range(reps):
+        ops.gemm(dP, X, ta=True, tb=True)
+    torch.cuda.synchronize()
+    ops.prof_enable(False)
+    n, ms = ops.prof_gemm(1, 1, M, N, K)
+    red = ops.prof_report().get("splitk_reduce", (0, 0.0))[1]
+    del X, dP
+    return n, ms, red
 
 
 def main():
@@ -131,11 +165,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=512, help="QA pairs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-overlap", action="store_true", help="A/B: image projection on the main stream")
+    ap.add_argument("--cpu-batch", type=int, default=512, help="batch of the cpu_baseline train step (default: the metric's 512)")
+    ap.add_argument("--no-overlap", action="store_true", help="A/B: projection + fusion as ONE autograd node")
     ap.add_argument("--overlap", action="store_true",
-                    help="two-stream step also at N=1 (default there: one stream, it is time-neutral on one GPU "
-                         "and keeps per-kernel timings clean; with N>1 the side stream is always on, it overlaps "
-                         "the weight-gradient GEMM with the gradient all-reduce)")
+                    help="A/B: image projection on a side HIP stream.  Default at EVERY N: one compute stream with "
+                         "the projection as its own autograd node ('same-stream'): its weight-gradient GEMM runs "
+                         "last in the backward and the other buckets' all-reduce (RCCL's stream) hides behind it")
     ap.add_argument("--miopen-lstm", action="store_true", help="A/B: question-encoder LSTM on nn.LSTM (MIOpen)")
     ap.add_argument("--pruned", action="store_true",
                     help="MFB.pruned: skip the work that is provably dead under the reference's singleton-axis softmaxes "
@@ -157,8 +192,10 @@ def main():
     vqa_amd.lib.load()
 
     rank, world, local = parallel.init_distributed(args.backend)
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N ranks with `python -m torch.distributed.run "
+                         "--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...`"
+                         % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
     local = local % torch.cuda.device_count()
@@ -184,8 +221,11 @@ def main():
         model.pruned = True
     if args.forward_only:
         model.eval()
-    if hasattr(model, "overlap_streams") and (args.no_overlap or (world == 1 and not args.overlap)):
-        model.overlap_streams = False
+    stream_mode = "one compute stream (projection + fusion one node)" if args.no_overlap else (
+        "two streams (projection on a side stream)" if args.overlap else
+        "one compute stream (projection its own node, weight gradient last)")
+    if hasattr(model, "overlap_streams"):                # the SAME configuration at every N
+        model.overlap_streams = False if args.no_overlap else (True if args.overlap else "same-stream")
     reducer = parallel.GradientAllReducer(model)        # broadcasts rank 0's weights; no-op at world 1
     # solver.py:25-29: criterion + Adam, both on the HIP path (host/train_step.py)
     opt = vqa_amd.Adam(model.parameters(), lr=7e-4)
@@ -222,6 +262,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    reducer.timing = True
     ops.prof_reset()
     ops.prof_enable(True)
     fence()
@@ -246,25 +287,41 @@ def main():
     roofline = None
     if n_f:
         ach = flops / (ms_f / n_f * 1e-3) / 1e12
-        traffic, traffic_note = None, None
-        try:        # PMC passes cannot run inside the timed process; use the committed rocprofv3 --pmc result
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_gemm.json")))
-            if (pmc["M"], pmc["N"], pmc["K"]) == (M, N, K):
-                traffic, traffic_note = pmc["traffic_bytes"], pmc["note"] + "; " + pmc["formula"]
-        except Exception:
-            pass
+        traffic, traffic_note, traffic_source = None, None, None
+        # PMC passes cannot run inside the timed process: the committed rocprofv3 --pmc result of this launch
+        for src in ("profiles/r02_pmc_gemm.json", "profiles/r01_pmc_gemm.json"):
+            try:
+                pmc = json.load(open(os.path.join(ROOT, src)))
+                if (pmc["M"], pmc["N"], pmc["K"]) == (M, N, K):
+                    traffic, traffic_note, traffic_source = pmc["traffic_bytes"], pmc["note"] + "; " + pmc["formula"], src
+                    break
+            except Exception:
+                pass
         roofline = {"bound": "mfma", "kernel": "img_conv1d forward GEMM (M=%d,N=%d,K=%d; gemm_f32_big.hip, 256x256 tiles; profiler id gemm_f32_a0b0)" % (M, N, K),
                     "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                    "traffic_note": traffic_note,
+                    "traffic_source": traffic_source, "traffic_note": traffic_note,
                     "avg_launch_ms": round(ms_f / n_f, 4), "launches": n_f,
                     "flops_per_launch": flops}
         if n_w:
             achw = flops / (ms_w / n_w * 1e-3) / 1e12
             roofline["wgrad"] = {"kernel": "gemm_f32_a1b1 img_conv1d wgrad (split-K)", "achieved": round(achw, 2),
                                  "frac": round(achw / FP32_MFMA_PEAK_TFLOPS, 4),
-                                 "avg_launch_ms": round(ms_w / n_w, 4), "launches": n_w}
+                                 "avg_launch_ms": round(ms_w / n_w, 4), "launches": n_w,
+                                 "operands": ("in-step launch; in faithful MFB dP is EXACTLY ZERO (singleton-axis "
+                                              "softmax): see wgrad_live for random operands")
+                                 if (args.model == "mfb" and not args.pruned) else "in-step launch, live operands"}
     rep = ops.prof_report()
+    exposed = reducer.exposed_ms()
+    if roofline is not None and world == 1 and args.dtype == "f32" and not args.forward_only:
+        n_l, ms_l, red_l = live_wgrad_probe(ops, B, dev)
+        if n_l:
+            achl = flops / (ms_l / n_l * 1e-3) / 1e12
+            roofline["wgrad_live"] = {"kernel": "the same launch (ops.gemm(dP, X, ta, tb), M=%d N=%d K=%d) on uniform "
+                                                "random dP / relu(N(0,1)) image, outside the step" % (N, K, M),
+                                      "achieved": round(achl, 2), "frac": round(achl / FP32_MFMA_PEAK_TFLOPS, 4),
+                                      "avg_launch_ms": round(ms_l / n_l, 4), "launches": n_l,
+                                      "splitk_reduce_ms_per_launch": round(red_l / n_l, 4)}
     kernels = {k: {"launches_per_step": round(n / args.steps, 2), "ms_per_step": round(ms / args.steps, 4)}
                for k, (n, ms) in sorted(rep.items(), key=lambda kv: -kv[1][1])}
     # secondary roofline: the HBM-bound MFB fusion kernels (mfb.py:98-106 and its backward).
@@ -297,14 +354,19 @@ def main():
                                       "pruned (NOT the headline: provably dead work skipped)" if args.pruned else "faithful")
                                    if args.model == "mfb" else "%s train step, batch %d per GPU, %s" % (args.model, B, args.dtype)),
                        "global_batch": B * world, "parallelism": "dp%d" % world,
-                       "grad_allreduce_bytes": reducer.gradient_bytes()},
+                       "grad_allreduce_bytes": reducer.gradient_bytes(),
+                       "ranks_seen": dist.get_world_size() if dist.is_initialized() else 1,
+                       "backend": (dist.get_backend() if dist.is_initialized() else "none (single process)"),
+                       "streams": stream_mode,
+                       "allreduce_bucket_bytes": reducer.bucket_bytes_list(),
+                       "allreduce_exposed_ms": exposed},
             "loss": round(float(loss.item()), 5),
             "roofline": roofline,
             "roofline_hbm_kernels": roofline_hbm,
             "kernels_ms_per_step": kernels,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(batch=args.cpu_batch)
             out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out))
     if world > 1:

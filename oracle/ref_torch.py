@@ -98,12 +98,16 @@ def glimpse_attention(feat, logits, compat_unit_softmax):
 # --------------------------------------------------------------------------
 # MFB-baseline  (mfb.py:61-140) and MHBCoAtt (mhb_coAtt.py:61-151)
 # --------------------------------------------------------------------------
-def _coatt_trunk(sd, cfg, img, q, glove, drop, *, mhb):
+def _coatt_trunk(sd, cfg, img, q, glove, drop, *, mhb, live_softmax=False):
     """Shared ladder up to (ques_att_feature, co_att_feature).
 
     Returns a dict of intermediates; `mhb` selects the MHBCoAtt deltas.
+    live_softmax (MFB only, NOT reference behaviour): take both attention softmaxes over the
+    token / region axis as mhb_coAtt.py:84,114 do, instead of mfb.py:84,118's singleton axis;
+    the checker for the product's `MFB.unit_softmax = False` mode, in which every tensor is live.
     """
     drop = drop or {}
+    unit = (not mhb) and not live_softmax
     multilayer = (not mhb) and getattr(cfg, "model_name", "") == "mfb-multilayer"
     N = img.shape[0]
     L, D = img.shape[1], img.shape[2]
@@ -132,7 +136,7 @@ def _coatt_trunk(sd, cfg, img, q, glove, drop, *, mhb):
         a = F.relu(a @ wm.t() + sd["ques_att_multiconv.bias"])
     w2 = sd["ques_att_conv2.weight"].flatten(1)
     qlog = a @ w2.t() + sd["ques_att_conv2.bias"]                     # (N,T,2)
-    qa, qw = glimpse_attention(h, qlog, compat_unit_softmax=not mhb)  # (N,2H)
+    qa, qw = glimpse_attention(h, qlog, compat_unit_softmax=unit)     # (N,2H)
 
     # a4: ques_proj1                              mfb.py:92-93
     qp = qa @ sd["ques_proj1.weight"].t() + sd["ques_proj1.bias"]     # (N,5000)
@@ -157,7 +161,7 @@ def _coatt_trunk(sd, cfg, img, q, glove, drop, *, mhb):
     clog = c @ wc2.t() + sd["co_att_conv2.bias"]                      # (N,L,2)
 
     # a8: softmax over regions + glimpse sums     mfb.py:116-123
-    va, vw = glimpse_attention(img, clog, compat_unit_softmax=not mhb)  # (N,2D)
+    va, vw = glimpse_attention(img, clog, compat_unit_softmax=unit)   # (N,2D)
     return dict(h=h, qlog=qlog, qw=qw, qa=qa, qp=qp, P=P, S=S, R=R, Y=Y,
                 clog=clog, vw=vw, va=va)
 
@@ -170,10 +174,10 @@ def _final_block(sd, qa, va, qname, iname, keep):
     return mfb_pool_norm(z, qa.shape[0])
 
 
-def mfb_forward(sd, cfg, img, q, drop=None, return_all=False):
+def mfb_forward(sd, cfg, img, q, drop=None, return_all=False, live_softmax=False):
     """MFB.forward(img_features, questions) -> logits (N,A).   mfb.py:61-140."""
     drop = drop or {}
-    t = _coatt_trunk(sd, cfg, img, q, None, drop, mhb=False)
+    t = _coatt_trunk(sd, cfg, img, q, None, drop, mhb=False, live_softmax=live_softmax)
     y = _final_block(sd, t["qa"], t["va"], "ques_proj2", "img_proj2", drop.get("m2"))
     logits = y @ sd["linear_pred.weight"].t() + sd["linear_pred.bias"]   # :137
     if return_all:

@@ -100,7 +100,24 @@ def check_grads64(named_grads, gold, tol=1e-8):
         assert d <= max(tol * max(np.abs(gold["g64samp/" + k]).max(), gn / np.sqrt(a.size)), floor), (k, d)
 
 
-def grad_parity(gpu_grads, g32, g64, k=8.0, floor=5e-4):
+def _report_parity(label, worst, worst_name):
+    """Drift visibility: the worst err/bound of every grad_parity call is printed and, on the
+    GPU box, appended to gpurun_out/grad_parity.log (copied to profiles/ per round)."""
+    import inspect
+    if not label:
+        for fr in inspect.stack()[2:8]:
+            if fr.function.startswith("test_"):
+                label = fr.function
+                break
+    line = "grad_parity %-70s worst err/bound %.3f  (%s)" % (label or "?", worst, worst_name)
+    print(line)
+    root = os.environ.get("GRAFT_REPO_ROOT")
+    if root and os.path.isdir(os.path.join(root, "gpurun_out")):
+        with open(os.path.join(root, "gpurun_out", "grad_parity.log"), "a") as f:
+            f.write(line + "\n")
+
+
+def grad_parity(gpu_grads, g32, g64, k=8.0, floor=5e-4, label=""):
     """Conditioning-aware gradient criterion.
 
     g64 = oracle gradients in float64 (pinned to the reference's fp64 run at 1e-8),
@@ -113,7 +130,7 @@ def grad_parity(gpu_grads, g32, g64, k=8.0, floor=5e-4):
     reference's own fp32 gradients is not meaningful.
     """
     gmax = max(float(g.norm()) for g in g64.values() if g is not None)
-    worst = 0.0
+    worst, worst_name = 0.0, "-"
     for name, gg in gpu_grads.items():
         r64 = g64[name]
         if r64 is None:
@@ -125,5 +142,7 @@ def grad_parity(gpu_grads, g32, g64, k=8.0, floor=5e-4):
         err = float((gg.detach().cpu().double() - r64).norm())
         bound = max(k * noise, floor * float(r64.norm()), 1e-6 * gmax)
         assert err <= bound, (name, "err %.3e bound %.3e noise32 %.3e norm %.3e" % (err, bound, noise, float(r64.norm())))
-        worst = max(worst, err / bound)
+        if err / bound > worst:
+            worst, worst_name = err / bound, name
+    _report_parity(label, worst, worst_name)
     return worst

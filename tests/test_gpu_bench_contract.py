@@ -13,7 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_bench_prints_one_contract_line():
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1"],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--cpu-batch", "64"],          # the default (the metric's B=512) takes ~45 s of CPU time
                        capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
@@ -30,6 +31,46 @@ def test_bench_prints_one_contract_line():
     assert r["bound"] in ("mfma", "hbm") and r["unit"] in ("TFLOP/s", "GB/s")
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.3 < r["frac"] < 1.0
     assert "traffic" in r                                   # bytes from the committed PMC passes, or null
+    assert r["traffic"] is None or str(r["traffic_source"]).startswith("profiles/")
+    assert r["wgrad"]["frac"] > 0.3 and "ZERO" in r["wgrad"]["operands"]      # faithful MFB: dP == 0, said so
+    assert 0.3 < r["wgrad_live"]["frac"] < 1.0                                   # the same launch on live operands
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    assert c["config1"]["value"] > 0 and "B=32" in c["config1"]["sample"]
     assert abs(d["value"] - 512 * 1000.0 / d["ms_per_step"]) / d["value"] < 1e-3
+    cfg = d["config"]
+    assert cfg["ranks_seen"] == 1 and cfg["allreduce_exposed_ms"] == [] and "one compute stream" in cfg["streams"]
+
+
+def test_bench_refuses_a_rank_count_that_is_not_there():
+    """`bench.py --gpus 8` without a launcher must not silently run one rank and call it 8."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)
+
+
+def test_bench_two_ranks_on_one_gpu_gloo_rehearsal(tmp_path):
+    """The N>1 code path of bench.py end to end without a second GPU: two fresh child processes with the
+    torchrun-style environment (started before anything touches the GPU), backend gloo, both on cuda:0.
+    Checks the contract line of rank 0: n_gpus, the gradient payload (MFB: 60 031 020 fp32 parameters =
+    240 124 080 bytes), ranks seen by torch.distributed, the per-bucket exposed all-reduce times."""
+    env = dict(os.environ, WORLD_SIZE="2", LOCAL_RANK="0", VQF_DIST_INIT="file://" + str(tmp_path / "store"))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--backend", "gloo", "--no-cpu-baseline"]
+    procs = [subprocess.Popen(cmd, cwd=ROOT, env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              text=True) for r in range(2)]
+    outs = [p.communicate(timeout=900) for p in procs]
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, "rank %d:\n%s" % (r, outs[r][1][-3000:])
+    lines = [l for l in outs[0][0].splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1 and not [l for l in outs[1][0].splitlines() if l.strip().startswith("{")]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 1024
+    assert d["config"]["grad_allreduce_bytes"] == 240124080
+    assert d["config"]["ranks_seen"] == 2 and d["config"]["backend"] == "gloo"
+    assert sum(d["config"]["allreduce_bucket_bytes"]) == 240124080
+    ex = d["config"]["allreduce_exposed_ms"]
+    assert len(ex) == len(d["config"]["allreduce_bucket_bytes"]) and all(b >= a - 1e-3 for a, b in zip(ex, ex[1:]))
+    assert abs(d["value"] - 1024 * 1000.0 / d["ms_per_step"]) / d["value"] < 1e-3
+    assert "cpu_baseline" not in d

@@ -109,3 +109,29 @@ def test_hiecoatten_single_sample_squeeze_semantics():
     ox, oav, oaq = O.hiecoatten_forward(recipe_sd(O.hiecoatten_shapes(96, 50, 64, 30), 105), img, q)
     assert rel_err(x.detach().cpu().numpy(), ox.numpy()) <= 1e-4
     assert rel_err(av.detach().cpu().numpy(), oav.numpy().reshape(-1)) <= 1e-4
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs in one process (nn.DataParallel-style use)")
+def test_gemm_kernels_on_a_second_device_of_the_same_process():
+    """The > 64 KB dynamic-LDS attribute is per device (common.h::vqf_set_dyn_lds): every GEMM family must launch
+    on device 1 after it has been used on device 0 (the reference drives several GPUs from one process,
+    solver.py:34-36)."""
+    import vqa_amd
+    ops = vqa_amd.ops
+    for dev in (0, 1):
+        with torch.cuda.device(dev):
+            d = torch.device("cuda", dev)
+            g = torch.Generator().manual_seed(5)
+            A = torch.rand((1024, 256), generator=g).to(d)
+            B = torch.rand((512, 256), generator=g).to(d)
+            ref = A.double() @ B.double().t()
+            out = ops.gemm(A, B)                                             # 128x128 kernel, 72 KB LDS
+            assert float((out.double() - ref).abs().max() / ref.abs().max()) <= 1e-5
+            ob = ops.gemm_bf16(A.to(torch.bfloat16), B.to(torch.bfloat16))
+            assert float((ob.double() - ref).abs().max() / ref.abs().max()) <= 2e-2
+            A2 = torch.rand((8192, 64), generator=g).to(d)
+            B2 = torch.rand((8192, 64), generator=g).to(d)                   # 1024 tiles: the large-tile kernels
+            r2 = A2.double() @ B2.double().t()
+            assert float((ops.gemm(A2, B2).double() - r2).abs().max() / r2.abs().max()) <= 1e-5
+            o2 = ops.gemm_bf16(A2.to(torch.bfloat16), B2.to(torch.bfloat16))
+            assert float((o2.double() - r2).abs().max() / r2.abs().max()) <= 2e-2

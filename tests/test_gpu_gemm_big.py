@@ -1,0 +1,118 @@
+"""Independent-reference parity of the large-tile GEMM kernels at the shapes the quoted numbers come from
+(VERDICT r01 "What's weak" #1): gemm_bf16_big.hip in all four layouts incl. its K-major/K-major weight-gradient
+layout, split-K, ragged M/N tails at N = 5000 and the bf16-output epilogue; and the exact headline fp32
+weight-gradient launch (M=5000, N=2048, K=100352, both operands K-major, split-K).
+
+Reference: an fp64 matmul of EXACTLY the kernel's operand values (bf16-rounded for the bf16 kernel).  The
+full product is computed by torch in fp64 on the GPU (rocBLAS: an independent implementation); a sampled
+block of it is re-computed with numpy on the CPU so that the reference itself is cross-checked.
+Tolerances (max-abs error relative to max |ref|): bf16 operands / fp32 accumulate 2e-5 * max(1, sqrt(K)/16);
+fp32 2e-6 * max(1, sqrt(K)/8) (the forms used for the small-tile kernels in test_gpu_bf16.py /
+test_gpu_kernels.py); bf16 output: within one bf16 ulp of the fp64 result and > 98 % equal to its RNE."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import vqa_amd
+    vqa_amd.lib.load()
+    return vqa_amd.ops
+
+
+def _u(shape, seed, scale=1.0, device="cuda"):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return ((torch.rand(shape, generator=g) * 2 - 1) * scale).to(device)
+
+
+def _ref64(A, B, ta, tb, bias=None):
+    """fp64 product on the GPU + numpy cross-check of a sampled 48x48 block (rows / columns incl. the edges)."""
+    A64, B64 = A.double(), B.double()
+    ref = (A64.t() if ta else A64) @ (B64 if tb else B64.t())
+    if bias is not None:
+        ref = ref + bias.double()
+    M, N = ref.shape
+    rs = np.unique(np.concatenate([np.linspace(0, M - 1, 40).astype(np.int64), [M - 1, M - 2, 255, 256]]))
+    cs = np.unique(np.concatenate([np.linspace(0, N - 1, 40).astype(np.int64), [N - 1, N - 2, 255, 256]]))
+    rs, cs = rs[rs < M], cs[cs < N]
+    rt, ct = torch.from_numpy(rs).to(A.device), torch.from_numpy(cs).to(A.device)
+    a = (A64[:, rt].t() if ta else A64[rt]).cpu().numpy()          # (rows, K)
+    b = (B64[:, ct].t() if tb else B64[ct]).cpu().numpy()          # (cols, K)
+    blk = a @ b.T
+    if bias is not None:
+        blk = blk + bias.double().cpu().numpy()[cs]
+    got = ref[rt][:, ct].cpu().numpy()
+    assert np.abs(got - blk).max() <= 1e-11 * max(1.0, np.abs(blk).max()), "the fp64 reference disagrees with numpy"
+    return ref
+
+
+def _rel(out, ref):
+    return float((out.double() - ref).abs().max() / (ref.abs().max() + 1e-300))
+
+
+# (M, N, K, what): >= 64 tiles of 256x256 each so that vqf_gemm_bf16 routes to gemm_bf16_big.hip
+BF16_BIG = [
+    (2104, 2200, 96, "ragged M and N tails, 3 slabs (shorter than the 4-deep copy pipeline)"),
+    (2104, 2200, 2048, "ragged tails, 81 tiles: split-K 3"),
+    (4096, 5000, 2048, "the projection's N = 5000 tail, 320 tiles: split-K"),
+    (7168, 7168, 512, "784 tiles >= 768: no split-K"),
+]
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K,what", BF16_BIG)
+def test_gemm_bf16_big_all_layouts_vs_fp64(ops, ta, tb, M, N, K, what):
+    A = _u((K, M) if ta else (M, K), 101).to(torch.bfloat16)
+    B = _u((K, N) if tb else (N, K), 102, 0.5).to(torch.bfloat16)
+    bias = _u((N,), 103)
+    ref = _ref64(A, B, ta, tb, bias)
+    tol = 2e-5 * max(1.0, np.sqrt(K) / 16)
+    out = ops.gemm_bf16(A, B, ta=bool(ta), tb=bool(tb), bias=bias)
+    assert out.shape == (M, N) and out.dtype == torch.float32
+    assert _rel(out, ref) <= tol, (what, _rel(out, ref), tol)
+    out_r = ops.gemm_bf16(A, B, ta=bool(ta), tb=bool(tb), bias=bias, relu=True)
+    assert _rel(out_r, torch.relu(ref)) <= tol
+    assert torch.equal(out, ops.gemm_bf16(A, B, ta=bool(ta), tb=bool(tb), bias=bias))     # deterministic split-K
+    # the same call MUST have gone through the large-tile kernel: its bf16-output epilogue exists only there
+    ob = ops.gemm_bf16(A, B, ta=bool(ta), tb=bool(tb), bias=bias, out_bf16=True)
+    assert ob is not None and ob.dtype == torch.bfloat16, "shape did not reach gemm_bf16_big.hip"
+    ulp = torch.maximum(ref.abs() * 2.0 ** -7, torch.full_like(ref, 2.0 ** -133))
+    assert bool(((ob.double() - ref).abs() <= ulp).all()), "bf16 output further than one ulp from the fp64 result"
+    same = (ob.view(torch.int16) == ref.float().to(torch.bfloat16).view(torch.int16)).float().mean()
+    assert float(same) > 0.98, float(same)
+
+
+def test_gemm_bf16_big_weight_gradient_layout_deep_k(ops):
+    """<ta,tb> = (1,1): both operands K-major (ds_read_b64_tr_b16 path), 20 x 8 tiles, deep K -> split-K.
+    dW[5000,2048] = dP^T X with K = 64 samples x 196 regions, then the headline K = 100352."""
+    for K, seed in ((64 * 196, 111), (512 * 196, 112)):
+        dP = _u((K, 5000), seed, 0.05).to(torch.bfloat16)
+        X = torch.relu(_u((K, 2048), seed + 1, 2.0)).to(torch.bfloat16)
+        ref = _ref64(dP, X, 1, 1)
+        out = ops.gemm_bf16(dP, X, ta=True, tb=True)
+        assert _rel(out, ref) <= 2e-5 * max(1.0, np.sqrt(K) / 16), (K, _rel(out, ref))
+        assert ops.gemm_bf16(dP, X, ta=True, tb=True, out_bf16=True) is not None      # big-kernel shape
+        del dP, X, ref, out
+        torch.cuda.empty_cache()
+
+
+def test_headline_fp32_weight_gradient_launch_vs_fp64(ops):
+    """The launch behind roofline.wgrad: ops.gemm(dP, X, ta=True, tb=True), M=5000, N=2048, K=100352 (split-K),
+    on LIVE operands (in faithful MFB dP is exactly zero).  fp64 reference, 2e-6 * sqrt(K)/8 = 7.9e-5."""
+    K = 512 * 196
+    dP = _u((K, 5000), 121, 0.05)
+    X = torch.relu(_u((K, 2048), 122, 2.0))
+    ref = _ref64(dP, X, 1, 1)
+    out = ops.gemm(dP, X, ta=True, tb=True)
+    tol = 2e-6 * max(1.0, np.sqrt(K) / 8)
+    assert _rel(out, ref) <= tol, (_rel(out, ref), tol)
+    assert torch.equal(out, ops.gemm(dP, X, ta=True, tb=True))          # slab reduction in a fixed order
+    # and the forward launch of the roofline line (M=100352, N=5000, K=2048), full product
+    W = _u((5000, 2048), 123, 0.03)
+    b = _u((5000,), 124)
+    P = ops.gemm(X, W, bias=b)
+    refP = _ref64(X, W, 0, 0, b)
+    assert _rel(P, refP) <= 2e-6 * max(1.0, np.sqrt(2048) / 8), _rel(P, refP)

@@ -2,8 +2,9 @@
 shard_rows partitioning, initial broadcast, bucketed overlapped all-reduce == gradient of
 the concatenated batch."""
 import os
-import socket
 import sys
+import tempfile
+import traceback
 
 import pytest
 import torch
@@ -13,14 +14,6 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
-
-
 def _make_model():
     torch.manual_seed(3)
     m = torch.nn.Sequential(torch.nn.Linear(12, 40), torch.nn.Tanh(), torch.nn.Linear(40, 7))
@@ -28,14 +21,22 @@ def _make_model():
     return m
 
 
-def _worker(rank, world, port, bucket_bytes, q):
+def _worker(rank, world, store, bucket_bytes, q):
+    try:
+        _worker_body(rank, world, store, bucket_bytes, q)
+    except Exception:
+        q.put((rank, "error", traceback.format_exc(), 0))
+        raise
+
+
+def _worker_body(rank, world, store, bucket_bytes, q):
     sys.path.insert(0, ROOT)
     torch.set_num_threads(1)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
-                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     from importlib import import_module
     par = import_module("vqa-attention-networks_amd.host.parallel")
-    r, w, _ = par.init_distributed(backend="gloo")
+    # file:// rendezvous in a directory the parent owns: no TCP port to lose between parent and children
+    r, w, _ = par.init_distributed(backend="gloo", init_method="file://" + store)
     assert (r, w) == (rank, world)
     model = _make_model()
     if rank != 0:                                        # replicas start different; broadcast fixes it
@@ -62,35 +63,34 @@ def _worker(rank, world, port, bucket_bytes, q):
 
 
 def _run_world(world, bucket_bytes):
-    port = _free_port()
+    """One attempt, no retry: a failing rank's traceback and exit code are the assertion message."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, bucket_bytes, q)) for r in range(world)]
-    for p in procs:
-        p.start()
     res = {}
-    try:
-        for _ in range(world):
-            rank, params, outs, nb = q.get(timeout=300)
-            res[rank] = (params, outs, nb)
+    with tempfile.TemporaryDirectory(prefix="vqf_dp_") as d:
+        store = os.path.join(d, "store")
+        procs = [ctx.Process(target=_worker, args=(r, world, store, bucket_bytes, q)) for r in range(world)]
         for p in procs:
-            p.join(timeout=120)
-            if p.exitcode != 0:
-                return None
-    except Exception:
-        return None
-    finally:
-        for p in procs:
-            if p.is_alive():
-                p.kill()
+            p.start()
+        try:
+            for _ in range(world):
+                rank, params, outs, nb = q.get(timeout=300)
+                assert params != "error", "rank %d failed:\n%s" % (rank, outs)
+                res[rank] = (params, outs, nb)
+            for r, p in enumerate(procs):
+                p.join(timeout=120)
+                assert p.exitcode == 0, "rank %d exit code %s" % (r, p.exitcode)
+        finally:
+            for p in procs:
+                if p.is_alive():
+                    p.kill()
     return res
 
 
 @pytest.mark.parametrize("bucket_bytes", [64 << 20, 256])
 def test_allreduce_equals_full_batch_gradient(bucket_bytes):
     world = 2
-    res = _run_world(world, bucket_bytes) or _run_world(world, bucket_bytes)   # one retry: rendezvous port race
-    assert res is not None, "2-rank gloo run failed twice"
+    res = _run_world(world, bucket_bytes)
     if bucket_bytes == 256:
         assert res[0][2] > 1                              # several buckets exercised
     # reference: single process, full batch, rank-0 initial weights

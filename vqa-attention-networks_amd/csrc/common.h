@@ -82,6 +82,21 @@ static inline int vqf_last_error() {
 
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is per device: a single process may drive several GPUs (the
+// reference wraps the model in nn.DataParallel, solver.py:34-36), so every kernel instantiation that asks for
+// more dynamic LDS than the default keeps one flag PER DEVICE.  Idempotent; a race only repeats the same call.
+struct VqfDynLdsFlags { bool done[64]; };
+static inline int vqf_set_dyn_lds(const void* fn, int bytes, VqfDynLdsFlags& f) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const bool tracked = dev >= 0 && dev < 64;
+  if (tracked && f.done[dev]) return VQF_OK;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return (int)e;
+  if (tracked) f.done[dev] = true;
+  return VQF_OK;
+}
+
 // ---- device helpers -------------------------------------------------------
 __device__ __forceinline__ bool aligned16_dev(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 __device__ __forceinline__ float wave_sum(float v) {

@@ -247,13 +247,8 @@ __global__ void __launch_bounds__(NTHREADS, 4) gemm_bf16_kernel(GemmArgs g) {
 
 template <bool TA, bool TB>
 int launch(const GemmArgs& g, dim3 grid, hipStream_t s) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<TA, TB>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-    if (e != hipSuccess) return (int)e;
-    attr_done = true;
-  }
+  static VqfDynLdsFlags attr = {};
+  if (int e = vqf_set_dyn_lds(reinterpret_cast<const void*>(&gemm_bf16_kernel<TA, TB>), SMEM_BYTES, attr)) return e;
   VQF_LAUNCH(KID_GEMM_BF16, (gemm_bf16_kernel<TA, TB>), grid, dim3(NTHREADS), SMEM_BYTES, s, g);
   return vqf_last_error();
 }

@@ -467,13 +467,8 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int splits,
 
 template <bool TA, bool TB, bool FAST>
 int launch_gemm_impl(const GemmArgs& g, dim3 grid, hipStream_t s, int kid) {
-  static bool attr_done = false;   // idempotent; a race only repeats the same call
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<TA, TB, FAST>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-    if (e != hipSuccess) return (int)e;
-    attr_done = true;
-  }
+  static VqfDynLdsFlags attr = {};   // 72 KB of dynamic LDS: the attribute is needed on EVERY device this process uses
+  if (int e = vqf_set_dyn_lds(reinterpret_cast<const void*>(&gemm_f32_kernel<TA, TB, FAST>), SMEM_BYTES, attr)) return e;
   VQF_LAUNCH(kid, (gemm_f32_kernel<TA, TB, FAST>), grid, dim3(NTHREADS), SMEM_BYTES, s, g);
   return vqf_last_error();
 }

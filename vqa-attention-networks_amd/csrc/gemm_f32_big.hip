@@ -233,17 +233,9 @@ int pick_splits(int tiles, int K, int M, int N, size_t ws_bytes) {
 
 template <bool TA, bool TB>
 int launch(const BigArgs& g, hipStream_t s) {
-  // > 64 KB of dynamic LDS needs the attribute, once per device and instantiation (a single process may drive
-  // several GPUs, e.g. under nn.DataParallel); idempotent, a race only repeats the same call
-  static bool attr_done[64] = {};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (dev < 0 || dev >= 64 || !attr_done[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_big_kernel<TA, TB>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BIG);
-    if (e != hipSuccess) return (int)e;
-    if (dev >= 0 && dev < 64) attr_done[dev] = true;
-  }
+  // > 64 KB of dynamic LDS needs the attribute, once per device and instantiation (common.h)
+  static VqfDynLdsFlags attr = {};
+  if (int e = vqf_set_dyn_lds(reinterpret_cast<const void*>(&gemm_f32_big_kernel<TA, TB>), SMEM_BIG, attr)) return e;
   VQF_LAUNCH(KID_GEMM_A0B0 + 2 * (TA ? 1 : 0) + (TB ? 1 : 0), (gemm_f32_big_kernel<TA, TB>), dim3(g.tiles_m * g.tiles_n * g.splits), dim3(NT), SMEM_BIG,
              s, g);
   return vqf_last_error();

@@ -17,6 +17,9 @@ if os.environ.get("VQF_LIB"):          # A/B builds (tools/build_variant.sh); ne
     LIB_PATH = os.path.abspath(os.environ["VQF_LIB"])
 HEADER_PATH = os.path.join(os.path.dirname(PKG_DIR), "include", "vqa_fusion.h")
 
+# The one place the expected ABI number lives (csrc/prof.hip returns it from vqf_abi_version()).
+ABI_VERSION = 2
+
 _lock = threading.Lock()
 _lib = None
 
@@ -147,8 +150,9 @@ def load():
             fn = getattr(lib, name)        # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if lib.vqf_abi_version() != 2:
-            raise VqfError("libvqa_fusion.so ABI version mismatch")
+        if lib.vqf_abi_version() != ABI_VERSION:
+            raise VqfError("libvqa_fusion.so ABI version %d, host expects %d: rebuild with `make -C %s`"
+                           % (lib.vqf_abi_version(), ABI_VERSION, CSRC_DIR))
         _lib = lib
         return _lib
 

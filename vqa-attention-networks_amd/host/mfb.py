@@ -35,6 +35,18 @@ def _image_is_data(img, gemm_dtype="fp32"):
                        "data and does not produce its gradient")
 
 
+_warned = set()
+
+
+def warn_once(key, msg):
+    """One log line per process and reason when a module leaves the HIP path for a torch/MIOpen op
+    (the answer stays the same, the speed does not: MHBCoAtt's batch-axis recursion costs ~35 ms per step there)."""
+    if key not in _warned:
+        _warned.add(key)
+        import warnings
+        warnings.warn("vqa fusion path: " + msg, RuntimeWarning, stacklevel=3)
+
+
 def batch_first_lstm(lstm, x, use_hip=True, bf16=False):
     """nn.LSTM(batch_first=True) forward of x (N,T,E) -> (N,T,H) with zero initial state (mfb.py:69).  The
     recursion runs on the HIP path (MFMA GEMMs + one point-wise kernel per step, functions.LstmBatchFn) with
@@ -45,6 +57,11 @@ def batch_first_lstm(lstm, x, use_hip=True, bf16=False):
         hs = LstmBatchFn.apply(x.transpose(0, 1).contiguous(), lstm.weight_ih_l0, lstm.weight_hh_l0,
                                lstm.bias_ih_l0 if lstm.bias else None, lstm.bias_hh_l0 if lstm.bias else None, bf16)
         return hs.transpose(0, 1)
+    if use_hip:
+        warn_once("lstm_batch", "question-encoder LSTM runs on nn.LSTM (MIOpen), not on the HIP LstmBatchFn: it needs "
+                  "a GPU fp32 input, one layer, unidirectional, no projection, hidden_size %% 4 == 0 (got layers=%d, "
+                  "bidirectional=%s, proj=%d, hidden=%d, dtype=%s)" % (lstm.num_layers, lstm.bidirectional,
+                                                                      lstm.proj_size, lstm.hidden_size, x.dtype))
     out, _ = lstm(x)
     return out
 
@@ -55,8 +72,13 @@ class _SideStream:
     def __init__(self):
         self.streams = {}
 
-    def project(self, img, conv, bf16):
+    def project(self, img, conv, bf16, same_stream=False):
         dev = img.device
+        if same_stream:
+            # the projection stays its own autograd node but runs on the caller's stream: created first, its
+            # backward (the weight-gradient GEMM) is the LAST node autograd runs, so every other gradient bucket
+            # is already being all-reduced (on RCCL's stream) while that 15 ms GEMM computes
+            return ImgProjFn.apply(img, conv.weight, bf16), None
         side = self.streams.get(dev)
         if side is None:
             side = self.streams[dev] = torch.cuda.Stream(device=dev)
@@ -68,6 +90,8 @@ class _SideStream:
 
     @staticmethod
     def join(P0, side):
+        if side is None:
+            return P0
         cur = torch.cuda.current_stream(P0.device)
         cur.wait_stream(side)
         P0.record_stream(cur)                    # allocated on the side stream, consumed here
@@ -125,8 +149,11 @@ class MFB(nn.Module):
         # "fp32" (default, parity 1e-4) or "bf16": bf16 operands / fp32 accumulate for the two large
         # GEMM families (img_conv1d and co_att_conv1, 96 % of the FLOPs); everything else stays fp32
         self.gemm_dtype = "fp32"
-        # run img_conv1d (and, through autograd, its weight gradient) on a side stream, concurrently
-        # with the question encoder / question attention (and their backward + gradient all-reduce)
+        # True: run img_conv1d (and, through autograd, its weight gradient) on a side stream, concurrently
+        # with the question encoder / question attention (and their backward + gradient all-reduce).
+        # "same-stream": the projection is its own autograd node on the caller's stream (its weight gradient
+        # then runs last in the backward, behind which the other buckets' all-reduce hides); one compute stream.
+        # False: projection + fusion as one node (ImgFuseFn).
         self.overlap_streams = True
         # question encoder's LSTM recursion on the HIP path instead of nn.LSTM / MIOpen (same parameters)
         self.use_hip_lstm = True
@@ -170,7 +197,8 @@ class MFB(nn.Module):
         # bf16 mode keeps projection + fusion in one autograd node (ImgFuseFn): its backward hands dP to the
         # weight-gradient GEMM in bf16 without an fp32 round trip, which is worth more than the stream overlap
         side = self.overlap_streams and not (bf16_img and self.fuse_bf16_dp) and not (self.pruned and self.unit_softmax)
-        proj = self._side.project(img_features, self.img_conv1d, bf16_img) if side else None
+        proj = self._side.project(img_features, self.img_conv1d, bf16_img,
+                                  self.overlap_streams == "same-stream") if side else None
         # a2: question encoder                                               mfb.py:68-70
         que_embedded = torch.tanh(self.word_embedding(questions))
         lstm_o = batch_first_lstm(self.lstm, que_embedded, self.use_hip_lstm, self.gemm_dtype == "bf16")

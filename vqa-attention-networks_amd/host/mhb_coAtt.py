@@ -10,7 +10,7 @@ import torch.nn.functional as F
 
 from . import ops
 from .functions import LinearFn, AttHeadFn, ImgFuseFn, MfbFuseFn, FinalMfbFn, LstmSeqFn, LstmBatchFn
-from .mfb import _DropSeeds, _image_is_data, _SideStream, batch_first_lstm
+from .mfb import _DropSeeds, _image_is_data, _SideStream, batch_first_lstm, warn_once
 
 
 class MHBCoAtt(nn.Module):
@@ -55,7 +55,8 @@ class MHBCoAtt(nn.Module):
         # bf16 mode keeps projection + fusion in one autograd node (ImgFuseFn): its backward hands dP to the
         # weight-gradient GEMM in bf16 without an fp32 round trip, which is worth more than the stream overlap
         side = self.overlap_streams and not (bf16_img and self.fuse_bf16_dp)
-        proj = self._side.project(img_features, self.img_conv1d, bf16_img) if side else None
+        proj = self._side.project(img_features, self.img_conv1d, bf16_img,
+                                  self.overlap_streams == "same-stream") if side else None
         que_embedded = torch.tanh(self.word_embedding(questions))            # (N,T,E)
         if self.cfg.glove:
             assert glove_matrix is not None, 'glove should not be NoneType.'
@@ -73,6 +74,11 @@ class MHBCoAtt(nn.Module):
                                  self.gemm_dtype == "bf16")     # bf16 mode: bf16 operands in the recurrent product
             ques_feature = self.dropout_l(hs).contiguous()
         else:
+            if self.use_hip_lstm:
+                warn_once("lstm_seq", "MHBCoAtt's batch-axis LSTM recursion runs on nn.LSTM (MIOpen: one tiny step per "
+                          "sample, ~35 ms per 512-sample step), not on the HIP LstmSeqFn, which covers one layer, "
+                          "tokens per question <= 32 and hidden_dim in {256, 512, 768, 1024} (got T=%d, H=%d, layers=%d)"
+                          % (que_embedded.shape[1], self.cfg.hidden_dim, self.lstm.num_layers))
             lstm_o, _ = self.lstm(que_embedded.permute(1, 0, 2))             # (T,N,H), recurs over N
             ques_feature = self.dropout_l(lstm_o).permute(1, 0, 2).contiguous()   # (N,T,H)
         T, H = ques_feature.shape[1], ques_feature.shape[2]
@@ -150,6 +156,9 @@ class MHB(nn.Module):
             lstm_outs = LstmBatchFn.apply(q_embedded.contiguous(), self.LSTM.weight_ih_l0, self.LSTM.weight_hh_l0,
                                           self.LSTM.bias_ih_l0, self.LSTM.bias_hh_l0)       # (T,N,H)
         else:
+            if self.use_hip_lstm:
+                warn_once("lstm_mhb", "MHB's LSTM runs on nn.LSTM (MIOpen), not on the HIP LstmBatchFn (one layer, "
+                          "unidirectional, hidden_size % 4 == 0, GPU input)")
             lstm_outs, _ = self.LSTM(q_embedded)                             # (T,N,H)
         idx = (q_length.to(torch.long) - 1).to(lstm_outs.device)
         lstm_out = lstm_outs[idx, torch.arange(batch_size, device=lstm_outs.device)]   # :185-186

@@ -63,11 +63,11 @@ class Attention_layer(nn.Module):
         self.nonlinear_3 = nn.ReLU()
 
     def forward(self, feature_1, feature_2):
-        feature_1_embbed = self.nonlinear_1(feature_1)
-        feature_2_embbed = self.nonlinear_2(feature_2)
-        f_hat, att = self.att_layer(feature_1_embbed, feature_2_embbed)
-        feature_2_embbed = self.nonlinear_3(feature_2_embbed + f_hat)
-        return (feature_1_embbed, feature_2_embbed, att)
+        # modules.py:26-33: ReLU both inputs, attend over the first, ReLU-residual into the second
+        src = self.nonlinear_1(feature_1)
+        dst = self.nonlinear_2(feature_2)
+        attended, att = self.att_layer(src, dst)
+        return (src, self.nonlinear_3(dst + attended), att)
 
 
 class Nonlinear_layer(nn.Module):

@@ -18,23 +18,28 @@ import torch
 import torch.distributed as dist
 
 
-def init_distributed(backend=None):
-    """Initialise torch.distributed from the torchrun environment.  Returns (rank, world, local_rank)."""
+def init_distributed(backend=None, init_method=None):
+    """Initialise torch.distributed from the torchrun environment.  Returns (rank, world, local_rank).
+
+    `init_method` (or the environment variable VQF_DIST_INIT) overrides the env:// rendezvous, e.g.
+    "file:///tmp/x/store" — used by the tests, whose parent cannot hold a TCP port open for its children."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    init_method = init_method or os.environ.get("VQF_DIST_INIT") or None
     if world > 1 and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        kw = dict(rank=rank, world_size=world)
+        if init_method:
+            kw["init_method"] = init_method
         if backend == "nccl":
             local = local % max(torch.cuda.device_count(), 1)
             torch.cuda.set_device(local)
-            dist.init_process_group(backend, rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            kw["device_id"] = torch.device("cuda", local)
+        dist.init_process_group(backend, **kw)
     return rank, world, local
 
 
@@ -64,6 +69,11 @@ class GradientAllReducer:
             self.broadcast_parameters()
         self.buckets = []       # list of dict(flat, params=[(p, offset, numel)], pending, handle)
         self._index = {}
+        # timing = True: finish() brackets its waits with events on the compute stream; exposed_ms() then
+        # reports, per bucket, how long after the last backward kernel that bucket's collective completed
+        # (the part of the all-reduce the backward did NOT hide)
+        self.timing = False
+        self._marks = []
         if self.world > 1:
             self._build_buckets(bucket_bytes)
             self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
@@ -136,14 +146,42 @@ class GradientAllReducer:
                     if p.grad is None:
                         b["flat"][off:off + n].zero_()
                 self._launch(b)
+        cuda = self.timing and self.buckets and self.buckets[0]["flat"].is_cuda
+        marks = None
+        if cuda:
+            cur = torch.cuda.current_stream(self.buckets[0]["flat"].device)
+            marks = [torch.cuda.Event(enable_timing=True)]
+            marks[0].record(cur)               # behind the last backward kernel of the compute stream
         for b in self.buckets:
             b["handle"].wait()
+            if cuda:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(cur)                 # the compute stream now waits on / has seen this collective
+                marks.append(ev)
             if not self._has_avg():
                 b["flat"].div_(self.world)
             for p, off, n in b["params"]:
                 p.grad = b["flat"][off:off + n].view_as(p)
             b["pending"] = len(b["params"])
             b["handle"] = None
+        if marks:
+            self._marks.append(marks)
+
+    def exposed_ms(self):
+        """Mean over the timed steps of [ms from the end of the backward kernels to bucket i's completion],
+        in launch order (bucket 0 = the gradients produced first); the last entry is the whole exposed tail."""
+        if not self._marks:
+            return []
+        torch.cuda.synchronize()
+        n = len(self._marks[0]) - 1
+        acc = [0.0] * n
+        for marks in self._marks:
+            for i in range(n):
+                acc[i] += marks[0].elapsed_time(marks[i + 1])
+        return [round(a / len(self._marks), 4) for a in acc]
+
+    def bucket_bytes_list(self):
+        return [b["flat"].numel() * b["flat"].element_size() for b in self.buckets]
 
     def gradient_bytes(self):
         return sum(b["flat"].numel() * b["flat"].element_size() for b in self.buckets)
