@@ -242,6 +242,149 @@ __global__ void __launch_bounds__(NT, 2) gemm_bf16_big_kernel(const BigArgs g) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Ping-pong variant (round 2, the default): same tile, staging, LDS images and epilogue as the kernel above, but the
+// two waves that share a SIMD (wave w and w + 4: row halves wr = 0 / 1 of the tile) run HALF A SLAB APART.  A slab
+// is two barrier-separated segments per wave,
+//     L(s): 12 fragment reads of slab s (both k-steps) + the 4 LDS-DMA copies that refill the slot of slab s-1
+//           + counted vmcnt (my copies of slab s+1 have landed) + lgkmcnt(0)
+//     M(s): the slab's 16 MFMAs back to back under s_setprio 1 (no LDS, no VMEM: nothing in it can stall),
+// and waves 4-7 execute one extra s_barrier before the loop (waves 0-3 one after it), so in every barrier interval one
+// wave of each SIMD multiplies while its partner loads: the matrix pipe sees one uninterrupted MFMA stream instead
+// of two waves that read together and then multiply together (the lockstep kernel above: 44 % MFMA-busy).
+// sched_barrier(0) pins both segments between their barriers (hipcc otherwise moves MFMAs across raw s_barriers).
+// Hazards, with global barrier numbers (#0 = pre-loop; waves 0-3: L(s) in (#2s, #2s+1), M(s) in (#2s+1, #2s+2);
+// waves 4-7 one interval later):
+//   RAW  slab s+1 is read by waves 0-3 after #2s+2 and by waves 4-7 after #2s+3; every wave's counted vmcnt for ITS
+//        copies of slab s+1 sits at the end of its L(s), i.e. before #2s+1 (waves 0-3) / #2s+2 (waves 4-7).
+//   WAR  the copies of slab s+4 overwrite the slot of slab s-1; they are issued after #2s at the earliest, the
+//        reads of slab s-1 were retired (lgkmcnt(0) in front of the barrier that ends L(s-1)) before #2s-1 / #2s.
+template <bool TA, bool TB>
+__global__ void __launch_bounds__(NT, 2) gemm_bf16_pp_kernel(const BigArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;             // rows wr*128 .. +127, columns wc*64 .. +63
+
+  const int ntiles = g.tiles_m * g.tiles_n;
+  const int z = blockIdx.x / ntiles;
+  int id = blockIdx.x % ntiles;
+  {
+    const int q8 = ntiles / 8, r8 = ntiles % 8, xcd = id % 8, k = id / 8;
+    id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
+  }
+  const int per_group = GROUP_M * g.tiles_n;
+  const int grp = id / per_group, in = id % per_group;
+  const int gm0 = grp * GROUP_M;
+  const int gsz = min(GROUP_M, g.tiles_m - gm0);
+  const int tm = gm0 + in % gsz, tn = in / gsz;
+  const int m0 = tm * TM, n0 = tn * TN;
+  const int kbeg = z * g.kchunk;
+  const int S = (min(g.K, kbeg + g.kchunk) - kbeg) / TK;       // slabs of this split (uniform over the workgroup)
+
+  gbf16* qa[NG];
+  gbf16* qb[NG];
+  init_src<TA>(qa, g.A, g.lda, m0, g.M, kbeg, wave, lane);
+  init_src<TB>(qb, g.B, g.ldb, n0, g.N, kbeg, wave, lane);
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+#pragma unroll
+  for (int p = 0; p < NSLOT - 1; ++p)
+    if (p < S) {
+      stage_operand<TA>(qa, g.lda, smem + p * SLOT_BYTES, wave);
+      stage_operand<TB>(qb, g.ldb, smem + p * SLOT_BYTES + OP_BYTES, wave);
+    }
+  {                                                    // my copies of slab 0 (4 per slab and thread)
+    const int later = min(NSLOT - 1, S) - 1;
+    if (later >= 3)      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (later == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();                        // #0: every wave's copies of slab 0 have landed
+  if (wr) __builtin_amdgcn_s_barrier();                // waves 4-7 fall half a slab behind (wave-uniform branch)
+
+  int slot = 0;                                        // slot of slab s
+  for (int s = 0; s < S; ++s) {
+    // ---------------- L(s): the partner wave of this SIMD is multiplying ----------------
+    __builtin_amdgcn_sched_barrier(0);
+    const char* sA = smem + slot * SLOT_BYTES;
+    const char* sB = sA + OP_BYTES;
+    bf16x8 a0[4], b0[2], a1[4], b1[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b0[j] = read_frag<TB>(sB, wc * 64 + j * 32, 0, lane);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a0[i] = read_frag<TA>(sA, wr * 128 + i * 32, 0, lane);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b1[j] = read_frag<TB>(sB, wc * 64 + j * 32, 1, lane);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a1[i] = read_frag<TA>(sA, wr * 128 + i * 32, 1, lane);
+    if (s + NSLOT - 1 < S) {                           // slab s+4 into the slot of slab s-1
+      const int sl = (slot == 0) ? NSLOT - 1 : slot - 1;
+      stage_operand<TA>(qa, g.lda, smem + sl * SLOT_BYTES, wave);
+      stage_operand<TB>(qb, g.ldb, smem + sl * SLOT_BYTES + OP_BYTES, wave);
+    }
+    {                                                  // my copies of slab s+1; later slabs stay in flight
+      const int later = min(s + NSLOT - 1, S - 1) - (s + 1);
+      if (later >= 3)      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else if (later == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);                // lgkmcnt(0): fragments in registers, slot s no longer read by me
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // ---------------- M(s): the partner loads ----------------
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b0[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    slot = (slot + 1 == NSLOT) ? 0 : slot + 1;
+  }
+  if (!wr) __builtin_amdgcn_s_barrier();               // waves 0-3 absorb the barrier waves 4-7 spent on the stagger
+
+  // ---- epilogue (as above)
+  const int r = lane & 31, h = lane >> 5;
+  const bool split = g.splits > 1;
+  const bool relu = !split && (g.flags & VQF_GEMM_RELU) != 0;
+  float* C = split ? g.C + (size_t)z * g.M * g.N : g.C;
+  float bv[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + wc * 64 + j * 32 + r;
+    bv[j] = (!split && g.bias && col < g.N) ? g.bias[col] : 0.f;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const int row_base = m0 + wr * 128 + 4 * h;
+  if (g.flags & VQF_GEMM_OUT_BF16) {
+    __bf16* Cb = reinterpret_cast<__bf16*>(g.C);
+    if (m0 + TM <= g.M) store_tile<false>(g, Cb, acc, bv, row_base, n0 + wc * 64 + r, relu);
+    else                store_tile<true>(g, Cb, acc, bv, row_base, n0 + wc * 64 + r, relu);
+  } else {
+    if (m0 + TM <= g.M) store_tile<false>(g, C, acc, bv, row_base, n0 + wc * 64 + r, relu);
+    else                store_tile<true>(g, C, acc, bv, row_base, n0 + wc * 64 + r, relu);
+  }
+}
+
 int pick_splits(int tiles, int K, int M, int N, size_t ws_bytes) {
   if (tiles >= 768) return 1;
   int best = 1;
@@ -260,7 +403,15 @@ int pick_splits(int tiles, int K, int M, int N, size_t ws_bytes) {
 template <bool TA, bool TB>
 int launch(const BigArgs& g, hipStream_t s) {
   // > 64 KB of dynamic LDS needs the attribute, once per device and instantiation (common.h)
-  static VqfDynLdsFlags attr = {};
+  static VqfDynLdsFlags attr = {}, attr_pp = {};
+  const char* ppe = getenv("VQF_GEMM_BF16_PP");        // A/B switch, read per launch (tools/gemm_bf16_ab.py flips it
+  const bool pingpong = !(ppe && ppe[0] == '0');       // in one process): 0 selects the lockstep kernel of round 1
+  if (pingpong) {
+    if (int e = vqf_set_dyn_lds(reinterpret_cast<const void*>(&gemm_bf16_pp_kernel<TA, TB>), SMEM_BIG, attr_pp)) return e;
+    VQF_LAUNCH(KID_GEMM_BF16, (gemm_bf16_pp_kernel<TA, TB>), dim3(g.tiles_m * g.tiles_n * g.splits), dim3(NT), SMEM_BIG,
+               s, g);
+    return vqf_last_error();
+  }
   if (int e = vqf_set_dyn_lds(reinterpret_cast<const void*>(&gemm_bf16_big_kernel<TA, TB>), SMEM_BIG, attr)) return e;
   VQF_LAUNCH(KID_GEMM_BF16, (gemm_bf16_big_kernel<TA, TB>), dim3(g.tiles_m * g.tiles_n * g.splits), dim3(NT), SMEM_BIG,
              s, g);
@@ -268,11 +419,8 @@ int launch(const BigArgs& g, hipStream_t s) {
 }
 
 bool big_applies(int ta, int tb, int M, int N, int K, int flags) {
-  static int enabled = -1;
-  if (enabled < 0) {
-    const char* e = getenv("VQF_GEMM_BF16_BIG");       // A/B switch: 0 selects the 128x128 kernel everywhere
-    enabled = (e && e[0] == '0') ? 0 : 1;
-  }
+  const char* e = getenv("VQF_GEMM_BF16_BIG");        // A/B switch, read per launch: 0 selects the 128x128 kernel everywhere
+  const bool enabled = !(e && e[0] == '0');
   if (!enabled || (K % TK) || M < TM || N < 128 || (flags & VQF_GEMM_ACCUM)) return false;
   if (ta && (M % 8)) return false;
   if (tb && (N % 8)) return false;

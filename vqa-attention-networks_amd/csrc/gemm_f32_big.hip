@@ -12,11 +12,19 @@
 //   * K-contiguous operand: [row][16] floats (64-byte rows, byte-identical to the bf16 image), chunk
 //     XOR (row >> 2) & 3 on the copy's source address and on the ds_read_b128; a lane's 4 floats feed
 //     4 MFMAs: lane (r, h) holds k = 8h + 4ks + e of row r for MFMA (ks, e).
-//   * K-major operand: [k][256] floats (1 KB k-rows, a wave copy = one k-row, whole lines); fragments are
-//     ds_read_b32 (32 lanes = 128 contiguous bytes, conflict-free without a swizzle), same k mapping.
+//   * K-major operand: [k][256] floats (1 KB k-rows, a wave copy = one k-row, whole lines).  The rows of the
+//     wave's strip are INTERLEAVED over its MFMA tiles: A row 4r+i belongs to row-tile i (B column 2c+j to column-tile
+//     j), so ONE ds_read_b128 (ds_read_b64) of a k-row hands lane r the operand value of all 4 (2) tiles: per k-pair
+//     and wave 2 LDS instructions feed 8 MFMAs, conflict-free without a swizzle (32 lanes read 512 contiguous
+//     bytes).  The accumulator -> output map follows: tile (i, j), MFMA row rm, MFMA column cm is output row
+//     4 rm + i (K-major A) and column 2 cm + j (K-major B), so a lane's two column-tiles are 8 contiguous bytes.
+//     (Round 1 read these fragments as 4 ds_read_b32 per tile and kept the weight gradients on the 128x128 kernel.)
 //   * deterministic split-K for few-tile / long-K shapes (the weight gradient).
-// Preconditions (else the caller uses gemm_f32.hip): K % 16 == 0, M >= 256, N >= 128, >= 1024 tiles, no
-// accumulate flag, 16-byte aligned bases, lda/ldb % 4 == 0, a K-major operand's row extent % 4 == 0.
+//   * two loop forms: the lockstep loop of round 1 (fragment reads one k-step ahead of the MFMAs, one barrier per
+//     slab) and a ping-pong loop (VQF_GEMM_F32_PP=1; see gemm_bf16_big.hip) in which the two waves of a SIMD run
+//     half a slab apart, one multiplying while the other loads.
+// Preconditions (else the caller uses gemm_f32.hip): K % 16 == 0, M >= 256, N >= 128, >= 1024 workgroups (tiles x
+// splits), no accumulate flag, 16-byte aligned bases, lda/ldb % 4 == 0, a K-major operand's row extent % 4 == 0.
 #include "common.h"
 #include <stdlib.h>
 
@@ -84,9 +92,51 @@ __device__ __forceinline__ void stage_operand(gfloat* (&q)[NG], int ld, char* s,
   }
 }
 
-// 4 operand values of rows row0 .. row0+31 for the MFMAs (ks, e = 0..3) of a slab: lane (r, h) holds
-// k = 8ks + 4h + e of row r (v_mfma_f32_32x32x2_f32 takes k = 0 from lanes 0-31 and k = 1 from lanes 32-63;
-// any fixed pairing of the slab's 16 k works as long as both operands use the same one).
+// Operand values of one slab for the wave's strip (A: 128 rows = 4 tiles, B: 64 columns = 2 tiles).
+// MFMA step (ks, e) of a slab multiplies k = 8ks + e (lanes 0-31) and k = 8ks + 4 + e (lanes 32-63): any fixed pairing
+// of the slab's 16 k works as long as both operands use the same one (v_mfma_f32_32x32x2_f32 takes k = 0 from lanes
+// 0-31 and k = 1 from lanes 32-63).
+//   K-contiguous: one ds_read_b128 per (tile, ks): lane (r, h) gets k = 8ks + 4h + e, e = 0..3, of row 32 tile + r.
+//   K-major:      one ds_read_b128 (A) / ds_read_b64 (B) per (ks, e): lane (r, h) gets k-row 8ks + 4h + e, strip rows
+//                 4r .. 4r+3 (columns 2r, 2r+1): element t belongs to tile t (interleaved strip, see the header).
+template <bool T>
+struct FragA {                                           // v(i, ks, e): value of row-tile i for step (ks, e)
+  f32x4 f[TK / 8][4];                                    // K-contiguous: [ks][tile] (e in the vector); K-major: [ks][e] (tile in the vector)
+  __device__ __forceinline__ void load(const char* s, int strip0, int lane) {
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int ks = 0; ks < TK / 8; ++ks)
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+        f[ks][x] = T ? *reinterpret_cast<const f32x4*>(s + (8 * ks + 4 * h + x) * 1024 + (strip0 + 4 * r) * 4)
+                     : *reinterpret_cast<const f32x4*>(s + (strip0 + 32 * x + r) * ROW_B + (((2 * ks + h) ^ swz(r)) << 4));
+  }
+  __device__ __forceinline__ float v(int i, int ks, int e) const { return T ? f[ks][e][i] : f[ks][i][e]; }
+};
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <bool T>
+struct FragB {
+  f32x4 fc[TK / 8][2];                                   // K-contiguous: [ks][tile]
+  f32x2 ft[TK / 8][4];                                   // K-major: [ks][e] (tile in the vector)
+  __device__ __forceinline__ void load(const char* s, int strip0, int lane) {
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int ks = 0; ks < TK / 8; ++ks) {
+      if (T) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          ft[ks][e] = *reinterpret_cast<const f32x2*>(s + (8 * ks + 4 * h + e) * 1024 + (strip0 + 2 * r) * 4);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          fc[ks][j] = *reinterpret_cast<const f32x4*>(s + (strip0 + 32 * j + r) * ROW_B + (((2 * ks + h) ^ swz(r)) << 4));
+      }
+    }
+  }
+  __device__ __forceinline__ float v(int j, int ks, int e) const { return T ? ft[ks][e][j] : fc[ks][j][e]; }
+};
+
+// round-1 readers (lockstep loop): one tile, one k-step at a time, standard (non-interleaved) strips
 template <bool T>
 __device__ __forceinline__ f32x4 read_frag(const char* s, int row0, int ks, int lane) {
   const int r = lane & 31, h = lane >> 5;
@@ -216,6 +266,151 @@ __global__ void __launch_bounds__(NT, 2) gemm_f32_big_kernel(const BigArgs g) {
   else                store_tile<true>(g, C, acc, bv, row_base, n0 + wc * 64 + r, relu);
 }
 
+
+// accumulator tile (i, j), register e, lane (cm = lane & 31, h = lane >> 5): MFMA row rm = (e & 3) + 8 (e >> 2) + 4h,
+// MFMA column cm.  Output row = strip row 4 rm + i (K-major A: interleaved strip) or 32 i + rm; output column =
+// strip column 2 cm + j (K-major B) or 32 j + cm.
+template <bool TA, bool TB, bool GUARD_M>
+__device__ __forceinline__ void store_tile_pp(const BigArgs& g, float* C, const f32x16 (&acc)[4][2], int row0, int col0,
+                                              int lane, bool relu, bool use_bias) {
+  const int cm = lane & 31, h = lane >> 5;
+  float bv[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = col0 + (TB ? 2 * cm + j : 32 * j + cm);
+    bv[j] = (use_bias && col < g.N) ? g.bias[col] : 0.f;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the biases, once: no wait may sit between the stores
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int rm = (e & 3) + 8 * (e >> 2) + 4 * h;
+      const int row = row0 + (TA ? 4 * rm + i : 32 * i + rm);
+      if (GUARD_M && row >= g.M) continue;
+      float v0 = acc[i][0][e] + bv[0], v1 = acc[i][1][e] + bv[1];
+      if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+      float* cp = C + (long long)row * g.ldc + col0;
+      if (TB) {
+        if (col0 + 2 * cm < g.N) *reinterpret_cast<f32x2*>(cp + 2 * cm) = f32x2{v0, v1};   // N % 4 == 0, ldc even: 8-byte aligned
+      } else {
+        if (col0 + cm < g.N) cp[cm] = v0;
+        if (col0 + 32 + cm < g.N) cp[32 + cm] = v1;
+      }
+    }
+  }
+}
+
+// Ping-pong form (round 2): see gemm_bf16_big.hip for the schedule and its hazard argument; identical here with
+// 64 MFMAs of 64 cycles per M segment, all fragments of the slab (12 or 16 LDS reads) taken in the L segment.
+template <bool TA, bool TB>
+__global__ void __launch_bounds__(NT, 2) gemm_f32_pp_kernel(const BigArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;             // strip rows wr*128 .. +127, strip columns wc*64 .. +63
+
+  const int ntiles = g.tiles_m * g.tiles_n;
+  const int z = blockIdx.x / ntiles;
+  int id = blockIdx.x % ntiles;
+  {
+    const int q8 = ntiles / 8, r8 = ntiles % 8, xcd = id % 8, k = id / 8;
+    id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
+  }
+  const int per_group = GROUP_M * g.tiles_n;
+  const int grp = id / per_group, in = id % per_group;
+  const int gm0 = grp * GROUP_M;
+  const int gsz = min(GROUP_M, g.tiles_m - gm0);
+  const int tm = gm0 + in % gsz, tn = in / gsz;
+  const int m0 = tm * TM, n0 = tn * TN;
+  const int kbeg = z * g.kchunk;
+  const int S = (min(g.K, kbeg + g.kchunk) - kbeg) / TK;       // slabs of this split (uniform over the workgroup)
+
+  gfloat* qa[NG];
+  gfloat* qb[NG];
+  init_src<TA>(qa, g.A, g.lda, m0, g.M, kbeg, wave, lane);
+  init_src<TB>(qb, g.B, g.ldb, n0, g.N, kbeg, wave, lane);
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  static_assert(2 * NG == 4 && NSLOT == 5 && TK == 16, "the ping-pong loop assumes 4 copies per thread per slab, 5 slots");
+#pragma unroll
+  for (int p = 0; p < NSLOT - 1; ++p)
+    if (p < S) {
+      stage_operand<TA>(qa, g.lda, smem + p * SLOT_BYTES, wave);
+      stage_operand<TB>(qb, g.ldb, smem + p * SLOT_BYTES + OP_BYTES, wave);
+    }
+  {                                                    // my copies of slab 0
+    const int later = min(NSLOT - 1, S) - 1;
+    if (later >= 3)      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (later == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();                        // #0: every wave's copies of slab 0 have landed
+  if (wr) __builtin_amdgcn_s_barrier();                // waves 4-7 fall half a slab behind (wave-uniform branch)
+
+  int slot = 0;
+  for (int s = 0; s < S; ++s) {
+    // ---------------- L(s) ----------------
+    __builtin_amdgcn_sched_barrier(0);
+    const char* sA = smem + slot * SLOT_BYTES;
+    const char* sB = sA + OP_BYTES;
+    FragA<TA> fa;
+    FragB<TB> fb;
+    fb.load(sB, wc * 64, lane);
+    fa.load(sA, wr * 128, lane);
+    if (s + NSLOT - 1 < S) {                           // slab s+4 into the slot of slab s-1
+      const int sl = (slot == 0) ? NSLOT - 1 : slot - 1;
+      stage_operand<TA>(qa, g.lda, smem + sl * SLOT_BYTES, wave);
+      stage_operand<TB>(qb, g.ldb, smem + sl * SLOT_BYTES + OP_BYTES, wave);
+    }
+    {                                                  // my copies of slab s+1; later slabs stay in flight
+      const int later = min(s + NSLOT - 1, S - 1) - (s + 1);
+      if (later >= 3)      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else if (later == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);                // lgkmcnt(0)
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // ---------------- M(s) ----------------
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < TK / 8; ++ks)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.v(i, ks, e), fb.v(j, ks, e), acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    slot = (slot + 1 == NSLOT) ? 0 : slot + 1;
+  }
+  if (!wr) __builtin_amdgcn_s_barrier();               // waves 0-3 absorb the barrier waves 4-7 spent on the stagger
+
+  const bool split = g.splits > 1;
+  const bool relu = !split && (g.flags & VQF_GEMM_RELU) != 0;
+  float* C = split ? g.C + (size_t)z * g.M * g.N : g.C;
+  const bool use_bias = !split && g.bias != nullptr;
+  if (m0 + TM <= g.M) store_tile_pp<TA, TB, false>(g, C, acc, m0 + wr * 128, n0 + wc * 64, lane, relu, use_bias);
+  else                store_tile_pp<TA, TB, true>(g, C, acc, m0 + wr * 128, n0 + wc * 64, lane, relu, use_bias);
+}
+
+// split count that minimises (rounds of 256 one-per-CU workgroups) x (time of one workgroup) + slab traffic, in
+// microseconds: a 256x256 tile costs a CU 2*256*256 / (157.3e12 / 256) = 0.213 us per unit of k; every split writes
+// and the reduce reads an M x N fp32 slab (~4 TB/s).
 int pick_splits(int tiles, int K, int M, int N, size_t ws_bytes) {
   if (tiles >= 768) return 1;
   int best = 1;
@@ -224,9 +419,10 @@ int pick_splits(int tiles, int K, int M, int N, size_t ws_bytes) {
     if (sp > 1 && (size_t)sp * M * N * sizeof(float) > ws_bytes) break;
     if (sp > 1 && K / sp < 16 * TK) break;
     const long long blocks = (long long)tiles * sp;
-    const double rounds = (double)((blocks + 255) / 256);            // one workgroup per CU
-    const double cost = rounds / sp + (sp > 1 ? 0.02 * sp : 0.0);    // + slab write / reduce traffic
-    if (cost < best_cost - 1e-12) { best_cost = cost; best = sp; }
+    const double rounds = (double)((blocks + 255) / 256);
+    const int slabs = (K / TK + sp - 1) / sp;
+    const double cost = rounds * slabs * TK * 0.213 + (sp > 1 ? sp * (double)M * N * 8.0 / 4.0e6 : 0.0);
+    if (cost < best_cost - 1e-9) { best_cost = cost; best = sp; }
   }
   return best;
 }
@@ -234,36 +430,43 @@ int pick_splits(int tiles, int K, int M, int N, size_t ws_bytes) {
 template <bool TA, bool TB>
 int launch(const BigArgs& g, hipStream_t s) {
   // > 64 KB of dynamic LDS needs the attribute, once per device and instantiation (common.h)
-  static VqfDynLdsFlags attr = {};
+  static VqfDynLdsFlags attr = {}, attr_pp = {};
+  // loop form, read per launch so that tools can A/B in one process: VQF_GEMM_F32_PP=0 lockstep (round 1), 1 ping-pong.
+  // K-major operands always take the ping-pong kernel (interleaved strips, one wide LDS read per k-pair).
+  const char* ppe = getenv("VQF_GEMM_F32_PP");
+  const bool pingpong = (TA || TB) ? !(ppe && ppe[0] == '0' && ppe[1] == '0') : !(ppe && ppe[0] == '0');
+  const int kid = KID_GEMM_A0B0 + 2 * (TA ? 1 : 0) + (TB ? 1 : 0);
+  if (pingpong) {
+    if (int e = vqf_set_dyn_lds(reinterpret_cast<const void*>(&gemm_f32_pp_kernel<TA, TB>), SMEM_BIG, attr_pp)) return e;
+    VQF_LAUNCH(kid, (gemm_f32_pp_kernel<TA, TB>), dim3(g.tiles_m * g.tiles_n * g.splits), dim3(NT), SMEM_BIG, s, g);
+    return vqf_last_error();
+  }
   if (int e = vqf_set_dyn_lds(reinterpret_cast<const void*>(&gemm_f32_big_kernel<TA, TB>), SMEM_BIG, attr)) return e;
-  VQF_LAUNCH(KID_GEMM_A0B0 + 2 * (TA ? 1 : 0) + (TB ? 1 : 0), (gemm_f32_big_kernel<TA, TB>), dim3(g.tiles_m * g.tiles_n * g.splits), dim3(NT), SMEM_BIG,
-             s, g);
+  VQF_LAUNCH(kid, (gemm_f32_big_kernel<TA, TB>), dim3(g.tiles_m * g.tiles_n * g.splits), dim3(NT), SMEM_BIG, s, g);
   return vqf_last_error();
 }
 
-bool big_applies(int ta, int tb, int M, int N, int K, int flags) {
-  static int enabled = -1;
-  if (enabled < 0) {
-    const char* e = getenv("VQF_GEMM_F32_BIG");        // A/B switch: 0 selects the 128x128 kernel everywhere
-    enabled = (e && e[0] == '0') ? 0 : 1;
-  }
+bool big_applies(int ta, int tb, int M, int N, int K, int flags, size_t ws_bytes) {
+  const char* e = getenv("VQF_GEMM_F32_BIG");        // A/B switch, read per launch: 0 selects the 128x128 kernel everywhere
+  const bool enabled = !(e && e[0] == '0');
   if (!enabled || (K % TK) || M < TM || N < 128 || (flags & VQF_GEMM_ACCUM)) return false;
   if (ta && (M % 4)) return false;
   if (tb && (N % 4)) return false;
-  // both operands K-major (the weight gradients): every fragment is 4 ds_read_b32 + address math, and the
-  // 128x128 kernel measured faster on img_conv1d's wgrad (15.1-15.9 vs 15.8-16.0 ms)
-  if (ta && tb) return false;
   // Only the large projections: a workgroup that needs a whole CU's LDS starts when the CU has drained, which
-  // costs mid-size launches more than the kernel gains (HieCoAtten, 392-tile GEMMs: step 5.57 -> 5.77 ms)
-  if (((M + TM - 1) / TM) * ((N + TN - 1) / TN) < 1024) return false;
-  return true;
+  // costs mid-size launches more than the kernel gains (HieCoAtten, 392-tile GEMMs: step 5.57 -> 5.77 ms) ...
+  const int tiles = ((M + TM - 1) / TM) * ((N + TN - 1) / TN);
+  if (tiles >= 1024) return true;
+  // ... and the deep-K weight gradients (both operands K-major, few tiles, K = N*L): img_conv1d's 20 x 8 tiles x 8
+  // splits of 784 slabs each.  co_att_conv1's 4 x 4 tiles stay on the 128x128 kernel (64 tiles x 4 splits).
+  if (ta && tb && K >= 16384 && tiles * pick_splits(tiles, K, M, N, ws_bytes) >= 768) return true;   // needs its slabs
+  return false;
 }
 
 }  // namespace
 
 // scratch the big kernel would like for this shape (split-K slabs); 0 when it does not apply
 size_t vqf_gemm_f32_big_ws_bytes(int ta, int tb, int M, int N, int K) {
-  if (!big_applies(ta, tb, M, N, K, 0)) return 0;
+  if (!big_applies(ta, tb, M, N, K, 0, (size_t)1 << 40)) return 0;
   const int tiles = ((M + TM - 1) / TM) * ((N + TN - 1) / TN);
   const int sp = pick_splits(tiles, K, M, N, (size_t)1 << 40);
   return sp > 1 ? (size_t)sp * M * N * sizeof(float) : 0;
@@ -272,7 +475,7 @@ size_t vqf_gemm_f32_big_ws_bytes(int ta, int tb, int M, int N, int K) {
 // 0 = this kernel does not apply (caller falls back to gemm_f32.hip), 1 = launched (rc holds the status)
 int vqf_gemm_f32_big_try(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
                           int ldc, const float* bias, int flags, void* ws, size_t ws_bytes, hipStream_t s, int* rc) {
-  if (!big_applies(ta, tb, M, N, K, flags)) return 0;
+  if (!big_applies(ta, tb, M, N, K, flags, (ws && aligned16(ws)) ? ws_bytes : 0)) return 0;
   BigArgs g;
   g.A = A; g.B = B; g.C = C; g.bias = bias;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.flags = flags;
