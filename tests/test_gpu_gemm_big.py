@@ -86,6 +86,26 @@ def test_gemm_bf16_big_all_layouts_vs_fp64(ops, ta, tb, M, N, K, what):
     assert float(same) > 0.98, float(same)
 
 
+@pytest.mark.parametrize("M,N,K", [(2100, 2203, 160), (4099, 4001, 64), (2048, 2050, 2048)])
+def test_gemm_bf16_big_k_contiguous_odd_edges(ops, M, N, K):
+    """(0,0) layout (the 16x16x32 ping-pong kernel with interleaved column strips): N not a multiple of 4 takes the
+    scalar-store epilogue, odd M the row guard; split-K with a slab whose M*N is not a multiple of 4."""
+    A = _u((M, K), 131).to(torch.bfloat16)
+    B = _u((N, K), 132, 0.5).to(torch.bfloat16)
+    bias = _u((N,), 133)
+    ref = _ref64(A, B, 0, 0, bias)
+    tol = 2e-5 * max(1.0, np.sqrt(K) / 16)
+    out = ops.gemm_bf16(A, B, bias=bias)
+    assert _rel(out, ref) <= tol, _rel(out, ref)
+    ob = ops.gemm_bf16(A, B, bias=bias, relu=True, out_bf16=True)
+    assert ob is not None
+    refr = torch.relu(ref)
+    assert bool(((ob.double() - refr).abs() <= refr.abs() * 2.0 ** -7 + tol * float(ref.abs().max())).all())
+    wide = torch.full((M, N + 5), 7.0, device="cuda")                 # row-strided output view: ldc = N + 5
+    ops.gemm_bf16(A, B, bias=bias, out=wide[:, :N])
+    assert _rel(wide[:, :N], ref) <= tol and bool((wide[:, N:] == 7.0).all())
+
+
 def test_gemm_bf16_big_weight_gradient_layout_deep_k(ops):
     """<ta,tb> = (1,1): both operands K-major (ds_read_b64_tr_b16 path), 20 x 8 tiles, deep K -> split-K.
     dW[5000,2048] = dP^T X with K = 64 samples x 196 regions, then the headline K = 100352."""

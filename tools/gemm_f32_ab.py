@@ -13,7 +13,8 @@ args = ap.parse_args()
 ENV = {"small": {"VQF_GEMM_F32_BIG": "0", "VQF_GEMM_F32_PP": "1"}, "lock": {"VQF_GEMM_F32_BIG": "1", "VQF_GEMM_F32_PP": "0"},
        "pp": {"VQF_GEMM_F32_BIG": "1", "VQF_GEMM_F32_PP": "1"}}
 SH = {"fwd": (0, 0, 100352, 5000, 2048), "wgrad": (1, 1, 5000, 2048, 100352), "coatt_fwd": (0, 0, 100352, 1024, 1024),
-      "coatt_dgrad": (0, 1, 100352, 1024, 1024), "sq": (0, 0, 8192, 8192, 8192), "sq_tn": (1, 0, 8192, 8192, 8192)}
+      "coatt_dgrad": (0, 1, 100352, 1024, 1024), "sq": (0, 0, 8192, 8192, 8192), "sq_tn": (1, 0, 8192, 8192, 8192),
+      "coatt_wgrad": (1, 1, 1024, 1000, 100352), "coatt1000": (0, 0, 100352, 1024, 1000)}
 for name in args.shapes.split(","):
     ta, tb, M, N, K = SH[name]
     g = torch.Generator(device="cpu").manual_seed(1)

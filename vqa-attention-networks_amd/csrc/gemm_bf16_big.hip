@@ -52,6 +52,13 @@ constexpr int NSLOT = 5;                               // slab s lives in slot s
 constexpr int SMEM_BIG = NSLOT * SLOT_BYTES;
 constexpr int NG = OP_BYTES / (NT * 16);               // 2 LDS-DMA instructions per thread per operand per slab
 constexpr int GROUP_M = 8;
+// ping-pong loop knobs (compile-time; tools/build_variant.sh for A/Bs)
+#ifndef VQF_PP_TAIL
+#define VQF_PP_TAIL 0          // MFMAs of a slab issued AFTER the barrier that ends M: the partner's MFMAs start behind them
+#endif
+#ifndef VQF_PP_GLDS_M
+#define VQF_PP_GLDS_M 0        // 1: the refill copies are issued inside M (after the first MFMAs) instead of in L
+#endif
 
 struct BigArgs {
   const bf16_t* A;
@@ -60,7 +67,22 @@ struct BigArgs {
   const float* bias;
   int M, N, K, lda, ldb, ldc, flags;
   int tiles_m, tiles_n, kchunk, splits;
+#ifdef VQF_PP_STAMPS
+  unsigned long long* dbg;   // diagnostic build only (tools/pp_stamps.py): per workgroup and wave, 8 cycle sums
+#endif
 };
+
+#ifdef VQF_PP_STAMPS
+// s_memtime stamp, fenced so that the segments hold what they are named for (cdna_hip_programming.md section 7)
+#define VQF_STAMP(t)                                                                         \
+  do {                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");              \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+  } while (0)
+#else
+#define VQF_STAMP(t) do { } while (0)
+#endif
 
 // per-lane global source pointers of the NG copies of one operand slab.
 //   K-contiguous: copy i, wave w, lane l -> row i*128 + 16w + (l >> 2), LDS chunk l & 3 (rows clamped to
@@ -313,9 +335,13 @@ __global__ void __launch_bounds__(NT, 2) gemm_bf16_pp_kernel(const BigArgs g) {
   if (wr) __builtin_amdgcn_s_barrier();                // waves 4-7 fall half a slab behind (wave-uniform branch)
 
   int slot = 0;                                        // slot of slab s
+#ifdef VQF_PP_STAMPS
+  unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0, t7 = 0, acc_t[7] = {0, 0, 0, 0, 0, 0, 0};
+#endif
   for (int s = 0; s < S; ++s) {
     // ---------------- L(s): the partner wave of this SIMD is multiplying ----------------
     __builtin_amdgcn_sched_barrier(0);
+    VQF_STAMP(t0);
     const char* sA = smem + slot * SLOT_BYTES;
     const char* sB = sA + OP_BYTES;
     bf16x8 a0[4], b0[2], a1[4], b1[2];
@@ -327,40 +353,69 @@ __global__ void __launch_bounds__(NT, 2) gemm_bf16_pp_kernel(const BigArgs g) {
     for (int j = 0; j < 2; ++j) b1[j] = read_frag<TB>(sB, wc * 64 + j * 32, 1, lane);
 #pragma unroll
     for (int i = 0; i < 4; ++i) a1[i] = read_frag<TA>(sA, wr * 128 + i * 32, 1, lane);
-    if (s + NSLOT - 1 < S) {                           // slab s+4 into the slot of slab s-1
+    VQF_STAMP(t1);                                     // (stamp builds: the 12 reads have RETURNED here)
+    if (!VQF_PP_GLDS_M && s + NSLOT - 1 < S) {         // slab s+4 into the slot of slab s-1
       const int sl = (slot == 0) ? NSLOT - 1 : slot - 1;
       stage_operand<TA>(qa, g.lda, smem + sl * SLOT_BYTES, wave);
       stage_operand<TB>(qb, g.ldb, smem + sl * SLOT_BYTES + OP_BYTES, wave);
     }
+    VQF_STAMP(t2);
     {                                                  // my copies of slab s+1; later slabs stay in flight
-      const int later = min(s + NSLOT - 1, S - 1) - (s + 1);
+      const int later = min(s + NSLOT - 1 - VQF_PP_GLDS_M, S - 1) - (s + 1);
       if (later >= 3)      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
       else if (later == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    VQF_STAMP(t3);
     __builtin_amdgcn_s_waitcnt(0xC07F);                // lgkmcnt(0): fragments in registers, slot s no longer read by me
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
+    VQF_STAMP(t4);
     // ---------------- M(s): the partner loads ----------------
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b0[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
+    for (int n = 0; n < 16; ++n) {                     // MFMA n: k-step n >> 3, row tile (n >> 1) & 3, column tile n & 1
+      const int i = (n >> 1) & 3, j = n & 1;
+      if (n == 16 - VQF_PP_TAIL) {                     // early hand-over: the partner's MFMAs queue up behind my last ones
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (VQF_PP_GLDS_M && n == 2) {                   // refill copies behind the first MFMAs (their issue overlaps the matrix pipe)
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + NSLOT - 1 < S) {
+          const int sl = (slot == 0) ? NSLOT - 1 : slot - 1;
+          stage_operand<TA>(qa, g.lda, smem + sl * SLOT_BYTES, wave);
+          stage_operand<TB>(qb, g.ldb, smem + sl * SLOT_BYTES + OP_BYTES, wave);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      acc[i][j] = (n < 8) ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b0[j], acc[i][j], 0, 0, 0)
+                          : __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
+    }
     __builtin_amdgcn_s_setprio(0);
+    VQF_STAMP(t5);
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
+    if (VQF_PP_TAIL == 0) __builtin_amdgcn_s_barrier();
+    VQF_STAMP(t6);
+#ifdef VQF_PP_STAMPS
+    acc_t[0] += t1 - t0; acc_t[1] += t2 - t1; acc_t[2] += t3 - t2; acc_t[3] += t4 - t3; acc_t[4] += t5 - t4;
+    acc_t[5] += t6 - t5; acc_t[6] += (s ? t0 - t7 : 0);
+    t7 = t6;
+#endif
     slot = (slot + 1 == NSLOT) ? 0 : slot + 1;
   }
   if (!wr) __builtin_amdgcn_s_barrier();               // waves 0-3 absorb the barrier waves 4-7 spent on the stagger
+#ifdef VQF_PP_STAMPS
+  if (g.dbg && lane == 0) {
+    unsigned long long* d = g.dbg + ((size_t)blockIdx.x * 8 + wave) * 8;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) d[i] = acc_t[i];
+    d[7] = (unsigned long long)S;
+  }
+#endif
 
   // ---- epilogue (as above)
   const int r = lane & 31, h = lane >> 5;
@@ -385,6 +440,198 @@ __global__ void __launch_bounds__(NT, 2) gemm_bf16_pp_kernel(const BigArgs g) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// pp16: the ping-pong loop on v_mfma_f32_16x16x32_bf16, both operands K-contiguous (the projections' forward GEMMs).
+//   * one MFMA covers the slab's whole 32-deep k: a fragment = one ds_read_b128 (lane l: row l & 15, 16-byte chunk
+//     l >> 4 of the 64-byte row); 8 A + 4 B reads and 32 MFMAs of 16 cycles per slab and wave.  The chip holds a higher
+//     clock on this shape than on 32x32x16 (MI355X_MICROARCH.md, DVFS give-back item 7).
+//   * chunk swizzle g(row) = (-(row >> 2)) & 3 on the copy's source address and on the read: the four 16-lane phases of
+//     a ds_read_b128 ({0-3,12-15,20-27}, ...) then hit 16 distinct 16-byte slots for this lane -> (row, chunk) map.
+//   * the wave's 64 columns are INTERLEAVED over its 4 column tiles (column 4c + j belongs to tile j, MFMA column c):
+//     the copy of the B slab permutes rows on its per-lane SOURCE address (LDS row 16j + c holds B row 4c + j), the
+//     loop is unchanged, and a lane's four column tiles are 16 contiguous output bytes: 32 global_store_dwordx4
+//     (bf16 output: dwordx2) per lane instead of 128 dword (short) stores -- the epilogue is store-issue bound.
+__device__ __forceinline__ int swz16(int row) { return (0 - (row >> 2)) & 3; }
+
+template <bool IS_B>
+__device__ __forceinline__ void init_src16(gbf16* (&q)[NG], const bf16_t* base, int ld, int r0, int R, int k0,
+                                           int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < NG; ++i) {
+    const int rho = i * 128 + wave * 16 + (lane >> 2);           // LDS row this lane's 16 bytes land in
+    const int chunk = (lane & 3) ^ swz16(rho);
+    int row = rho;
+    if (IS_B) { const int sig = rho & 63; row = (rho & ~63) + 4 * (sig & 15) + (sig >> 4); }   // strip row 16j + c <- column 4c + j
+    q[i] = (gbf16*)(base + (long long)min(r0 + row, R - 1) * ld + k0 + chunk * 8);
+  }
+}
+
+__device__ __forceinline__ bf16x8 read_frag16(const char* s, int row0, int lane) {
+  const int row = row0 + (lane & 15);
+  return *reinterpret_cast<const bf16x8*>(s + row * 64 + (((lane >> 4) ^ swz16(row)) << 4));
+}
+
+template <bool GUARD_M, bool VEC, typename OT>
+__device__ __forceinline__ void store_tile16(const BigArgs& g, OT* C, const f32x4 (&acc)[8][4], int row0, int col0,
+                                             int lane, bool relu, bool use_bias) {
+  const int cm = lane & 15, rq = lane >> 4;
+  const int col = col0 + 4 * cm;                                  // this lane's 4 consecutive output columns
+  float bv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bv[j] = (use_bias && col + j < g.N) ? g.bias[col + j] : 0.f;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the biases, once: no wait may sit between the stores
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = row0 + 16 * i + 4 * rq + e;
+      if (GUARD_M && row >= g.M) continue;
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[j] = acc[i][j][e] + bv[j];
+        if (relu) v[j] = fmaxf(v[j], 0.f);
+      }
+      OT* cp = C + (long long)row * g.ldc + col;
+      if (VEC) {
+        if (col < g.N) {
+          if (sizeof(OT) == 4) {
+            *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
+          } else {
+            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+            *reinterpret_cast<bf16x4*>(cp) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (col + j < g.N) cp[j] = (OT)v[j];
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(NT, 2) gemm_bf16_pp16_kernel(const BigArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;             // rows wr*128 .. +127, column strip wc*64 .. +63
+
+  const int ntiles = g.tiles_m * g.tiles_n;
+  const int z = blockIdx.x / ntiles;
+  int id = blockIdx.x % ntiles;
+  {
+    const int q8 = ntiles / 8, r8 = ntiles % 8, xcd = id % 8, k = id / 8;
+    id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
+  }
+  const int per_group = GROUP_M * g.tiles_n;
+  const int grp = id / per_group, in = id % per_group;
+  const int gm0 = grp * GROUP_M;
+  const int gsz = min(GROUP_M, g.tiles_m - gm0);
+  const int tm = gm0 + in % gsz, tn = in / gsz;
+  const int m0 = tm * TM, n0 = tn * TN;
+  const int kbeg = z * g.kchunk;
+  const int S = (min(g.K, kbeg + g.kchunk) - kbeg) / TK;       // slabs of this split (uniform over the workgroup)
+
+  gbf16* qa[NG];
+  gbf16* qb[NG];
+  init_src16<false>(qa, g.A, g.lda, m0, g.M, kbeg, wave, lane);
+  init_src16<true>(qb, g.B, g.ldb, n0, g.N, kbeg, wave, lane);
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int p = 0; p < NSLOT - 1; ++p)
+    if (p < S) {
+      stage_operand<false>(qa, g.lda, smem + p * SLOT_BYTES, wave);
+      stage_operand<false>(qb, g.ldb, smem + p * SLOT_BYTES + OP_BYTES, wave);
+    }
+  {                                                    // my copies of slab 0 (4 per slab and thread)
+    const int later = min(NSLOT - 1, S) - 1;
+    if (later >= 3)      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (later == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();                        // #0: every wave's copies of slab 0 have landed
+  if (wr) __builtin_amdgcn_s_barrier();                // waves 4-7 fall half a slab behind (wave-uniform branch)
+
+  int slot = 0;                                        // slot of slab s
+  for (int s = 0; s < S; ++s) {
+    // ---------------- L(s) ----------------
+    __builtin_amdgcn_sched_barrier(0);
+    const char* sA = smem + slot * SLOT_BYTES;
+    const char* sB = sA + OP_BYTES;
+    bf16x8 a[8], b[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[j] = read_frag16(sB, wc * 64 + 16 * j, lane);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = read_frag16(sA, wr * 128 + 16 * i, lane);
+    if (!VQF_PP_GLDS_M && s + NSLOT - 1 < S) {         // slab s+4 into the slot of slab s-1
+      const int sl = (slot == 0) ? NSLOT - 1 : slot - 1;
+      stage_operand<false>(qa, g.lda, smem + sl * SLOT_BYTES, wave);
+      stage_operand<false>(qb, g.ldb, smem + sl * SLOT_BYTES + OP_BYTES, wave);
+    }
+    {                                                  // my copies of slab s+1; later slabs stay in flight
+      const int later = min(s + NSLOT - 1 - VQF_PP_GLDS_M, S - 1) - (s + 1);
+      if (later >= 3)      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else if (later == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);                // lgkmcnt(0): fragments in registers, slot s no longer read by me
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // ---------------- M(s) ----------------
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int n = 0; n < 32; ++n) {                     // MFMA n: row tile n >> 2, column tile n & 3
+      const int i = n >> 2, j = n & 3;
+      if (VQF_PP_GLDS_M && n == 4) {                   // refill copies behind the first MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + NSLOT - 1 < S) {
+          const int sl = (slot == 0) ? NSLOT - 1 : slot - 1;
+          stage_operand<false>(qa, g.lda, smem + sl * SLOT_BYTES, wave);
+          stage_operand<false>(qb, g.ldb, smem + sl * SLOT_BYTES + OP_BYTES, wave);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    slot = (slot + 1 == NSLOT) ? 0 : slot + 1;
+  }
+  if (!wr) __builtin_amdgcn_s_barrier();               // waves 0-3 absorb the barrier waves 4-7 spent on the stagger
+
+  const bool split = g.splits > 1;
+  const bool relu = !split && (g.flags & VQF_GEMM_RELU) != 0;
+  const bool use_bias = !split && g.bias != nullptr;
+  const int row0 = m0 + wr * 128, col0 = n0 + wc * 64;
+  const bool full = m0 + TM <= g.M;
+  if (g.flags & VQF_GEMM_OUT_BF16) {                   // bf16 storage of the result (round-to-nearest-even), never with split-K
+    __bf16* Cb = reinterpret_cast<__bf16*>(g.C);
+    const bool vec = (g.N % 4 == 0) && (g.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(Cb) & 7) == 0);
+    if (vec) { if (full) store_tile16<false, true>(g, Cb, acc, row0, col0, lane, relu, use_bias);
+               else      store_tile16<true, true>(g, Cb, acc, row0, col0, lane, relu, use_bias); }
+    else     { store_tile16<true, false>(g, Cb, acc, row0, col0, lane, relu, use_bias); }
+  } else {
+    float* C = split ? g.C + (size_t)z * g.M * g.N : g.C;
+    const bool vec = (g.N % 4 == 0) && (g.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
+                     (!split || (((size_t)g.M * g.N) % 4 == 0));
+    if (vec) { if (full) store_tile16<false, true>(g, C, acc, row0, col0, lane, relu, use_bias);
+               else      store_tile16<true, true>(g, C, acc, row0, col0, lane, relu, use_bias); }
+    else     { store_tile16<true, false>(g, C, acc, row0, col0, lane, relu, use_bias); }
+  }
+}
+
 int pick_splits(int tiles, int K, int M, int N, size_t ws_bytes) {
   if (tiles >= 768) return 1;
   int best = 1;
@@ -406,6 +653,12 @@ int launch(const BigArgs& g, hipStream_t s) {
   static VqfDynLdsFlags attr = {}, attr_pp = {};
   const char* ppe = getenv("VQF_GEMM_BF16_PP");        // A/B switch, read per launch (tools/gemm_bf16_ab.py flips it
   const bool pingpong = !(ppe && ppe[0] == '0');       // in one process): 0 selects the lockstep kernel of round 1
+  if (pingpong && !TA && !TB && !(ppe && ppe[0] == '3')) {   // VQF_GEMM_BF16_PP=3: the 32x32x16 ping-pong loop also for (0,0)
+    static VqfDynLdsFlags attr16 = {};
+    if (int e = vqf_set_dyn_lds(reinterpret_cast<const void*>(&gemm_bf16_pp16_kernel), SMEM_BIG, attr16)) return e;
+    VQF_LAUNCH(KID_GEMM_BF16, gemm_bf16_pp16_kernel, dim3(g.tiles_m * g.tiles_n * g.splits), dim3(NT), SMEM_BIG, s, g);
+    return vqf_last_error();
+  }
   if (pingpong) {
     if (int e = vqf_set_dyn_lds(reinterpret_cast<const void*>(&gemm_bf16_pp_kernel<TA, TB>), SMEM_BIG, attr_pp)) return e;
     VQF_LAUNCH(KID_GEMM_BF16, (gemm_bf16_pp_kernel<TA, TB>), dim3(g.tiles_m * g.tiles_n * g.splits), dim3(NT), SMEM_BIG,
@@ -457,6 +710,9 @@ int vqf_gemm_bf16_big_try(int ta, int tb, int M, int N, int K, const void* A, in
   splits = (K + g.kchunk - 1) / g.kchunk;
   g.splits = splits;
   if (splits > 1) { g.C = (float*)ws; g.ldc = N; }
+#ifdef VQF_PP_STAMPS
+  g.dbg = (splits == 1 && ws && ws_bytes >= (size_t)tiles * 8 * 8 * 8) ? (unsigned long long*)ws : nullptr;
+#endif
   vqf_prof_dims(M, N, K);
   if (ta) *rc = tb ? launch<true, true>(g, s) : launch<true, false>(g, s);
   else    *rc = tb ? launch<false, true>(g, s) : launch<false, false>(g, s);

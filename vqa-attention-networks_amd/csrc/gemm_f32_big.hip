@@ -20,9 +20,9 @@
 //     4 rm + i (K-major A) and column 2 cm + j (K-major B), so a lane's two column-tiles are 8 contiguous bytes.
 //     (Round 1 read these fragments as 4 ds_read_b32 per tile and kept the weight gradients on the 128x128 kernel.)
 //   * deterministic split-K for few-tile / long-K shapes (the weight gradient).
-//   * two loop forms: the lockstep loop of round 1 (fragment reads one k-step ahead of the MFMAs, one barrier per
-//     slab) and a ping-pong loop (VQF_GEMM_F32_PP=1; see gemm_bf16_big.hip) in which the two waves of a SIMD run
-//     half a slab apart, one multiplying while the other loads.
+//   * two loop forms: the lockstep loop (default: fragment reads one k-step ahead of the MFMAs, one barrier per slab)
+//     and the ping-pong loop of gemm_bf16_big.hip (VQF_GEMM_F32_PP=1, for A/Bs: with 64-cycle MFMAs the lockstep
+//     form is 5 % faster here).
 // Preconditions (else the caller uses gemm_f32.hip): K % 16 == 0, M >= 256, N >= 128, >= 1024 workgroups (tiles x
 // splits), no accumulate flag, 16-byte aligned bases, lda/ldb % 4 == 0, a K-major operand's row extent % 4 == 0.
 #include "common.h"
@@ -92,187 +92,51 @@ __device__ __forceinline__ void stage_operand(gfloat* (&q)[NG], int ld, char* s,
   }
 }
 
-// Operand values of one slab for the wave's strip (A: 128 rows = 4 tiles, B: 64 columns = 2 tiles).
+// Operand values of one k-step (8 k) of a slab for the wave's strip (A: 128 rows = 4 tiles, B: 64 columns = 2 tiles).
 // MFMA step (ks, e) of a slab multiplies k = 8ks + e (lanes 0-31) and k = 8ks + 4 + e (lanes 32-63): any fixed pairing
 // of the slab's 16 k works as long as both operands use the same one (v_mfma_f32_32x32x2_f32 takes k = 0 from lanes
 // 0-31 and k = 1 from lanes 32-63).
-//   K-contiguous: one ds_read_b128 per (tile, ks): lane (r, h) gets k = 8ks + 4h + e, e = 0..3, of row 32 tile + r.
-//   K-major:      one ds_read_b128 (A) / ds_read_b64 (B) per (ks, e): lane (r, h) gets k-row 8ks + 4h + e, strip rows
+//   K-contiguous: one ds_read_b128 per tile: lane (r, h) gets k = 8ks + 4h + e, e = 0..3, of row 32 tile + r.
+//   K-major:      one ds_read_b128 (A) / ds_read_b64 (B) per e: lane (r, h) gets k-row 8ks + 4h + e, strip rows
 //                 4r .. 4r+3 (columns 2r, 2r+1): element t belongs to tile t (interleaved strip, see the header).
-template <bool T>
-struct FragA {                                           // v(i, ks, e): value of row-tile i for step (ks, e)
-  f32x4 f[TK / 8][4];                                    // K-contiguous: [ks][tile] (e in the vector); K-major: [ks][e] (tile in the vector)
-  __device__ __forceinline__ void load(const char* s, int strip0, int lane) {
-    const int r = lane & 31, h = lane >> 5;
-#pragma unroll
-    for (int ks = 0; ks < TK / 8; ++ks)
-#pragma unroll
-      for (int x = 0; x < 4; ++x)
-        f[ks][x] = T ? *reinterpret_cast<const f32x4*>(s + (8 * ks + 4 * h + x) * 1024 + (strip0 + 4 * r) * 4)
-                     : *reinterpret_cast<const f32x4*>(s + (strip0 + 32 * x + r) * ROW_B + (((2 * ks + h) ^ swz(r)) << 4));
-  }
-  __device__ __forceinline__ float v(int i, int ks, int e) const { return T ? f[ks][e][i] : f[ks][i][e]; }
-};
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <bool T>
-struct FragB {
-  f32x4 fc[TK / 8][2];                                   // K-contiguous: [ks][tile]
-  f32x2 ft[TK / 8][4];                                   // K-major: [ks][e] (tile in the vector)
-  __device__ __forceinline__ void load(const char* s, int strip0, int lane) {
+struct FragA {                                           // v(i, e): value of row-tile i for step e of this k-step
+  f32x4 f[4];                                            // K-contiguous: [tile] (e in the vector); K-major: [e] (tile in the vector)
+  __device__ __forceinline__ void load(const char* s, int strip0, int ks, int lane) {
     const int r = lane & 31, h = lane >> 5;
 #pragma unroll
-    for (int ks = 0; ks < TK / 8; ++ks) {
-      if (T) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          ft[ks][e] = *reinterpret_cast<const f32x2*>(s + (8 * ks + 4 * h + e) * 1024 + (strip0 + 2 * r) * 4);
-      } else {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          fc[ks][j] = *reinterpret_cast<const f32x4*>(s + (strip0 + 32 * j + r) * ROW_B + (((2 * ks + h) ^ swz(r)) << 4));
-      }
-    }
+    for (int x = 0; x < 4; ++x)
+      f[x] = T ? *reinterpret_cast<const f32x4*>(s + (8 * ks + 4 * h + x) * 1024 + (strip0 + 4 * r) * 4)
+               : *reinterpret_cast<const f32x4*>(s + (strip0 + 32 * x + r) * ROW_B + (((2 * ks + h) ^ swz(r)) << 4));
   }
-  __device__ __forceinline__ float v(int j, int ks, int e) const { return T ? ft[ks][e][j] : fc[ks][j][e]; }
+  __device__ __forceinline__ float v(int i, int e) const { return T ? f[e][i] : f[i][e]; }
 };
-
-// round-1 readers (lockstep loop): one tile, one k-step at a time, standard (non-interleaved) strips
 template <bool T>
-__device__ __forceinline__ f32x4 read_frag(const char* s, int row0, int ks, int lane) {
-  const int r = lane & 31, h = lane >> 5;
-  if (!T) return *reinterpret_cast<const f32x4*>(s + (row0 + r) * ROW_B + (((2 * ks + h) ^ swz(r)) << 4));
-  const float* p = reinterpret_cast<const float*>(s) + (8 * ks + 4 * h) * 256 + row0 + r;
-  return f32x4{p[0], p[256], p[512], p[768]};
-}
-
-template <bool GUARD_M>
-__device__ __forceinline__ void store_tile(const BigArgs& g, float* C, const f32x16 (&acc)[4][2], const float (&bv)[2],
-                                           int row_base, int col0, bool relu) {
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int col = col0 + j * 32;
-    if (col >= g.N) continue;
-    float* cp = C + (long long)row_base * g.ldc + col;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int dr = i * 32 + (e & 3) + 8 * (e >> 2);       // compile-time row offset
-        float v = acc[i][j][e] + bv[j];
-        if (relu) v = fmaxf(v, 0.f);
-        if (!GUARD_M || row_base + dr < g.M) cp[(long long)dr * g.ldc] = v;
-      }
-    }
-  }
-}
-
-template <bool TA, bool TB>
-__global__ void __launch_bounds__(NT, 2) gemm_f32_big_kernel(const BigArgs g) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 2, wc = wave & 3;             // rows wr*128 .. +127, columns wc*64 .. +63
-
-  // ---- tile order: split index slowest; bijective XCD remap, then groups of GROUP_M row tiles, m fastest
-  const int ntiles = g.tiles_m * g.tiles_n;
-  const int z = blockIdx.x / ntiles;
-  int id = blockIdx.x % ntiles;
-  {
-    const int q8 = ntiles / 8, r8 = ntiles % 8, xcd = id % 8, k = id / 8;
-    id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
-  }
-  const int per_group = GROUP_M * g.tiles_n;
-  const int grp = id / per_group, in = id % per_group;
-  const int gm0 = grp * GROUP_M;
-  const int gsz = min(GROUP_M, g.tiles_m - gm0);
-  const int tm = gm0 + in % gsz, tn = in / gsz;
-  const int m0 = tm * TM, n0 = tn * TN;
-  const int kbeg = z * g.kchunk;
-  const int S = (min(g.K, kbeg + g.kchunk) - kbeg) / TK;       // slabs of this split
-
-  gfloat* qa[NG];
-  gfloat* qb[NG];
-  init_src<TA>(qa, g.A, g.lda, m0, g.M, kbeg, wave, lane);
-  init_src<TB>(qb, g.B, g.ldb, n0, g.N, kbeg, wave, lane);
-
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-#pragma unroll
-  for (int p = 0; p < NSLOT - 1; ++p)
-    if (p < S) {
-      stage_operand<TA>(qa, g.lda, smem + p * SLOT_BYTES, wave);
-      stage_operand<TB>(qb, g.ldb, smem + p * SLOT_BYTES + OP_BYTES, wave);
-    }
-  int slot = 0;                                        // slot of slab s
-  for (int s = 0; s < S; ++s) {
-    const int later = min(NSLOT - 2, S - 1 - s);       // slabs issued after slab s that may stay in flight
-    static_assert(2 * NG == 4 || NSLOT == 2, "the vmcnt immediates below assume 4 copies per thread per slab");
-    if (later >= 3)      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if (later == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    const char* sA = smem + slot * SLOT_BYTES;
-    const char* sB = sA + OP_BYTES;
-    f32x4 fa[2][4], fb[2][2];                            // fragment double buffer: reads run one k-step ahead
-#pragma unroll
-    for (int i = 0; i < 4; ++i) fa[0][i] = read_frag<TA>(sA, wr * 128 + i * 32, 0, lane);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) fb[0][j] = read_frag<TB>(sB, wc * 64 + j * 32, 0, lane);
-    if (s + NSLOT - 1 < S) {                           // refill the slot of slab s-1 (its address math hides LDS latency)
-      const int sl = (slot == 0) ? NSLOT - 1 : slot - 1;
-      stage_operand<TA>(qa, g.lda, smem + sl * SLOT_BYTES, wave);
-      stage_operand<TB>(qb, g.ldb, smem + sl * SLOT_BYTES + OP_BYTES, wave);
-    }
-#pragma unroll
-    for (int ks = 0; ks < TK / 8; ++ks) {
-      if (ks + 1 < TK / 8) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fa[(ks + 1) & 1][i] = read_frag<TA>(sA, wr * 128 + i * 32, ks + 1, lane);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) fb[(ks + 1) & 1][j] = read_frag<TB>(sB, wc * 64 + j * 32, ks + 1, lane);
-      }
+struct FragB {
+  f32x4 fc[2];                                           // K-contiguous: [tile]
+  f32x2 ft[4];                                           // K-major: [e] (tile in the vector)
+  __device__ __forceinline__ void load(const char* s, int strip0, int ks, int lane) {
+    const int r = lane & 31, h = lane >> 5;
+    if (T) {
 #pragma unroll
       for (int e = 0; e < 4; ++e)
+        ft[e] = *reinterpret_cast<const f32x2*>(s + (8 * ks + 4 * h + e) * 1024 + (strip0 + 2 * r) * 4);
+    } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ks & 1][i][e], fb[ks & 1][j][e], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < 2; ++j)
+        fc[j] = *reinterpret_cast<const f32x4*>(s + (strip0 + 32 * j + r) * ROW_B + (((2 * ks + h) ^ swz(r)) << 4));
     }
-    slot = (slot + 1 == NSLOT) ? 0 : slot + 1;
   }
-
-  // ---- epilogue: D[row = (e & 3) + 8 (e >> 2) + 4 h][col = lane & 31]; a half-wave stores 128 contiguous bytes
-  const int r = lane & 31, h = lane >> 5;
-  const bool split = g.splits > 1;
-  const bool relu = !split && (g.flags & VQF_GEMM_RELU) != 0;
-  float* C = split ? g.C + (size_t)z * g.M * g.N : g.C;
-  float bv[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int col = n0 + wc * 64 + j * 32 + r;
-    bv[j] = (!split && g.bias && col < g.N) ? g.bias[col] : 0.f;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the biases, once: no wait may sit between the stores
-  const int row_base = m0 + wr * 128 + 4 * h;
-  if (m0 + TM <= g.M) store_tile<false>(g, C, acc, bv, row_base, n0 + wc * 64 + r, relu);
-  else                store_tile<true>(g, C, acc, bv, row_base, n0 + wc * 64 + r, relu);
-}
-
+  __device__ __forceinline__ float v(int j, int e) const { return T ? ft[e][j] : fc[j][e]; }
+};
 
 // accumulator tile (i, j), register e, lane (cm = lane & 31, h = lane >> 5): MFMA row rm = (e & 3) + 8 (e >> 2) + 4h,
 // MFMA column cm.  Output row = strip row 4 rm + i (K-major A: interleaved strip) or 32 i + rm; output column =
 // strip column 2 cm + j (K-major B) or 32 j + cm.
 template <bool TA, bool TB, bool GUARD_M>
-__device__ __forceinline__ void store_tile_pp(const BigArgs& g, float* C, const f32x16 (&acc)[4][2], int row0, int col0,
-                                              int lane, bool relu, bool use_bias) {
+__device__ __forceinline__ void store_tile(const BigArgs& g, float* C, const f32x16 (&acc)[4][2], int row0, int col0,
+                                           int lane, bool relu, bool use_bias) {
   const int cm = lane & 31, h = lane >> 5;
   float bv[2];
 #pragma unroll
@@ -291,8 +155,11 @@ __device__ __forceinline__ void store_tile_pp(const BigArgs& g, float* C, const 
       float v0 = acc[i][0][e] + bv[0], v1 = acc[i][1][e] + bv[1];
       if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
       float* cp = C + (long long)row * g.ldc + col0;
-      if (TB) {
-        if (col0 + 2 * cm < g.N) *reinterpret_cast<f32x2*>(cp + 2 * cm) = f32x2{v0, v1};   // N % 4 == 0, ldc even: 8-byte aligned
+      if (TB) {      // N % 4 == 0; an odd ldc (row-strided output view) falls back to two dword stores
+        if (col0 + 2 * cm < g.N) {
+          if ((g.ldc & 1) == 0 && (reinterpret_cast<uintptr_t>(C) & 7) == 0) *reinterpret_cast<f32x2*>(cp + 2 * cm) = f32x2{v0, v1};
+          else { cp[2 * cm] = v0; cp[2 * cm + 1] = v1; }
+        }
       } else {
         if (col0 + cm < g.N) cp[cm] = v0;
         if (col0 + 32 + cm < g.N) cp[32 + cm] = v1;
@@ -301,15 +168,26 @@ __device__ __forceinline__ void store_tile_pp(const BigArgs& g, float* C, const 
   }
 }
 
-// Ping-pong form (round 2): see gemm_bf16_big.hip for the schedule and its hazard argument; identical here with
-// 64 MFMAs of 64 cycles per M segment, all fragments of the slab (12 or 16 LDS reads) taken in the L segment.
-template <bool TA, bool TB>
-__global__ void __launch_bounds__(NT, 2) gemm_f32_pp_kernel(const BigArgs g) {
+__device__ __forceinline__ void wait_copies(int later) {     // all but the 4 * later youngest LDS-DMA copies of this wave have landed
+  static_assert(2 * NG == 4 || NSLOT == 2, "the vmcnt immediates below assume 4 copies per thread per slab");
+  if (later >= 3)      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if (later == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// PP = false: lockstep loop (one barrier per slab, fragment reads one k-step ahead of the MFMAs; both waves of a SIMD
+//             interleave their MFMAs on the matrix pipe) -- the faster form for fp32, whose 64-cycle MFMAs make the
+//             per-slab overheads small (136 vs 129 TFLOP/s on the image projection).
+// PP = true:  ping-pong loop of gemm_bf16_big.hip (kept for A/Bs: VQF_GEMM_F32_PP=1).
+template <bool TA, bool TB, bool PP>
+__global__ void __launch_bounds__(NT, 2) gemm_f32_big_kernel(const BigArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;             // strip rows wr*128 .. +127, strip columns wc*64 .. +63
 
+  // ---- tile order: split index slowest; bijective XCD remap, then groups of GROUP_M row tiles, m fastest
   const int ntiles = g.tiles_m * g.tiles_n;
   const int z = blockIdx.x / ntiles;
   int id = blockIdx.x % ntiles;
@@ -339,73 +217,96 @@ __global__ void __launch_bounds__(NT, 2) gemm_f32_pp_kernel(const BigArgs g) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  static_assert(2 * NG == 4 && NSLOT == 5 && TK == 16, "the ping-pong loop assumes 4 copies per thread per slab, 5 slots");
 #pragma unroll
   for (int p = 0; p < NSLOT - 1; ++p)
     if (p < S) {
       stage_operand<TA>(qa, g.lda, smem + p * SLOT_BYTES, wave);
       stage_operand<TB>(qb, g.ldb, smem + p * SLOT_BYTES + OP_BYTES, wave);
     }
-  {                                                    // my copies of slab 0
-    const int later = min(NSLOT - 1, S) - 1;
-    if (later >= 3)      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if (later == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __builtin_amdgcn_s_barrier();                        // #0: every wave's copies of slab 0 have landed
-  if (wr) __builtin_amdgcn_s_barrier();                // waves 4-7 fall half a slab behind (wave-uniform branch)
-
-  int slot = 0;
-  for (int s = 0; s < S; ++s) {
-    // ---------------- L(s) ----------------
-    __builtin_amdgcn_sched_barrier(0);
-    const char* sA = smem + slot * SLOT_BYTES;
-    const char* sB = sA + OP_BYTES;
-    FragA<TA> fa;
-    FragB<TB> fb;
-    fb.load(sB, wc * 64, lane);
-    fa.load(sA, wr * 128, lane);
-    if (s + NSLOT - 1 < S) {                           // slab s+4 into the slot of slab s-1
-      const int sl = (slot == 0) ? NSLOT - 1 : slot - 1;
-      stage_operand<TA>(qa, g.lda, smem + sl * SLOT_BYTES, wave);
-      stage_operand<TB>(qb, g.ldb, smem + sl * SLOT_BYTES + OP_BYTES, wave);
+  int slot = 0;                                        // slot of slab s
+  if (!PP) {
+    for (int s = 0; s < S; ++s) {
+      wait_copies(min(NSLOT - 2, S - 1 - s));          // my copies of slab s; later slabs stay in flight
+      __builtin_amdgcn_s_barrier();
+      const char* sA = smem + slot * SLOT_BYTES;
+      const char* sB = sA + OP_BYTES;
+      FragA<TA> fa[2];                                 // fragment double buffer: reads run one k-step ahead
+      FragB<TB> fb[2];
+      fa[0].load(sA, wr * 128, 0, lane);
+      fb[0].load(sB, wc * 64, 0, lane);
+      if (s + NSLOT - 1 < S) {                         // refill the slot of slab s-1 (its address math hides LDS latency)
+        const int sl = (slot == 0) ? NSLOT - 1 : slot - 1;
+        stage_operand<TA>(qa, g.lda, smem + sl * SLOT_BYTES, wave);
+        stage_operand<TB>(qb, g.ldb, smem + sl * SLOT_BYTES + OP_BYTES, wave);
+      }
+#pragma unroll
+      for (int ks = 0; ks < TK / 8; ++ks) {
+        if (ks + 1 < TK / 8) {
+          fa[(ks + 1) & 1].load(sA, wr * 128, ks + 1, lane);
+          fb[(ks + 1) & 1].load(sB, wc * 64, ks + 1, lane);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ks & 1].v(i, e), fb[ks & 1].v(j, e), acc[i][j], 0, 0, 0);
+      }
+      slot = (slot + 1 == NSLOT) ? 0 : slot + 1;
     }
-    {                                                  // my copies of slab s+1; later slabs stay in flight
-      const int later = min(s + NSLOT - 1, S - 1) - (s + 1);
-      if (later >= 3)      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-      else if (later == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    static_assert(!PP || (2 * NG == 4 && NSLOT == 5 && TK == 16), "the ping-pong loop assumes 4 copies per thread per slab, 5 slots");
+    wait_copies(min(NSLOT - 1, S) - 1);                // my copies of slab 0
+    __builtin_amdgcn_s_barrier();                      // #0: every wave's copies of slab 0 have landed
+    if (wr) __builtin_amdgcn_s_barrier();              // waves 4-7 fall half a slab behind (wave-uniform branch)
+    for (int s = 0; s < S; ++s) {
+      // ---------------- L(s) ----------------
+      __builtin_amdgcn_sched_barrier(0);
+      const char* sA = smem + slot * SLOT_BYTES;
+      const char* sB = sA + OP_BYTES;
+      FragA<TA> fa[2];
+      FragB<TB> fb[2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        fb[ks].load(sB, wc * 64, ks, lane);
+        fa[ks].load(sA, wr * 128, ks, lane);
+      }
+      if (s + NSLOT - 1 < S) {                         // slab s+4 into the slot of slab s-1
+        const int sl = (slot == 0) ? NSLOT - 1 : slot - 1;
+        stage_operand<TA>(qa, g.lda, smem + sl * SLOT_BYTES, wave);
+        stage_operand<TB>(qb, g.ldb, smem + sl * SLOT_BYTES + OP_BYTES, wave);
+      }
+      wait_copies(min(s + NSLOT - 1, S - 1) - (s + 1));   // my copies of slab s+1; later slabs stay in flight
+      __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0)
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      // ---------------- M(s) ----------------
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ks].v(i, e), fb[ks].v(j, e), acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      slot = (slot + 1 == NSLOT) ? 0 : slot + 1;
     }
-    __builtin_amdgcn_s_waitcnt(0xC07F);                // lgkmcnt(0)
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    // ---------------- M(s) ----------------
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < TK / 8; ++ks)
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.v(i, ks, e), fb.v(j, ks, e), acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    slot = (slot + 1 == NSLOT) ? 0 : slot + 1;
+    if (!wr) __builtin_amdgcn_s_barrier();             // waves 0-3 absorb the barrier waves 4-7 spent on the stagger
   }
-  if (!wr) __builtin_amdgcn_s_barrier();               // waves 0-3 absorb the barrier waves 4-7 spent on the stagger
 
   const bool split = g.splits > 1;
   const bool relu = !split && (g.flags & VQF_GEMM_RELU) != 0;
   float* C = split ? g.C + (size_t)z * g.M * g.N : g.C;
   const bool use_bias = !split && g.bias != nullptr;
-  if (m0 + TM <= g.M) store_tile_pp<TA, TB, false>(g, C, acc, m0 + wr * 128, n0 + wc * 64, lane, relu, use_bias);
-  else                store_tile_pp<TA, TB, true>(g, C, acc, m0 + wr * 128, n0 + wc * 64, lane, relu, use_bias);
+  if (m0 + TM <= g.M) store_tile<TA, TB, false>(g, C, acc, m0 + wr * 128, n0 + wc * 64, lane, relu, use_bias);
+  else                store_tile<TA, TB, true>(g, C, acc, m0 + wr * 128, n0 + wc * 64, lane, relu, use_bias);
 }
 
 // split count that minimises (rounds of 256 one-per-CU workgroups) x (time of one workgroup) + slab traffic, in
@@ -431,21 +332,23 @@ template <bool TA, bool TB>
 int launch(const BigArgs& g, hipStream_t s) {
   // > 64 KB of dynamic LDS needs the attribute, once per device and instantiation (common.h)
   static VqfDynLdsFlags attr = {}, attr_pp = {};
-  // loop form, read per launch so that tools can A/B in one process: VQF_GEMM_F32_PP=0 lockstep (round 1), 1 ping-pong.
-  // K-major operands always take the ping-pong kernel (interleaved strips, one wide LDS read per k-pair).
-  const char* ppe = getenv("VQF_GEMM_F32_PP");
-  const bool pingpong = (TA || TB) ? !(ppe && ppe[0] == '0' && ppe[1] == '0') : !(ppe && ppe[0] == '0');
+  const char* ppe = getenv("VQF_GEMM_F32_PP");         // A/B switch, read per launch: 1 selects the ping-pong loop
+  const bool pingpong = ppe && ppe[0] == '1';
   const int kid = KID_GEMM_A0B0 + 2 * (TA ? 1 : 0) + (TB ? 1 : 0);
+  const dim3 grid(g.tiles_m * g.tiles_n * g.splits);
   if (pingpong) {
-    if (int e = vqf_set_dyn_lds(reinterpret_cast<const void*>(&gemm_f32_pp_kernel<TA, TB>), SMEM_BIG, attr_pp)) return e;
-    VQF_LAUNCH(kid, (gemm_f32_pp_kernel<TA, TB>), dim3(g.tiles_m * g.tiles_n * g.splits), dim3(NT), SMEM_BIG, s, g);
+    if (int e = vqf_set_dyn_lds(reinterpret_cast<const void*>(&gemm_f32_big_kernel<TA, TB, true>), SMEM_BIG, attr_pp)) return e;
+    VQF_LAUNCH(kid, (gemm_f32_big_kernel<TA, TB, true>), grid, dim3(NT), SMEM_BIG, s, g);
     return vqf_last_error();
   }
-  if (int e = vqf_set_dyn_lds(reinterpret_cast<const void*>(&gemm_f32_big_kernel<TA, TB>), SMEM_BIG, attr)) return e;
-  VQF_LAUNCH(kid, (gemm_f32_big_kernel<TA, TB>), dim3(g.tiles_m * g.tiles_n * g.splits), dim3(NT), SMEM_BIG, s, g);
+  if (int e = vqf_set_dyn_lds(reinterpret_cast<const void*>(&gemm_f32_big_kernel<TA, TB, false>), SMEM_BIG, attr)) return e;
+  VQF_LAUNCH(kid, (gemm_f32_big_kernel<TA, TB, false>), grid, dim3(NT), SMEM_BIG, s, g);
   return vqf_last_error();
 }
 
+#ifndef F32BIG_WGRAD_MIN_BLOCKS
+#define F32BIG_WGRAD_MIN_BLOCKS 768
+#endif
 bool big_applies(int ta, int tb, int M, int N, int K, int flags, size_t ws_bytes) {
   const char* e = getenv("VQF_GEMM_F32_BIG");        // A/B switch, read per launch: 0 selects the 128x128 kernel everywhere
   const bool enabled = !(e && e[0] == '0');
@@ -455,10 +358,11 @@ bool big_applies(int ta, int tb, int M, int N, int K, int flags, size_t ws_bytes
   // Only the large projections: a workgroup that needs a whole CU's LDS starts when the CU has drained, which
   // costs mid-size launches more than the kernel gains (HieCoAtten, 392-tile GEMMs: step 5.57 -> 5.77 ms) ...
   const int tiles = ((M + TM - 1) / TM) * ((N + TN - 1) / TN);
-  if (tiles >= 1024) return true;
+  // (and a K long enough to amortise the tile's prologue / 256 KB epilogue: at K = 1024 the 128x128 kernel is 5 % faster)
+  if (tiles >= 1024) return K >= 1536;
   // ... and the deep-K weight gradients (both operands K-major, few tiles, K = N*L): img_conv1d's 20 x 8 tiles x 8
   // splits of 784 slabs each.  co_att_conv1's 4 x 4 tiles stay on the 128x128 kernel (64 tiles x 4 splits).
-  if (ta && tb && K >= 16384 && tiles * pick_splits(tiles, K, M, N, ws_bytes) >= 768) return true;   // needs its slabs
+  if (ta && tb && K >= 16384 && tiles * pick_splits(tiles, K, M, N, ws_bytes) >= F32BIG_WGRAD_MIN_BLOCKS) return true;   // needs its slabs
   return false;
 }
 

@@ -126,8 +126,10 @@ def gemm_bf16(a, b, ta=False, tb=False, bias=None, relu=False, M=None, N=None, K
     out_bf16: store C as bf16 (large-tile kernel only); returns None when that kernel does not apply."""
     _chk_bf16(a, b)
     _chk(bias)
-    if out is not None:
-        (_chk_bf16 if out_bf16 else _chk)(out)
+    if out is not None:          # 2-D, rows may be strided (the ABI takes ldc)
+        want = torch.bfloat16 if out_bf16 else torch.float32
+        if not out.is_cuda or out.dtype != want or out.dim() != 2 or out.stride(1) != 1:
+            raise _l.VqfError("gemm_bf16: out must be a 2-D %s GPU tensor with contiguous rows" % want)
     if M is None:
         M = a.shape[1] if ta else a.shape[0]
     if K is None:
