@@ -255,3 +255,40 @@ def test_gemm_large_tile_kernel_splitk_relu_bias(ops, ta, tb):
     assert _rel(out, ref) <= 2e-5
     out2 = ops.gemm(A.float().cuda(), B.float().cuda(), ta=bool(ta), tb=bool(tb), bias=bias.float().cuda(), relu=True)
     assert torch.equal(out, out2)                       # fixed-order slab reduction: run-to-run identical
+
+
+# small-M products (gemm_f32_wave.hip: one 32x64 tile per wave, WK = 1 whole K per wave / WK = 4 in-workgroup K split)
+WAVE_SHAPES = [  # (tb, M, N, K, what)
+    (0, 512, 4096, 1024, "LSTM forward recurrent product: 1024 wave tiles, WK = 1"),
+    (1, 512, 1024, 4096, "LSTM backward recurrent product: 256 wave tiles x 4 K ranges, WK = 4"),
+    (0, 500, 4090, 1024, "ragged M and N (row clamp / guarded stores, odd N -> scalar tail)"),
+    (1, 509, 1020, 4096, "ragged, K-major B, WK = 4"),
+    (0, 256, 2048, 2048, "WK = 4 with a K-contiguous B"),
+    (1, 1000, 2048, 512, "WK = 1 with a K-major B, M up to 1024"),
+]
+
+
+@pytest.mark.parametrize("tb,M,N,K,what", WAVE_SHAPES)
+def test_gemm_small_m_wave_kernel(ops, tb, M, N, K, what):
+    A, B, bias = _rand((M, K), 31), _rand((K, N) if tb else (N, K), 32), _rand((N,), 33)
+    ref = A @ (B if tb else B.t())
+    tol = 2e-6 * max(1.0, np.sqrt(K) / 8)
+    Ad, Bd = A.float().cuda(), B.float().cuda()
+    out = ops.gemm(Ad, Bd, tb=bool(tb))
+    assert _rel(out, ref) <= tol, (what, _rel(out, ref))
+    import os
+    os.environ["VQF_GEMM_F32_WAVE"] = "0"                      # the 128x128 split-K path on the same operands
+    try:
+        old = ops.gemm(Ad, Bd, tb=bool(tb))
+    finally:
+        del os.environ["VQF_GEMM_F32_WAVE"]
+    assert _rel(old, ref) <= tol and not torch.equal(old, out), "the wave kernel did not take this shape"
+    assert torch.equal(out, ops.gemm(Ad, Bd, tb=bool(tb)))      # fixed-order in-workgroup K reduction
+    # bias + relu, and accumulate into a row-strided output view (LstmBatchFn adds into xw[t])
+    out2 = ops.gemm(Ad, Bd, tb=bool(tb), bias=bias.float().cuda(), relu=True)
+    assert _rel(out2, torch.relu(ref + bias)) <= tol
+    C0 = _rand((M, N + 3), 34)
+    wide = C0.float().cuda().clone()
+    ops.gemm(Ad, Bd, tb=bool(tb), out=wide[:, 1:N + 1], accumulate=True)
+    assert _rel(wide[:, 1:N + 1], ref + C0[:, 1:N + 1]) <= tol
+    assert torch.equal(wide[:, 0].cpu(), C0[:, 0].float()) and torch.equal(wide[:, N + 1:].cpu(), C0[:, N + 1:].float())

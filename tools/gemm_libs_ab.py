@@ -17,7 +17,8 @@ for kv in filter(None, args.env.split(",")):
     k, v = kv.split("=")
     os.environ[k] = v
 SH = {"fwd": (0, 0, 100352, 5000, 2048), "wgrad": (1, 1, 5000, 2048, 100352), "coatt_fwd": (0, 0, 100352, 1024, 1024),
-      "coatt_dgrad": (0, 1, 100352, 1024, 1024), "sq": (0, 0, 8192, 8192, 8192)}
+      "coatt_dgrad": (0, 1, 100352, 1024, 1024), "sq": (0, 0, 8192, 8192, 8192),
+      "coatt_wgrad": (1, 1, 1024, 1000, 100352), "coatt_wgrad512": (1, 1, 512, 1000, 100352)}
 dev = torch.device("cuda")
 bf = args.dtype == "bf16"
 libs = []

@@ -74,6 +74,9 @@ size_t vqf_gemm_bf16_big_ws_bytes(int ta, int tb, int M, int N, int K);
 int vqf_gemm_f32_big_try(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
                          int ldc, const float* bias, int flags, void* ws, size_t ws_bytes, hipStream_t s, int* rc);
 size_t vqf_gemm_f32_big_ws_bytes(int ta, int tb, int M, int N, int K);
+// gemm_f32_wave.hip: small-M products, one 32x64 tile per wave, no split-K slabs; returns 0 when it does not apply
+int vqf_gemm_f32_wave_try(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
+                          int ldc, const float* bias, int flags, hipStream_t s, int* rc);
 
 static inline int vqf_last_error() {
   hipError_t e = hipGetLastError();

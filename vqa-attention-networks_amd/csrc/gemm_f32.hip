@@ -509,6 +509,8 @@ extern "C" int vqf_gemm_f32(int ta, int tb, int M, int N, int K, const float* A,
   if (aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0)) {
     int rc = VQF_OK;      // large shapes take the 256x256-tile LDS-DMA kernel (gemm_f32_big.hip)
     if (vqf_gemm_f32_big_try(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, ws, ws_bytes, s, &rc)) return rc;
+    // small-M products (the LSTM's recurrent GEMMs): one tile per wave, no split-K slabs / reduce launch (gemm_f32_wave.hip)
+    if (vqf_gemm_f32_wave_try(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, s, &rc)) return rc;
   }
   GemmArgs g;
   g.A = A; g.B = B; g.C = C; g.bias = bias; g.slab = nullptr;

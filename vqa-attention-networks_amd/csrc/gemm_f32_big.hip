@@ -347,7 +347,7 @@ int launch(const BigArgs& g, hipStream_t s) {
 }
 
 #ifndef F32BIG_WGRAD_MIN_BLOCKS
-#define F32BIG_WGRAD_MIN_BLOCKS 768
+#define F32BIG_WGRAD_MIN_BLOCKS 256   // co_att_conv1's wgrad: 16 tiles x 16 splits = one full round, 1.71 -> 1.52 ms
 #endif
 bool big_applies(int ta, int tb, int M, int N, int K, int flags, size_t ws_bytes) {
   const char* e = getenv("VQF_GEMM_F32_BIG");        // A/B switch, read per launch: 0 selects the 128x128 kernel everywhere
@@ -361,7 +361,7 @@ bool big_applies(int ta, int tb, int M, int N, int K, int flags, size_t ws_bytes
   // (and a K long enough to amortise the tile's prologue / 256 KB epilogue: at K = 1024 the 128x128 kernel is 5 % faster)
   if (tiles >= 1024) return K >= 1536;
   // ... and the deep-K weight gradients (both operands K-major, few tiles, K = N*L): img_conv1d's 20 x 8 tiles x 8
-  // splits of 784 slabs each.  co_att_conv1's 4 x 4 tiles stay on the 128x128 kernel (64 tiles x 4 splits).
+  // splits of 784 slabs each, co_att_conv1's 4 x 4 tiles x 16 splits (one workgroup per CU, 392 slabs each).
   if (ta && tb && K >= 16384 && tiles * pick_splits(tiles, K, M, N, ws_bytes) >= F32BIG_WGRAD_MIN_BLOCKS) return true;   // needs its slabs
   return false;
 }

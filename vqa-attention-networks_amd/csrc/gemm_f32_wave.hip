@@ -1,0 +1,272 @@
+// Small-M fp32 GEMM (gfx950 only): the products whose output has too few 128x128 tiles to fill 256 CUs
+// -- above all the 26 recurrent products of the question encoder's LSTM per train step,
+//    gates_t += h_{t-1} W_hh^T   (512 x 4096 x 1024, accumulate)        mfb.py:69 via host/functions.py::LstmBatchFn
+//    dh_{t-1} = dG_t W_hh        (512 x 1024 x 4096, B K-major)
+// which the 128x128 kernel ran as 128 tiles x 4 K-splits + a slab-reduce LAUNCH each (62 us per product, 43
+// splitk_reduce launches per step).
+//
+//   C[m,n] (+)= sum_k A[m,k] * Bop[n,k] (+ bias[n]) (relu)     A (M,K) K-contiguous; B (N,K) "tb = 0" or (K,N) "tb = 1".
+//
+// Every WAVE owns a 32 x 64 output tile (1 x 2 tiles of v_mfma_f32_32x32x2_f32, 32 accumulator registers) over a K
+// range and runs its OWN six-slot LDS-DMA pipeline (K slabs of 16, five in flight, counted vmcnt): there is no
+// workgroup barrier in the K loop, the four waves of a workgroup (one per SIMD) drift apart freely, and a 64-cycle
+// MFMA stream with fragment reads one k-step ahead keeps each SIMD's matrix pipe fed from a single wave.
+//   WK = 1: the workgroup's 4 waves own 4 different tiles (same 64 columns, 4 consecutive row tiles), whole K each.
+//   WK = 4: the 4 waves own ONE tile and a quarter of K each; their accumulators are summed through LDS in a fixed
+//           order (wave 0 + 1 + 2 + 3): deterministic, no slab round trip through HBM, no second launch.
+// The host picks the form that gives ~256 workgroups (one per CU).  LDS images: K-contiguous operands [row][16] floats
+// with the chunk XOR (row >> 2) & 3 of gemm_f32_big.hip on the copy's source address and on the ds_read_b128; a
+// K-major B as [k][64] floats read with ds_read_b64.  B's 64 columns are interleaved over the two column tiles
+// (column 2c + j belongs to tile j), by a row permutation on the copy's source address for a K-contiguous B, so a lane's
+// two accumulator tiles are 8 contiguous output bytes.
+// Preconditions (else the caller uses gemm_f32.hip): A K-contiguous, K % 16 == 0 (K % 64 for WK = 4), 16-byte
+// aligned bases, lda/ldb % 4 == 0, N % 4 == 0 for a K-major B.
+#include "common.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef const float __attribute__((address_space(1))) gfloat;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int WTM = 32, WTN = 64, TK = 16, NSLOT = 6, NT = 256;
+constexpr int A_BYTES = WTM * TK * 4, B_BYTES = WTN * TK * 4, SLOT_BYTES = A_BYTES + B_BYTES;   // 2 + 4 KB
+constexpr int WAVE_LDS = NSLOT * SLOT_BYTES;           // 36 KB per wave
+constexpr int SMEM_WAVE = 4 * WAVE_LDS;                // 144 KB per workgroup: one workgroup per CU
+constexpr int NGA = A_BYTES / 1024, NGB = B_BYTES / 1024, NGL = NGA + NGB;   // 2 + 4 copies per lane and slab
+
+struct WaveArgs {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;
+  int M, N, K, lda, ldb, ldc, flags;
+  int tiles_m, tiles_n, kpart;       // kpart: K range per wave (K for WK = 1, K / 4 for WK = 4)
+};
+
+__device__ __forceinline__ int swz(int r) { return (r >> 2) & 3; }
+
+template <bool TB>
+__device__ __forceinline__ void init_src(gfloat* (&q)[NGL], const WaveArgs& g, int m0, int n0, int k0, int lane) {
+#pragma unroll
+  for (int i = 0; i < NGA; ++i) {                      // A: copy i -> rows 16 i + (l >> 2), LDS chunk l & 3
+    const int row = 16 * i + (lane >> 2);
+    const int chunk = (lane & 3) ^ swz(row);
+    q[i] = (gfloat*)(g.A + (long long)min(m0 + row, g.M - 1) * g.lda + k0 + chunk * 4);
+  }
+#pragma unroll
+  for (int i = 0; i < NGB; ++i) {
+    if (!TB) {                                         // B (N,K): LDS row rho = 16 i + (l >> 2) holds column 2 (rho & 31) + (rho >> 5)
+      const int rho = 16 * i + (lane >> 2);
+      const int chunk = (lane & 3) ^ swz(rho);
+      const int col = 2 * (rho & 31) + (rho >> 5);
+      q[NGA + i] = (gfloat*)(g.B + (long long)min(n0 + col, g.N - 1) * g.ldb + k0 + chunk * 4);
+    } else {                                           // B (K,N): copy i -> k-rows 4 i + (l >> 4), columns 4 (l & 15) .. +3
+      const int k = 4 * i + (lane >> 4);
+      q[NGA + i] = (gfloat*)(g.B + (long long)(k0 + k) * g.ldb + min(n0 + 4 * (lane & 15), g.N - 4));
+    }
+  }
+}
+
+template <bool TB>
+__device__ __forceinline__ void stage(gfloat* (&q)[NGL], const WaveArgs& g, char* slot) {
+  typedef __attribute__((address_space(3))) char lds_char;
+#pragma unroll
+  for (int i = 0; i < NGL; ++i) {
+    __builtin_amdgcn_global_load_lds(q[i], (lds_char*)(slot + i * 1024), 16, 0, 0);   // wave-uniform base; the DMA adds lane * 16
+    q[i] += (i >= NGA && TB) ? (long long)TK * g.ldb : TK;
+  }
+}
+
+// k-step ks (8 k) of a slab: MFMA step e multiplies k = 8ks + e (lanes 0-31) and k = 8ks + 4 + e (lanes 32-63)
+template <bool TB>
+struct Frag {
+  f32x4 a;             // row r, k = 8ks + 4h + e
+  f32x4 bc[2];         // K-contiguous B: [tile] (e in the vector)
+  f32x2 bt[4];         // K-major B: [e] (tile in the vector)
+  __device__ __forceinline__ void load(const char* slot, int ks, int lane) {
+    const int r = lane & 31, h = lane >> 5;
+    a = *reinterpret_cast<const f32x4*>(slot + r * 64 + (((2 * ks + h) ^ swz(r)) << 4));
+    const char* sb = slot + A_BYTES;
+    if (!TB) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        bc[j] = *reinterpret_cast<const f32x4*>(sb + (32 * j + r) * 64 + (((2 * ks + h) ^ swz(r)) << 4));   // swz(32j + r) == swz(r)
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bt[e] = *reinterpret_cast<const f32x2*>(sb + (8 * ks + 4 * h + e) * 256 + r * 8);
+    }
+  }
+  __device__ __forceinline__ float b(int j, int e) const { return TB ? bt[e][j] : bc[j][e]; }
+};
+
+__device__ __forceinline__ void wait_copies(int later) {   // all but the 6 * later youngest copies of this wave have landed
+  if (later >= 4)      asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+  else if (later == 3) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+  else if (later == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if (later == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// one output row's two values of this lane: (+bias) (+C) (relu), 8-byte store when the row pitch allows it
+__device__ __forceinline__ void put2(const WaveArgs& g, int row, int col, float v0, float v1, float b0, float b1, bool vec) {
+  if (row >= g.M || col >= g.N) return;
+  float* pc = g.C + (long long)row * g.ldc + col;
+  const bool two = col + 1 < g.N;
+  v0 += b0; v1 += b1;
+  if (g.flags & VQF_GEMM_ACCUM) { v0 += pc[0]; if (two) v1 += pc[1]; }
+  if (g.flags & VQF_GEMM_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+  if (vec && two) *reinterpret_cast<f32x2*>(pc) = f32x2{v0, v1};
+  else { pc[0] = v0; if (two) pc[1] = v1; }
+}
+
+template <bool TB, int WK>
+__global__ void __launch_bounds__(NT, 1) gemm_f32_wave_kernel(const WaveArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // tile order: row tiles fastest, so the 4 waves of a WK = 1 workgroup (and neighbouring workgroups) stream the same
+  // 64 columns of B; blocks b and b + 8 share an XCD: XCD-aware bijective remap of the workgroup index first
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int t = (WK == 1) ? 4 * wg + wave : wg;        // this wave's tile
+  const int ntiles = g.tiles_m * g.tiles_n;
+  const bool live = t < ntiles;                        // WK = 1: the last workgroup may have idle waves (wave-uniform)
+  const int tm = live ? t % g.tiles_m : 0, tn = live ? t / g.tiles_m : 0;
+  const int m0 = tm * WTM, n0 = tn * WTN;
+  const int k0 = (WK == 1) ? 0 : wave * g.kpart;
+  const int S = live ? g.kpart / TK : 0;
+  char* my = smem + wave * WAVE_LDS;
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+  gfloat* q[NGL];
+  init_src<TB>(q, g, m0, n0, k0, lane);
+#pragma unroll
+  for (int p = 0; p < NSLOT - 1; ++p)
+    if (p < S) stage<TB>(q, g, my + p * SLOT_BYTES);
+  // Fragments are double-buffered ACROSS slabs: the 6 LDS reads of slab s+1 are issued before the 16 MFMAs of slab s
+  // (two named sets, loop unrolled by two: a runtime-indexed set would live in scratch).
+  Frag<TB> fa[2], fb[2];
+  int slot = 0;                                        // slot of slab s
+  // One slab: its 16 MFMAs with the next slab's LDS reads and the refill copies issued BETWEEN them, one auxiliary
+  // instruction group per 64-cycle MFMA (a single wave feeds its SIMD's matrix pipe: anything issued in a block in front
+  // of the MFMAs -- 6 copies cost ~330 issue cycles -- would leave the pipe idle for that long).
+  auto half = [&](int s, Frag<TB> (&cur)[2], Frag<TB> (&nxt)[2]) {
+    const bool more = s + 1 < S, refill = s + NSLOT - 1 < S;
+    if (more) wait_copies(min(NSLOT - 3, S - 2 - s));  // my copies of slab s+1 (issued 4 slabs ago); up to 3 later slabs stay in flight
+    const char* nx = my + (slot + 1 == NSLOT ? 0 : slot + 1) * SLOT_BYTES;
+    char* rf = my + ((slot == 0) ? NSLOT - 1 : slot - 1) * SLOT_BYTES;   // slot of slab s-1 (read two slabs ago) takes slab s+5
+    typedef __attribute__((address_space(3))) char lds_char;
+#pragma unroll
+    for (int n = 0; n < 16; ++n) {                     // MFMA n: k-step n >> 3, step e = (n >> 1) & 3, column tile n & 1
+      const int ks = n >> 3, e = (n >> 1) & 3, j = n & 1;
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[ks].a[e], cur[ks].b(j, e), acc[j], 0, 0, 0);
+      if (n == 0 && more) nxt[0].load(nx, 0, lane);
+      if (n == 2 && more) nxt[1].load(nx, 1, lane);
+      if (n >= 4 && n < 4 + NGL && refill) {
+        const int i = n - 4;
+        __builtin_amdgcn_global_load_lds(q[i], (lds_char*)(rf + i * 1024), 16, 0, 0);
+        q[i] += (i >= NGA && TB) ? (long long)TK * g.ldb : TK;
+      }
+      __builtin_amdgcn_sched_barrier(0);               // keep this interleave
+    }
+    // the reads of slab s+1 returned long ago: draining the counter HERE costs nothing and tells hipcc that no LDS read is
+    // pending at the loop head (else it waits lgkmcnt(0) in front of the next slab's first MFMA)
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_sched_barrier(0);
+    slot = (slot + 1 == NSLOT) ? 0 : slot + 1;
+  };
+  if (S > 0) {
+    wait_copies(min(NSLOT - 2, S - 1));                // slab 0
+    fa[0].load(my, 0, lane);
+    fa[1].load(my, 1, lane);
+    __builtin_amdgcn_sched_barrier(0);                 // (same reason as in half(): no LDS read pending at the loop head)
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  for (int s = 0; s < S; s += 2) {
+    half(s, fa, fb);
+    if (s + 1 < S) half(s + 1, fb, fa);
+  }
+
+  // ---- epilogue: tile j, register e, lane (cm, h): row (e & 3) + 8 (e >> 2) + 4h, column 2 cm + j
+  const int cm = lane & 31, h = lane >> 5;
+  const bool vec = ((g.ldc & 1) == 0) && ((reinterpret_cast<uintptr_t>(g.C) & 7) == 0);
+  if (WK == 1) {
+    if (!live) return;
+    const int col = n0 + 2 * cm;
+    const float b0 = (g.bias && col < g.N) ? g.bias[col] : 0.f;
+    const float b1 = (g.bias && col + 1 < g.N) ? g.bias[col + 1] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+      put2(g, m0 + (e & 3) + 8 * (e >> 2) + 4 * h, col, acc[0][e], acc[1][e], b0, b1, vec);
+  } else {
+    // partial tiles through LDS (each wave's own region, free once its last slab has been read): [e][lane] float2
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    f32x2* mine = reinterpret_cast<f32x2*>(my);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) mine[e * 64 + lane] = f32x2{acc[0][e], acc[1][e]};
+    __syncthreads();
+    if (!live) return;
+    const int col = n0 + 2 * cm;
+    const float b0 = (g.bias && col < g.N) ? g.bias[col] : 0.f;
+    const float b1 = (g.bias && col + 1 < g.N) ? g.bias[col + 1] : 0.f;
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {                   // wave w finishes registers e = w, w + 4, w + 8, w + 12
+      const int e = wave + 4 * qd;
+      f32x2 v = reinterpret_cast<const f32x2*>(smem)[e * 64 + lane];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {                    // fixed order: ((wave0 + wave1) + wave2) + wave3
+        const f32x2 p = reinterpret_cast<const f32x2*>(smem + w * WAVE_LDS)[e * 64 + lane];
+        v[0] += p[0]; v[1] += p[1];
+      }
+      put2(g, m0 + (e & 3) + 8 * (e >> 2) + 4 * h, col, v[0], v[1], b0, b1, vec);
+    }
+  }
+}
+
+template <bool TB, int WK>
+int launch(const WaveArgs& g, int nwg, hipStream_t s) {
+  static VqfDynLdsFlags attr = {};
+  if (int e = vqf_set_dyn_lds(reinterpret_cast<const void*>(&gemm_f32_wave_kernel<TB, WK>), SMEM_WAVE, attr)) return e;
+  VQF_LAUNCH(KID_GEMM_A0B0 + (TB ? 1 : 0), (gemm_f32_wave_kernel<TB, WK>), dim3(nwg), dim3(NT), SMEM_WAVE, s, g);
+  return vqf_last_error();
+}
+
+}  // namespace
+
+// 0 = this kernel does not apply (caller continues with gemm_f32.hip), 1 = launched (rc holds the status)
+int vqf_gemm_f32_wave_try(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
+                          int ldc, const float* bias, int flags, hipStream_t s, int* rc) {
+  const char* e = getenv("VQF_GEMM_F32_WAVE");         // A/B switch, read per launch: 0 disables this kernel
+  if (e && e[0] == '0') return 0;
+  if (ta || M > 1024 || (K % TK) || K < 256 || !aligned16(A) || !aligned16(B) || (lda % 4) || (ldb % 4)) return 0;
+  if (tb && (N % 4)) return 0;
+  // only where the 128x128 kernel cannot fill the chip without split-K slabs
+  if ((long long)((M + 127) / 128) * ((N + 127) / 128) >= 256) return 0;
+  WaveArgs g;
+  g.A = A; g.B = B; g.C = C; g.bias = bias;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.flags = flags;
+  g.tiles_m = (M + WTM - 1) / WTM;
+  g.tiles_n = (N + WTN - 1) / WTN;
+  const int tiles = g.tiles_m * g.tiles_n;
+  const int nwg1 = (tiles + 3) / 4, nwg4 = tiles;
+  const bool ok4 = (K % (4 * TK) == 0) && K / 4 >= 256;
+  // one wave per tile and whole K when that fills the chip, else four K ranges per tile; neither -> not this kernel
+  int wk = 0;
+  // (one round only: with several rounds per CU the 128x128 kernel's split-K form measured faster, 512 x 5000 x 2048)
+  if (nwg1 <= 256 && nwg1 >= 192) wk = 1;
+  else if (ok4 && nwg4 <= 256 && nwg4 >= 192) wk = 4;
+  if (!wk) return 0;
+  g.kpart = (wk == 1) ? K : K / 4;
+  vqf_prof_dims(M, N, K);
+  if (wk == 1) *rc = tb ? launch<true, 1>(g, nwg1, s) : launch<false, 1>(g, nwg1, s);
+  else         *rc = tb ? launch<true, 4>(g, nwg4, s) : launch<false, 4>(g, nwg4, s);
+  return 1;
+}
