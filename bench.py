@@ -322,6 +322,12 @@ def main():
                                       "achieved": round(achl, 2), "frac": round(achl / FP32_MFMA_PEAK_TFLOPS, 4),
                                       "avg_launch_ms": round(ms_l / n_l, 4), "launches": n_l,
                                       "splitk_reduce_ms_per_launch": round(red_l / n_l, 4)}
+            try:        # beyond-L2 bytes of this launch from the committed rocprofv3 --pmc passes
+                pw = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_wgrad.json")))
+                if (pw["M"], pw["N"], pw["K"]) == (N, K, M):
+                    roofline["wgrad_live"].update(traffic=pw["traffic_bytes"], traffic_source="profiles/r02_pmc_wgrad.json")
+            except Exception:
+                pass
     kernels = {k: {"launches_per_step": round(n / args.steps, 2), "ms_per_step": round(ms / args.steps, 4)}
                for k, (n, ms) in sorted(rep.items(), key=lambda kv: -kv[1][1])}
     # secondary roofline: the HBM-bound MFB fusion kernels (mfb.py:98-106 and its backward).

@@ -120,6 +120,24 @@ def test_gemm_bf16_big_weight_gradient_layout_deep_k(ops):
         torch.cuda.empty_cache()
 
 
+def test_config3_co_attention_bf16_launches_vs_fp64(ops):
+    """The three co_att_conv1 launches of BASELINE config 3 (MHBCoAtt, B=512, hidden 512, K padded 1000 -> 1024) at
+    their exact shapes: forward (0,0) 100352 x 512 x 1024, dgrad (0,1) 100352 x 1000 x 512 (N = logical 1000 of a
+    1024-wide weight), weight gradient (1,1) 512 x 1024 x 100352 (split-K)."""
+    R = 512 * 196
+    Y = _u((R, 1024), 141).to(torch.bfloat16)
+    W = _u((512, 1024), 142, 0.1).to(torch.bfloat16)
+    b = _u((512,), 143)
+    hid = ops.gemm_bf16(Y, W, bias=b, relu=True)
+    assert _rel(hid, torch.relu(_ref64(Y, W, 0, 0, b))) <= 2e-5 * 2
+    D = _u((R, 512), 144, 0.05).to(torch.bfloat16)
+    dY = ops.gemm_bf16(D, W, tb=True, N=1000)
+    assert dY.shape == (R, 1000)
+    assert _rel(dY, _ref64(D, W[:, :1000].contiguous(), 0, 1)) <= 2e-5 * max(1.0, np.sqrt(512) / 16)
+    dW = ops.gemm_bf16(D, Y, ta=True, tb=True)
+    assert _rel(dW, _ref64(D, Y, 1, 1)) <= 2e-5 * np.sqrt(R) / 16
+
+
 def test_headline_fp32_weight_gradient_launch_vs_fp64(ops):
     """The launch behind roofline.wgrad: ops.gemm(dP, X, ta=True, tb=True), M=5000, N=2048, K=100352 (split-K),
     on LIVE operands (in faithful MFB dP is exactly zero).  fp64 reference, 2e-6 * sqrt(K)/8 = 7.9e-5."""

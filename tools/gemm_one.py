@@ -1,0 +1,33 @@
+"""A few launches of ONE hot GEMM on live random operands, for rocprofv3 --pmc passes.
+    python tools/gemm_one.py --dtype f32|bf16 --shape fwd|wgrad [--out-bf16]"""
+import argparse, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, vqa_amd
+ap = argparse.ArgumentParser()
+ap.add_argument("--dtype", default="f32")
+ap.add_argument("--shape", default="fwd")
+ap.add_argument("--out-bf16", action="store_true")
+ap.add_argument("--reps", type=int, default=3)
+args = ap.parse_args()
+ops = vqa_amd.ops
+vqa_amd.lib.load()
+R = 512 * 196
+g = torch.Generator().manual_seed(0)
+if args.shape == "fwd":       # P = X W^T + b          (mfb.py:96)
+    A = torch.relu(torch.randn((R, 2048), generator=g)).cuda()
+    B = (torch.randn((5000, 2048), generator=g) * 0.03).cuda()
+    ta = tb = False
+    bias = torch.zeros(5000, device="cuda")
+else:                          # dW = dP^T X            (autograd of mfb.py:96), live dP
+    A = ((torch.rand((R, 5000), generator=g) - 0.5) * 0.1).cuda()
+    B = torch.relu(torch.randn((R, 2048), generator=g)).cuda()
+    ta = tb = True
+    bias = None
+if args.dtype == "bf16":
+    A, B = A.to(torch.bfloat16), B.to(torch.bfloat16)
+    fn = lambda: ops.gemm_bf16(A, B, ta=ta, tb=tb, bias=bias, out_bf16=args.out_bf16)
+else:
+    fn = lambda: ops.gemm(A, B, ta=ta, tb=tb, bias=bias)
+for _ in range(args.reps):
+    fn()
+torch.cuda.synchronize()
