@@ -297,7 +297,7 @@ def main():
                     break
             except Exception:
                 pass
-        roofline = {"bound": "mfma", "kernel": "img_conv1d forward GEMM (M=%d,N=%d,K=%d; gemm_f32_big.hip, 256x256 tiles; profiler id gemm_f32_a0b0)" % (M, N, K),
+        roofline = {"bound": "mfma", "kernel": "img_conv1d forward GEMM (M=%d,N=%d,K=%d; gemm_f32_big.hip, 256x256 tiles, LDS-DMA, staggered wave halves; profiler id gemm_f32_a0b0)" % (M, N, K),
                     "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                     "traffic_source": traffic_source, "traffic_note": traffic_note,
@@ -305,7 +305,7 @@ def main():
                     "flops_per_launch": flops}
         if n_w:
             achw = flops / (ms_w / n_w * 1e-3) / 1e12
-            roofline["wgrad"] = {"kernel": "gemm_f32_a1b1 img_conv1d wgrad (split-K)", "achieved": round(achw, 2),
+            roofline["wgrad"] = {"kernel": "gemm_f32_a1b1 img_conv1d wgrad (gemm_f32_big.hip, K-major interleaved strips, split-K 8)", "achieved": round(achw, 2),
                                  "frac": round(achw / FP32_MFMA_PEAK_TFLOPS, 4),
                                  "avg_launch_ms": round(ms_w / n_w, 4), "launches": n_w,
                                  "operands": ("in-step launch; in faithful MFB dP is EXACTLY ZERO (singleton-axis "

@@ -1,6 +1,6 @@
 """Same-process A/B of the fp32 GEMM kernels on the hot shapes (random, LIVE operands), interleaved rounds:
-  small = 128x128 kernel (VQF_GEMM_F32_BIG=0), lock = 256x256 lockstep loop (round 1; K-contiguous layouts only),
-  pp = 256x256 ping-pong loop (round 2).          python tools/gemm_f32_ab.py [--rounds 5] [--shapes fwd,wgrad]"""
+  small = 128x128 kernel (VQF_GEMM_F32_BIG=0), lock = 256x256 lockstep loop, pp = 256x256 ping-pong loop,
+  stag = lockstep loop with waves 4-7 half a slab behind.          python tools/gemm_f32_ab.py [--rounds 5] [--shapes fwd,wgrad]"""
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, vqa_amd
@@ -11,7 +11,7 @@ ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--shapes", default="fwd,wgrad,coatt_fwd,coatt_dgrad,sq")
 args = ap.parse_args()
 ENV = {"small": {"VQF_GEMM_F32_BIG": "0", "VQF_GEMM_F32_PP": "1"}, "lock": {"VQF_GEMM_F32_BIG": "1", "VQF_GEMM_F32_PP": "0"},
-       "pp": {"VQF_GEMM_F32_BIG": "1", "VQF_GEMM_F32_PP": "1"}}
+       "pp": {"VQF_GEMM_F32_BIG": "1", "VQF_GEMM_F32_PP": "1"}, "stag": {"VQF_GEMM_F32_BIG": "1", "VQF_GEMM_F32_PP": "2"}}
 SH = {"fwd": (0, 0, 100352, 5000, 2048), "wgrad": (1, 1, 5000, 2048, 100352), "coatt_fwd": (0, 0, 100352, 1024, 1024),
       "coatt_dgrad": (0, 1, 100352, 1024, 1024), "sq": (0, 0, 8192, 8192, 8192), "sq_tn": (1, 0, 8192, 8192, 8192),
       "coatt_wgrad": (1, 1, 1024, 1000, 100352), "coatt1000": (0, 0, 100352, 1024, 1000)}

@@ -4,7 +4,7 @@
 //   C[m,n] = sum_k Aop[m,k] * Bop[n,k] (+ bias[n]) (relu)      each operand K-contiguous ((rows, K)) or
 //   K-major ((K, rows)), as in gemm_f32.hip.
 //
-// 256x256 workgroup tile, 8 waves of 128x64 (4x2 MFMA tiles, 128 accumulator registers, 2 waves per
+// 256x256 workgroup tile, 8 waves of 64x128 (2x4 MFMA tiles, 128 accumulator registers, 2 waves per
 // SIMD), operands staged by LDS-DMA (global_load_lds_dwordx4) in K slabs of 16 into five 32 KB slots
 // with four slabs in flight (counted s_waitcnt vmcnt + raw s_barrier).  A slab costs a wave 64 MFMAs
 // of 64 cycles, so the copy / barrier / fragment-read overheads that limit the bf16 kernel are a few
@@ -46,6 +46,9 @@ constexpr int NSLOT = VQF_F32BIG_NSLOT;                // slab s lives in slot s
 constexpr int SMEM_BIG = NSLOT * SLOT_BYTES;
 constexpr int NG = OP_BYTES / (NT * 16);               // 2 LDS-DMA instructions per thread per operand per slab
 constexpr int GROUP_M = 8;
+#ifndef VQF_F32BIG_DEFAULT_MODE
+#define VQF_F32BIG_DEFAULT_MODE 2     // loop form when VQF_GEMM_F32_PP is unset (see gemm_f32_big_kernel)
+#endif
 
 struct BigArgs {
   const float* A;
@@ -64,15 +67,19 @@ struct BigArgs {
 // chunk XOR of row r: the 16 lanes of a ds_read_b128 phase must hit 16 distinct 16-byte slots of the 256-byte bank row
 __device__ __forceinline__ int swz(int r) { return CH == 4 ? ((r >> 2) & 3) : ((r >> 1) & 7); }
 
-template <bool T>
+// A K-contiguous B is stored with its columns PERMUTED inside each wave strip of 128 (PERM): LDS row 32 j + c of a strip
+// holds column 4 c + j, so that column tile j of a wave is the set of columns = j (mod 4) and a lane's four column tiles
+// are 16 contiguous output bytes (a K-major B has this property without a permutation: see FragB).
+template <bool T, bool PERM>
 __device__ __forceinline__ void init_src(gfloat* (&q)[NG], const float* base, int ld, int r0, int R, int k0,
                                          int wave, int lane) {
 #pragma unroll
   for (int i = 0; i < NG; ++i) {
     if (!T) {
       constexpr int RPW = 1024 / ROW_B;                        // rows per wave copy (1 KB)
-      const int row = i * (8 * RPW) + wave * RPW + lane / CH;
-      const int chunk = (lane % CH) ^ swz(row);                // source chunk that lands on LDS slot lane % CH
+      const int rho = i * (8 * RPW) + wave * RPW + lane / CH;  // LDS row
+      const int chunk = (lane % CH) ^ swz(rho);                // source chunk that lands on LDS slot lane % CH
+      const int row = PERM ? (rho & ~127) + 4 * (rho & 31) + ((rho >> 5) & 3) : rho;
       q[i] = (gfloat*)(base + (long long)min(r0 + row, R - 1) * ld + k0 + chunk * 4);
     } else {
       const int k = i * 8 + wave;
@@ -92,29 +99,17 @@ __device__ __forceinline__ void stage_operand(gfloat* (&q)[NG], int ld, char* s,
   }
 }
 
-// Operand values of one k-step (8 k) of a slab for the wave's strip (A: 128 rows = 4 tiles, B: 64 columns = 2 tiles).
+// Operand values of one k-step (8 k) of a slab for the wave's strip (A: 64 rows = 2 tiles, B: 128 columns = 4 tiles).
 // MFMA step (ks, e) of a slab multiplies k = 8ks + e (lanes 0-31) and k = 8ks + 4 + e (lanes 32-63): any fixed pairing
 // of the slab's 16 k works as long as both operands use the same one (v_mfma_f32_32x32x2_f32 takes k = 0 from lanes
 // 0-31 and k = 1 from lanes 32-63).
-//   K-contiguous: one ds_read_b128 per tile: lane (r, h) gets k = 8ks + 4h + e, e = 0..3, of row 32 tile + r.
-//   K-major:      one ds_read_b128 (A) / ds_read_b64 (B) per e: lane (r, h) gets k-row 8ks + 4h + e, strip rows
-//                 4r .. 4r+3 (columns 2r, 2r+1): element t belongs to tile t (interleaved strip, see the header).
+//   K-contiguous: one ds_read_b128 per tile: lane (r, h) gets k = 8ks + 4h + e, e = 0..3, of LDS row 32 tile + r.
+//   K-major:      one ds_read_b64 (A) / ds_read_b128 (B) per e: lane (r, h) gets k-row 8ks + 4h + e, strip rows
+//                 2r, 2r+1 (columns 4r .. 4r+3): element t belongs to tile t (interleaved strip, see the header).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <bool T>
 struct FragA {                                           // v(i, e): value of row-tile i for step e of this k-step
-  f32x4 f[4];                                            // K-contiguous: [tile] (e in the vector); K-major: [e] (tile in the vector)
-  __device__ __forceinline__ void load(const char* s, int strip0, int ks, int lane) {
-    const int r = lane & 31, h = lane >> 5;
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-      f[x] = T ? *reinterpret_cast<const f32x4*>(s + (8 * ks + 4 * h + x) * 1024 + (strip0 + 4 * r) * 4)
-               : *reinterpret_cast<const f32x4*>(s + (strip0 + 32 * x + r) * ROW_B + (((2 * ks + h) ^ swz(r)) << 4));
-  }
-  __device__ __forceinline__ float v(int i, int e) const { return T ? f[e][i] : f[i][e]; }
-};
-template <bool T>
-struct FragB {
-  f32x4 fc[2];                                           // K-contiguous: [tile]
+  f32x4 fc[2];                                           // K-contiguous: [tile] (e in the vector)
   f32x2 ft[4];                                           // K-major: [e] (tile in the vector)
   __device__ __forceinline__ void load(const char* s, int strip0, int ks, int lane) {
     const int r = lane & 31, h = lane >> 5;
@@ -124,45 +119,58 @@ struct FragB {
         ft[e] = *reinterpret_cast<const f32x2*>(s + (8 * ks + 4 * h + e) * 1024 + (strip0 + 2 * r) * 4);
     } else {
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-        fc[j] = *reinterpret_cast<const f32x4*>(s + (strip0 + 32 * j + r) * ROW_B + (((2 * ks + h) ^ swz(r)) << 4));
+      for (int i = 0; i < 2; ++i)
+        fc[i] = *reinterpret_cast<const f32x4*>(s + (strip0 + 32 * i + r) * ROW_B + (((2 * ks + h) ^ swz(r)) << 4));
     }
   }
-  __device__ __forceinline__ float v(int j, int e) const { return T ? ft[e][j] : fc[j][e]; }
+  __device__ __forceinline__ float v(int i, int e) const { return T ? ft[e][i] : fc[i][e]; }
+};
+template <bool T>
+struct FragB {
+  f32x4 f[4];                                            // K-contiguous: [tile] (e in the vector); K-major: [e] (tile in the vector)
+  __device__ __forceinline__ void load(const char* s, int strip0, int ks, int lane) {
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+      f[x] = T ? *reinterpret_cast<const f32x4*>(s + (8 * ks + 4 * h + x) * 1024 + (strip0 + 4 * r) * 4)
+               : *reinterpret_cast<const f32x4*>(s + (strip0 + 32 * x + r) * ROW_B + (((2 * ks + h) ^ swz(r)) << 4));
+  }
+  __device__ __forceinline__ float v(int j, int e) const { return T ? f[e][j] : f[j][e]; }
 };
 
 // accumulator tile (i, j), register e, lane (cm = lane & 31, h = lane >> 5): MFMA row rm = (e & 3) + 8 (e >> 2) + 4h,
-// MFMA column cm.  Output row = strip row 4 rm + i (K-major A: interleaved strip) or 32 i + rm; output column =
-// strip column 2 cm + j (K-major B) or 32 j + cm.
-template <bool TA, bool TB, bool GUARD_M>
-__device__ __forceinline__ void store_tile(const BigArgs& g, float* C, const f32x16 (&acc)[4][2], int row0, int col0,
+// MFMA column cm.  Output row = strip row 2 rm + i (K-major A: interleaved strip) or 32 i + rm; output column = strip
+// column 4 cm + j (both B layouts): a lane stores its four column tiles as ONE 16-byte store, 32 per lane and tile
+// instead of 128 dword stores (the epilogue is store-issue bound: the 256 KB tile took ~12 slab times).
+template <bool TA, bool GUARD_M, bool VEC>
+__device__ __forceinline__ void store_tile(const BigArgs& g, float* C, const f32x16 (&acc)[2][4], int row0, int col0,
                                            int lane, bool relu, bool use_bias) {
   const int cm = lane & 31, h = lane >> 5;
-  float bv[2];
+  const int col = col0 + 4 * cm;
+  float bv[4];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int col = col0 + (TB ? 2 * cm + j : 32 * j + cm);
-    bv[j] = (use_bias && col < g.N) ? g.bias[col] : 0.f;
-  }
+  for (int j = 0; j < 4; ++j) bv[j] = (use_bias && col + j < g.N) ? g.bias[col + j] : 0.f;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the biases, once: no wait may sit between the stores
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < 2; ++i) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int rm = (e & 3) + 8 * (e >> 2) + 4 * h;
-      const int row = row0 + (TA ? 4 * rm + i : 32 * i + rm);
+      const int row = row0 + (TA ? 2 * rm + i : 32 * i + rm);
       if (GUARD_M && row >= g.M) continue;
-      float v0 = acc[i][0][e] + bv[0], v1 = acc[i][1][e] + bv[1];
-      if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-      float* cp = C + (long long)row * g.ldc + col0;
-      if (TB) {      // N % 4 == 0; an odd ldc (row-strided output view) falls back to two dword stores
-        if (col0 + 2 * cm < g.N) {
-          if ((g.ldc & 1) == 0 && (reinterpret_cast<uintptr_t>(C) & 7) == 0) *reinterpret_cast<f32x2*>(cp + 2 * cm) = f32x2{v0, v1};
-          else { cp[2 * cm] = v0; cp[2 * cm + 1] = v1; }
-        }
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[j] = acc[i][j][e] + bv[j];
+        if (relu) v[j] = fmaxf(v[j], 0.f);
+      }
+      float* cp = C + (long long)row * g.ldc + col;
+      if (VEC) {
+        if (col < g.N) *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
       } else {
-        if (col0 + cm < g.N) cp[cm] = v0;
-        if (col0 + 32 + cm < g.N) cp[32 + cm] = v1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (col + j < g.N) cp[j] = v[j];
       }
     }
   }
@@ -176,16 +184,25 @@ __device__ __forceinline__ void wait_copies(int later) {     // all but the 4 * 
   else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// PP = false: lockstep loop (one barrier per slab, fragment reads one k-step ahead of the MFMAs; both waves of a SIMD
-//             interleave their MFMAs on the matrix pipe) -- the faster form for fp32, whose 64-cycle MFMAs make the
-//             per-slab overheads small (136 vs 129 TFLOP/s on the image projection).
-// PP = true:  ping-pong loop of gemm_bf16_big.hip (kept for A/Bs: VQF_GEMM_F32_PP=1).
-template <bool TA, bool TB, bool PP>
+// MODE 0: lockstep loop (one barrier per slab, fragment reads one k-step ahead of the MFMAs; both waves of a SIMD
+//         interleave their MFMAs on the matrix pipe).
+// MODE 1: ping-pong loop of gemm_bf16_big.hip (for A/Bs, VQF_GEMM_F32_PP=1: with 64-cycle MFMAs it is 5 % slower here).
+// MODE 2: the lockstep loop with waves 4-7 HALF A SLAB behind waves 0-3 (VQF_GEMM_F32_PP=2): both halves still share the
+//         matrix pipe of their SIMD, but while one half sits in its per-slab barrier / first fragment reads the other is
+//         in the middle of its MFMAs and takes the whole pipe.  One barrier per slab as before: waves 0-3 execute it at
+//         the START of slab s (after their vmcnt for slab s), waves 4-7 in the MIDDLE of slab s-1 (after lgkmcnt(0) for
+//         all their reads of slab s-1 and their vmcnt for slab s).  Hazards: every wave's copies of slab s are waited for
+//         in front of that barrier and every read of slab s comes after it; the slot of slab s-1 is refilled (slab s+4) by
+//         waves 0-3 right behind that barrier and by waves 4-7 at their own slab-s start, in both cases after every read
+//         of slab s-1 (waves 0-3: consumed by MFMAs issued before the barrier; waves 4-7: the lgkmcnt(0) above).
+template <bool TA, bool TB, int MODE>
 __global__ void __launch_bounds__(NT, 2) gemm_f32_big_kernel(const BigArgs g) {
+  constexpr bool PP = MODE == 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 2, wc = wave & 3;             // strip rows wr*128 .. +127, strip columns wc*64 .. +63
+  const int wr = wave >> 1, wc = wave & 1;             // strip rows wr*64 .. +63, strip columns wc*128 .. +127
+  const int late = wave >> 2;                          // waves 4-7: the half that runs behind in the staggered / ping-pong loops
 
   // ---- tile order: split index slowest; bijective XCD remap, then groups of GROUP_M row tiles, m fastest
   const int ntiles = g.tiles_m * g.tiles_n;
@@ -206,14 +223,14 @@ __global__ void __launch_bounds__(NT, 2) gemm_f32_big_kernel(const BigArgs g) {
 
   gfloat* qa[NG];
   gfloat* qb[NG];
-  init_src<TA>(qa, g.A, g.lda, m0, g.M, kbeg, wave, lane);
-  init_src<TB>(qb, g.B, g.ldb, n0, g.N, kbeg, wave, lane);
+  init_src<TA, false>(qa, g.A, g.lda, m0, g.M, kbeg, wave, lane);
+  init_src<TB, true>(qb, g.B, g.ldb, n0, g.N, kbeg, wave, lane);
 
-  f32x16 acc[4][2];
+  f32x16 acc[2][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
@@ -224,7 +241,7 @@ __global__ void __launch_bounds__(NT, 2) gemm_f32_big_kernel(const BigArgs g) {
       stage_operand<TB>(qb, g.ldb, smem + p * SLOT_BYTES + OP_BYTES, wave);
     }
   int slot = 0;                                        // slot of slab s
-  if (!PP) {
+  if (MODE == 0 || (MODE == 2 && late == 0)) {
     for (int s = 0; s < S; ++s) {
       wait_copies(min(NSLOT - 2, S - 1 - s));          // my copies of slab s; later slabs stay in flight
       __builtin_amdgcn_s_barrier();
@@ -232,8 +249,8 @@ __global__ void __launch_bounds__(NT, 2) gemm_f32_big_kernel(const BigArgs g) {
       const char* sB = sA + OP_BYTES;
       FragA<TA> fa[2];                                 // fragment double buffer: reads run one k-step ahead
       FragB<TB> fb[2];
-      fa[0].load(sA, wr * 128, 0, lane);
-      fb[0].load(sB, wc * 64, 0, lane);
+      fa[0].load(sA, wr * 64, 0, lane);
+      fb[0].load(sB, wc * 128, 0, lane);
       if (s + NSLOT - 1 < S) {                         // refill the slot of slab s-1 (its address math hides LDS latency)
         const int sl = (slot == 0) ? NSLOT - 1 : slot - 1;
         stage_operand<TA>(qa, g.lda, smem + sl * SLOT_BYTES, wave);
@@ -242,24 +259,64 @@ __global__ void __launch_bounds__(NT, 2) gemm_f32_big_kernel(const BigArgs g) {
 #pragma unroll
       for (int ks = 0; ks < TK / 8; ++ks) {
         if (ks + 1 < TK / 8) {
-          fa[(ks + 1) & 1].load(sA, wr * 128, ks + 1, lane);
-          fb[(ks + 1) & 1].load(sB, wc * 64, ks + 1, lane);
+          fa[(ks + 1) & 1].load(sA, wr * 64, ks + 1, lane);
+          fb[(ks + 1) & 1].load(sB, wc * 128, ks + 1, lane);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
+          for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 4; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ks & 1].v(i, e), fb[ks & 1].v(j, e), acc[i][j], 0, 0, 0);
       }
+      slot = (slot + 1 == NSLOT) ? 0 : slot + 1;
+    }
+    if (MODE == 2) __builtin_amdgcn_s_barrier();       // pairs with the mid-slab barrier of waves 4-7 in their last slab
+  } else if (MODE == 2) {                              // waves 4-7: half a slab behind
+    static_assert(TK == 16, "the staggered loop splits a slab into its two k-steps");
+    wait_copies(min(NSLOT - 1, S) - 1);                // my copies of slab 0
+    __builtin_amdgcn_s_barrier();                      // pairs with the slab-0 barrier of waves 0-3
+    for (int s = 0; s < S; ++s) {
+      const char* sA = smem + slot * SLOT_BYTES;
+      const char* sB = sA + OP_BYTES;
+      FragA<TA> fa[2];
+      FragB<TB> fb[2];
+      fa[0].load(sA, wr * 64, 0, lane);
+      fb[0].load(sB, wc * 128, 0, lane);
+      if (s + NSLOT - 1 < S) {                         // slab s+4 into the slot of slab s-1
+        const int sl = (slot == 0) ? NSLOT - 1 : slot - 1;
+        stage_operand<TA>(qa, g.lda, smem + sl * SLOT_BYTES, wave);
+        stage_operand<TB>(qb, g.ldb, smem + sl * SLOT_BYTES + OP_BYTES, wave);
+      }
+      fa[1].load(sA, wr * 64, 1, lane);
+      fb[1].load(sB, wc * 128, 1, lane);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0].v(i, e), fb[0].v(j, e), acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0): every read of slab s by this wave has returned
+      wait_copies(min(s + NSLOT - 1, S - 1) - (s + 1));   // my copies of slab s+1; later slabs stay in flight
+      __builtin_amdgcn_s_barrier();                    // pairs with the slab-(s+1) barrier of waves 0-3 (their final one for s = S-1)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1].v(i, e), fb[1].v(j, e), acc[i][j], 0, 0, 0);
       slot = (slot + 1 == NSLOT) ? 0 : slot + 1;
     }
   } else {
     static_assert(!PP || (2 * NG == 4 && NSLOT == 5 && TK == 16), "the ping-pong loop assumes 4 copies per thread per slab, 5 slots");
     wait_copies(min(NSLOT - 1, S) - 1);                // my copies of slab 0
     __builtin_amdgcn_s_barrier();                      // #0: every wave's copies of slab 0 have landed
-    if (wr) __builtin_amdgcn_s_barrier();              // waves 4-7 fall half a slab behind (wave-uniform branch)
+    if (late) __builtin_amdgcn_s_barrier();            // waves 4-7 fall half a slab behind (wave-uniform branch)
     for (int s = 0; s < S; ++s) {
       // ---------------- L(s) ----------------
       __builtin_amdgcn_sched_barrier(0);
@@ -269,8 +326,8 @@ __global__ void __launch_bounds__(NT, 2) gemm_f32_big_kernel(const BigArgs g) {
       FragB<TB> fb[2];
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        fb[ks].load(sB, wc * 64, ks, lane);
-        fa[ks].load(sA, wr * 128, ks, lane);
+        fb[ks].load(sB, wc * 128, ks, lane);
+        fa[ks].load(sA, wr * 64, ks, lane);
       }
       if (s + NSLOT - 1 < S) {                         // slab s+4 into the slot of slab s-1
         const int sl = (slot == 0) ? NSLOT - 1 : slot - 1;
@@ -289,24 +346,31 @@ __global__ void __launch_bounds__(NT, 2) gemm_f32_big_kernel(const BigArgs g) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
+          for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 4; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ks].v(i, e), fb[ks].v(j, e), acc[i][j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       slot = (slot + 1 == NSLOT) ? 0 : slot + 1;
     }
-    if (!wr) __builtin_amdgcn_s_barrier();             // waves 0-3 absorb the barrier waves 4-7 spent on the stagger
+    if (!late) __builtin_amdgcn_s_barrier();           // waves 0-3 absorb the barrier waves 4-7 spent on the stagger
   }
 
   const bool split = g.splits > 1;
   const bool relu = !split && (g.flags & VQF_GEMM_RELU) != 0;
   float* C = split ? g.C + (size_t)z * g.M * g.N : g.C;
   const bool use_bias = !split && g.bias != nullptr;
-  if (m0 + TM <= g.M) store_tile<TA, TB, false>(g, C, acc, m0 + wr * 128, n0 + wc * 64, lane, relu, use_bias);
-  else                store_tile<TA, TB, true>(g, C, acc, m0 + wr * 128, n0 + wc * 64, lane, relu, use_bias);
+  const bool vec = (g.N % 4 == 0) && (g.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
+                   (!split || (((size_t)g.M * g.N) % 4 == 0));
+  const int row0 = m0 + wr * 64, col0 = n0 + wc * 128;
+  if (vec) {
+    if (m0 + TM <= g.M) store_tile<TA, false, true>(g, C, acc, row0, col0, lane, relu, use_bias);
+    else                store_tile<TA, true, true>(g, C, acc, row0, col0, lane, relu, use_bias);
+  } else {
+    store_tile<TA, true, false>(g, C, acc, row0, col0, lane, relu, use_bias);
+  }
 }
 
 // split count that minimises (rounds of 256 one-per-CU workgroups) x (time of one workgroup) + slab traffic, in
@@ -332,17 +396,23 @@ template <bool TA, bool TB>
 int launch(const BigArgs& g, hipStream_t s) {
   // > 64 KB of dynamic LDS needs the attribute, once per device and instantiation (common.h)
   static VqfDynLdsFlags attr = {}, attr_pp = {};
-  const char* ppe = getenv("VQF_GEMM_F32_PP");         // A/B switch, read per launch: 1 selects the ping-pong loop
-  const bool pingpong = ppe && ppe[0] == '1';
+  const char* ppe = getenv("VQF_GEMM_F32_PP");         // A/B switch, read per launch: 0 lockstep, 1 ping-pong, 2 staggered lockstep
+  const int mode = (ppe && ppe[0] >= '0' && ppe[0] <= '2') ? ppe[0] - '0' : VQF_F32BIG_DEFAULT_MODE;
   const int kid = KID_GEMM_A0B0 + 2 * (TA ? 1 : 0) + (TB ? 1 : 0);
   const dim3 grid(g.tiles_m * g.tiles_n * g.splits);
-  if (pingpong) {
-    if (int e = vqf_set_dyn_lds(reinterpret_cast<const void*>(&gemm_f32_big_kernel<TA, TB, true>), SMEM_BIG, attr_pp)) return e;
-    VQF_LAUNCH(kid, (gemm_f32_big_kernel<TA, TB, true>), grid, dim3(NT), SMEM_BIG, s, g);
+  if (mode == 1) {
+    if (int e = vqf_set_dyn_lds(reinterpret_cast<const void*>(&gemm_f32_big_kernel<TA, TB, 1>), SMEM_BIG, attr_pp)) return e;
+    VQF_LAUNCH(kid, (gemm_f32_big_kernel<TA, TB, 1>), grid, dim3(NT), SMEM_BIG, s, g);
     return vqf_last_error();
   }
-  if (int e = vqf_set_dyn_lds(reinterpret_cast<const void*>(&gemm_f32_big_kernel<TA, TB, false>), SMEM_BIG, attr)) return e;
-  VQF_LAUNCH(kid, (gemm_f32_big_kernel<TA, TB, false>), grid, dim3(NT), SMEM_BIG, s, g);
+  if (mode == 2) {
+    static VqfDynLdsFlags attr_st = {};
+    if (int e = vqf_set_dyn_lds(reinterpret_cast<const void*>(&gemm_f32_big_kernel<TA, TB, 2>), SMEM_BIG, attr_st)) return e;
+    VQF_LAUNCH(kid, (gemm_f32_big_kernel<TA, TB, 2>), grid, dim3(NT), SMEM_BIG, s, g);
+    return vqf_last_error();
+  }
+  if (int e = vqf_set_dyn_lds(reinterpret_cast<const void*>(&gemm_f32_big_kernel<TA, TB, 0>), SMEM_BIG, attr)) return e;
+  VQF_LAUNCH(kid, (gemm_f32_big_kernel<TA, TB, 0>), grid, dim3(NT), SMEM_BIG, s, g);
   return vqf_last_error();
 }
 
