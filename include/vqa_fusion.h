@@ -177,8 +177,8 @@ int vqf_glimpse_pool_bwd_bf16(const float* dpooled, const float* dwts_extra, con
  *  cascade (N*L, 5*O) or NULL: third factor of MHB's high-order block
  *                   (mhb_coAtt.py:205, the dropped-out first-order product)
  *  keep (N*L, 5*O)  uint8 keep-mask or NULL.  NULL and p_drop > 0: the mask is
- *                   generated in-kernel from Philox4x32-10(seed, element index),
- *                   identically in forward and backward.
+ *                   generated in-kernel from Philox4x32-10(seed, element index / 8), one 16-bit draw
+ *                   per element (keep iff draw >= p * 65536), identically in forward and backward.
  *  R    (N*L, O)    signed sqrt of the pooled sums (un-normalised)
  *  rowssq (N*L)     per-row sum of R^2 (= sum |pooled|)
  *  zdrop (N*L,5*O) or NULL: the dropped-out product itself (only MHB needs it)
@@ -242,7 +242,7 @@ int vqf_mfb_fuse_bwd_pbf16(const float* dY, const float* Y, const float* inv, co
 
 /* --------------------------------------------------------------------------
  * Element-wise stages of HieCoAtten / AttentionNet.  n % 4 == 0, 16-byte aligned pointers.
- * keep: uint8 keep-mask or NULL (then Philox4x32-10(seed, index/4), as in vqf_mfb_fuse_*).
+ * keep: uint8 keep-mask or NULL (then Philox4x32-10(seed, index/4), one 32-bit draw per element).
  */
 /* y = x * keep / (1-p)      F.dropout, hieCoAtten.py:26,28; networks.py:22,24,55,57.
  * Its own backward: call it with x = dy and the same keep/seed. */
@@ -257,6 +257,12 @@ int vqf_tanh_dropout_bwd(const float* dy, const float* y, const uint8_t* keep, u
 /* softmax over the last axis of (R,W) and its backward   modules.py:91-92 */
 int vqf_softmax_rows_fwd(const float* x, int R, int W, float* y, void* stream);
 int vqf_softmax_rows_bwd(const float* dy, const float* y, int R, int W, float* dx, void* stream);
+
+/* log_softmax over the last axis of a (R, W) tensor and its gradient: the classifier tail of MHBCoAtt / MHB
+ * (mhb_coAtt.py:149-151, :215-217; implicit dim = 1 on the 2-D logits).  y = (x - max) - log(sum exp(x - max));
+ * dx = dy - exp(y) * sum_c dy. */
+int vqf_log_softmax_rows_fwd(const float* x, int R, int W, float* y, void* stream);
+int vqf_log_softmax_rows_bwd(const float* dy, const float* y, int R, int W, float* dx, void* stream);
 
 /* --------------------------------------------------------------------------
  * LSTM recursion of the question encoder for small per-step batches:

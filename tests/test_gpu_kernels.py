@@ -292,3 +292,40 @@ def test_gemm_small_m_wave_kernel(ops, tb, M, N, K, what):
     ops.gemm(Ad, Bd, tb=bool(tb), out=wide[:, 1:N + 1], accumulate=True)
     assert _rel(wide[:, 1:N + 1], ref + C0[:, 1:N + 1]) <= tol
     assert torch.equal(wide[:, 0].cpu(), C0[:, 0].float()) and torch.equal(wide[:, N + 1:].cpu(), C0[:, N + 1:].float())
+
+
+def test_log_softmax_rows_vs_torch_fp64(ops):
+    """vqf_log_softmax_rows_fwd/bwd (the classifier tail of MHBCoAtt / MHB, mhb_coAtt.py:149-151) vs torch in fp64."""
+    for R, W in ((512, 1000), (3, 7), (5, 64), (2, 1)):
+        x = _rand((R, W), 81, 6.0)
+        g = _rand((R, W), 82)
+        xr = x.clone().requires_grad_(True)
+        ref = torch.log_softmax(xr, dim=1)
+        ref.backward(g)
+        y = ops.log_softmax_rows_fwd(x.float().cuda())
+        assert float((y.double().cpu() - ref.detach()).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max()))
+        dx = ops.log_softmax_rows_bwd(g.float().cuda(), y)
+        assert float((dx.double().cpu() - xr.grad).abs().max()) <= 1e-5 * max(1.0, float(xr.grad.abs().max()))
+        assert torch.allclose(y.exp().sum(1).cpu(), torch.ones(R), atol=1e-5)
+
+
+@pytest.mark.parametrize("O", [1000, 1004, 8])
+def test_mfb_fuse_philox_16bit_draws(ops, O):
+    """One Philox4x32-10 call per 8 elements, a 16-bit draw each: drop rate, forward == backward mask, and no
+    correlation between neighbours; O = 1004 makes rows start at element offsets = 4 (mod 8) (the window's other phase)."""
+    N, L = 3, 64
+    P = torch.ones((N * L, 5 * O), device="cuda")
+    q = torch.ones((N, 5 * O), device="cuda")
+    _, _, _, z = ops.mfb_fuse_fwd(P, q, N, L, O, seed=99, p_drop=0.25, want_zdrop=True)
+    kept = (z != 0)
+    k = kept.float()
+    n = k.numel()
+    assert abs(1.0 - float(k.mean()) - 0.25) < 4.0 * (0.25 * 0.75 / n) ** 0.5 + 1e-4
+    for lag in (1, 2, 3, 4, 7, 8):                         # neighbours within and across a call's 8 draws
+        a, b = k[:, :-lag].flatten(), k[:, lag:].flatten()
+        corr = float(((a - a.mean()) * (b - b.mean())).mean() / (a.std() * b.std() + 1e-12))
+        assert abs(corr) < 5.0 / a.numel() ** 0.5 + 1e-3, (lag, corr)
+    Y, norm, inv, _ = ops.mfb_fuse_fwd(P, q, N, L, O, seed=99, p_drop=0.25)
+    dP, _, _, _ = ops.mfb_fuse_bwd(torch.ones_like(Y), Y, norm, inv, P, q, N, L, O, seed=99, p_drop=0.25)
+    same = float(((dP != 0) == kept).float().mean())
+    assert same > 0.999, same                               # (dP can be exactly 0 where the pooled sum is 0)

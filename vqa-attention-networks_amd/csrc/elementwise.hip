@@ -87,6 +87,37 @@ __global__ void softmax_rows_bwd_kernel(const float* __restrict__ dy, const floa
   for (int c = lane; c < W; c += 64) dx[(long long)row * W + c] = p[c] * (g[c] - dot);
 }
 
+// log_softmax over the last axis, one wave per row: y = (x - max) - log(sum exp(x - max))   (torch's formulation)
+__global__ void log_softmax_rows_fwd_kernel(const float* __restrict__ x, int R, int W, float* __restrict__ y) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const int lane = threadIdx.x & 63;
+  const float* p = x + (long long)row * W;
+  float* q = y + (long long)row * W;
+  float mx = -INFINITY;
+  for (int c = lane; c < W; c += 64) mx = fmaxf(mx, p[c]);
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int c = lane; c < W; c += 64) sum += expf(p[c] - mx);
+  sum = wave_sum(sum);
+  const float ls = logf(sum);
+  for (int c = lane; c < W; c += 64) q[c] = (p[c] - mx) - ls;
+}
+
+// dx = dy - exp(y) * sum_c dy
+__global__ void log_softmax_rows_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, int R,
+                                            int W, float* __restrict__ dx) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const int lane = threadIdx.x & 63;
+  const float* g = dy + (long long)row * W;
+  const float* p = y + (long long)row * W;
+  float tot = 0.f;
+  for (int c = lane; c < W; c += 64) tot += g[c];
+  tot = wave_sum(tot);
+  for (int c = lane; c < W; c += 64) dx[(long long)row * W + c] = g[c] - expf(p[c]) * tot;
+}
+
 int ew_args_ok(const void* a, const void* out, const uint8_t* keep, float p, long long n) {
   if (!a || !out || n <= 0) return VQF_E_BADARG;
   if (n % 4) return VQF_E_UNSUPPORTED;
@@ -145,6 +176,20 @@ int vqf_softmax_rows_fwd(const float* x, int R, int W, float* y, void* stream) {
 int vqf_softmax_rows_bwd(const float* dy, const float* y, int R, int W, float* dx, void* stream) {
   if (!dy || !y || !dx || R <= 0 || W <= 0) return VQF_E_BADARG;
   VQF_LAUNCH(KID_SOFTMAX_BWD, softmax_rows_bwd_kernel, dim3((R + 3) / 4), dim3(256), 0,
+             (hipStream_t)stream, dy, y, R, W, dx);
+  return vqf_last_error();
+}
+
+int vqf_log_softmax_rows_fwd(const float* x, int R, int W, float* y, void* stream) {
+  if (!x || !y || R <= 0 || W <= 0) return VQF_E_BADARG;
+  VQF_LAUNCH(KID_SOFTMAX_FWD, log_softmax_rows_fwd_kernel, dim3((R + 3) / 4), dim3(256), 0,
+             (hipStream_t)stream, x, R, W, y);
+  return vqf_last_error();
+}
+
+int vqf_log_softmax_rows_bwd(const float* dy, const float* y, int R, int W, float* dx, void* stream) {
+  if (!dy || !y || !dx || R <= 0 || W <= 0) return VQF_E_BADARG;
+  VQF_LAUNCH(KID_SOFTMAX_BWD, log_softmax_rows_bwd_kernel, dim3((R + 3) / 4), dim3(256), 0,
              (hipStream_t)stream, dy, y, R, W, dx);
   return vqf_last_error();
 }

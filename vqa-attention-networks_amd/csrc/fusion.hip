@@ -10,8 +10,10 @@
 // HBM access is a fully coalesced 16-B-per-lane stream.  The 5-wide pooling
 // window never crosses a thread (20 = 4*5), so no cross-lane traffic is needed
 // for the pool; the row's sum of squares is a wavefront-shuffle reduction.
-// Dropout masks are never stored: forward and backward regenerate them from
-// Philox4x32-10(seed, element index / 4).
+// Dropout masks are never stored: forward and backward regenerate them from Philox4x32-10(seed, element index / 8),
+// one 16-bit draw per element (keep iff draw >= p * 65536).  Round 1 spent one call per 4 elements on 32-bit draws: the
+// 40 quarter-rate 32-bit multiplies of a call made these kernels VALU-bound (0.5 ms of SIMD time per pass over the
+// 5e8 elements -- the bf16-P forward took as long as the fp32-P one); 16-bit draws halve that.
 #include "common.h"
 
 namespace {
@@ -66,13 +68,18 @@ __device__ __forceinline__ void keep_scale20(const uint8_t* __restrict__ keep, u
       for (int j = 0; j < 4; ++j) sc[4 * i + j] = ((w >> (8 * j)) & 0xFFu) ? inv_keep : 0.f;
     }
   } else if (thr != 0u) {
+    // elements e0 .. e0+19 are halfwords (e0 & 7) .. +19 of the 24-halfword stream of calls e0/8, e0/8 + 1, e0/8 + 2
+    // (e0 % 4 == 0: the window starts at halfword 0 or 4, i.e. at word 0 or 2 of the 12-word stream)
+    const uint64_t g0 = (uint64_t)(e0 >> 3);
+    const uint4 r0 = philox4x32_10(g0, seed), r1 = philox4x32_10(g0 + 1, seed), r2 = philox4x32_10(g0 + 2, seed);
+    const uint32_t w[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+    const bool hi = (e0 & 4) != 0;
+    const uint32_t t16 = thr >> 16;
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      const uint4 r = philox4x32_10((uint64_t)(e0 >> 2) + i, seed);
-      sc[4 * i] = r.x >= thr ? inv_keep : 0.f;
-      sc[4 * i + 1] = r.y >= thr ? inv_keep : 0.f;
-      sc[4 * i + 2] = r.z >= thr ? inv_keep : 0.f;
-      sc[4 * i + 3] = r.w >= thr ? inv_keep : 0.f;
+    for (int k = 0; k < 10; ++k) {
+      const uint32_t x = hi ? w[k + 2] : w[k];
+      sc[2 * k] = (x & 0xFFFFu) >= t16 ? inv_keep : 0.f;
+      sc[2 * k + 1] = (x >> 16) >= t16 ? inv_keep : 0.f;
     }
   } else {
 #pragma unroll

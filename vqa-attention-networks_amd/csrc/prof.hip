@@ -46,10 +46,11 @@ void vqf_prof_end(int id, hipStream_t s) {
 void vqf_prof_dims(int d0, int d1, int d2) { t_dims[0] = d0; t_dims[1] = d1; t_dims[2] = d2; }
 
 extern "C" {
-int vqf_abi_version(void) { return 2; }
+int vqf_abi_version(void) { return 3; }
 const char* vqf_build_info(void) {
-  return "libvqa_fusion gfx950 fp32-mfma(v_mfma_f32_32x32x2_f32) tiles 128x128x16 + 256x256x16(lds-dma) "
-         "bf16-mfma(v_mfma_f32_32x32x16_bf16) tiles 128x128x32 + 256x256x32(lds-dma) wave64 philox4x32-10";
+  return "libvqa_fusion gfx950 fp32-mfma(v_mfma_f32_32x32x2_f32) tiles 128x128x16 + 256x256x16(lds-dma, staggered) + "
+         "32x64-per-wave(small M) bf16-mfma(v_mfma_f32_16x16x32_bf16 / 32x32x16) tiles 128x128x32 + "
+         "256x256x32(lds-dma, ping-pong) wave64 philox4x32-10";
 }
 void vqf_prof_enable(int on) { g_vqf_prof_on = on ? 1 : 0; }
 void vqf_prof_reset(void) {

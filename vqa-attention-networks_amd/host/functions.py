@@ -362,6 +362,21 @@ class SoftmaxRowsFn(torch.autograd.Function):
         return ops.softmax_rows_bwd(_c(dy), y)
 
 
+class LogSoftmaxRowsFn(torch.autograd.Function):
+    """log_softmax over the last axis of the 2-D logits: the classifier tail of MHBCoAtt / MHB (mhb_coAtt.py:149-151,215-217)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        y = ops.log_softmax_rows_fwd(_c(x))
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return ops.log_softmax_rows_bwd(_c(dy), y)
+
+
 class LstmSeqFn(torch.autograd.Function):
     """Single-layer LSTM over dim 0 of x (S,B,I) -> hs (S,B,H), zero initial state.
 

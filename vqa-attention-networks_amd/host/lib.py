@@ -18,7 +18,7 @@ if os.environ.get("VQF_LIB"):          # A/B builds (tools/build_variant.sh); ne
 HEADER_PATH = os.path.join(os.path.dirname(PKG_DIR), "include", "vqa_fusion.h")
 
 # The one place the expected ABI number lives (csrc/prof.hip returns it from vqf_abi_version()).
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lock = threading.Lock()
 _lib = None
@@ -56,6 +56,8 @@ SIGNATURES = {
     "vqf_tanh_dropout_bwd": (c_i, [c_f, c_f, c_p, c_u64, ctypes.c_float, ctypes.c_longlong, c_f, c_p]),
     "vqf_softmax_rows_fwd": (c_i, [c_f, c_i, c_i, c_f, c_p]),
     "vqf_softmax_rows_bwd": (c_i, [c_f, c_f, c_i, c_i, c_f, c_p]),
+    "vqf_log_softmax_rows_fwd": (c_i, [c_f, c_i, c_i, c_f, c_p]),
+    "vqf_log_softmax_rows_bwd": (c_i, [c_f, c_f, c_i, c_i, c_f, c_p]),
     "vqf_mfb_fuse_fwd": (c_i, [c_f, c_f, c_f, c_f, c_p, c_u64, ctypes.c_float, c_i, c_i, c_i, c_f, c_f, c_f, c_p]),
     "vqf_l2_group_norm": (c_i, [c_f, c_i, c_i, c_f, c_f, c_p]),
     "vqf_scale_rows": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f, c_p]),

@@ -6,10 +6,9 @@ axis (mhb_coAtt.py:27-36,72-74); set `fix_lstm_orientation=True` to opt out.
 """
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import ops
-from .functions import LinearFn, AttHeadFn, ImgFuseFn, MfbFuseFn, FinalMfbFn, LstmSeqFn, LstmBatchFn
+from .functions import LinearFn, AttHeadFn, ImgFuseFn, MfbFuseFn, FinalMfbFn, LstmSeqFn, LstmBatchFn, LogSoftmaxRowsFn
 from .mfb import _DropSeeds, _image_is_data, _SideStream, batch_first_lstm, warn_once
 
 
@@ -107,7 +106,7 @@ class MHBCoAtt(nn.Module):
                                        pm if kk is not None else p))
         att_normed_23 = torch.cat(ys, 1)                                     # (N,2000)  :147
         logits = LinearFn.apply(att_normed_23, self.linear_pred.weight, self.linear_pred.bias)
-        return F.log_softmax(logits, dim=1)                                  # :149 (implicit dim=1)
+        return LogSoftmaxRowsFn.apply(logits)                                # :149-151 (implicit dim = 1 on the 2-D logits)
 
 
 class MHB(nn.Module):
@@ -176,4 +175,4 @@ class MHB(nn.Module):
                                  pm if k2 is not None else p, z1, False)             # :201-211
         mhb_12 = torch.cat((mhb_1, mhb_2), 1)
         logits = LinearFn.apply(mhb_12, self.linear_out.weight, self.linear_out.bias)
-        return F.log_softmax(logits, dim=1)
+        return LogSoftmaxRowsFn.apply(logits)                                # :215-217

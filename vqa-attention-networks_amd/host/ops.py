@@ -293,6 +293,22 @@ def softmax_rows_bwd(dy, y):
     return dx
 
 
+def log_softmax_rows_fwd(x):
+    _chk(x)
+    R, W = x.shape
+    y = torch.empty_like(x)
+    _l.check(_lib().vqf_log_softmax_rows_fwd(_ptr(x), R, W, _ptr(y), _stream()), "vqf_log_softmax_rows_fwd")
+    return y
+
+
+def log_softmax_rows_bwd(dy, y):
+    _chk(dy, y)
+    R, W = y.shape
+    dx = torch.empty_like(y)
+    _l.check(_lib().vqf_log_softmax_rows_bwd(_ptr(dy), _ptr(y), R, W, _ptr(dx), _stream()), "vqf_log_softmax_rows_bwd")
+    return dx
+
+
 def _keep_ptr(keep):
     if keep is None:
         return ctypes.c_void_p(0)
