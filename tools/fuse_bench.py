@@ -1,25 +1,27 @@
-"""Timing of the MFB fusion kernels alone at the headline shape (N=512, L=196, O=1000)."""
+"""Timing of the MFB fusion kernels alone at the headline shape (N=512, L=196, O=1000): direct (strided) vs coalesced
+(LDS-transposed) P / dP access (VQF_FUSE_COAL), fp32 and bf16 projection storage, with and without Philox dropout."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, vqa_amd
 ops = vqa_amd.ops
 N, L, O = 512, 196, 1000
 P = torch.randn(N * L, 5 * O, device="cuda"); q = torch.randn(N, 5 * O, device="cuda"); pb = torch.randn(5 * O, device="cuda")
-def timed(fn, n=10):
-    fn(); torch.cuda.synchronize()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(n): fn()
-    b.record(); torch.cuda.synchronize()
-    return a.elapsed_time(b) / n
-for pd in (0.1, 0.0):
-    ops.prof_reset(); ops.prof_enable(True)
-    for _ in range(5):
-        Y, norm, inv, _ = ops.mfb_fuse_fwd(P, q, N, L, O, seed=123, p_drop=pd, pbias=pb)
-        dY = torch.randn_like(Y)
-        ops.mfb_fuse_bwd(dY, Y, norm, inv, P, q, N, L, O, seed=123, p_drop=pd, want_dbias=True, pbias=pb)
-    torch.cuda.synchronize()
-    rep = ops.prof_report()
-    ops.prof_enable(False)
-    for k in ("mfb_fuse_fwd", "mfb_fuse_bwd", "scale_rows", "rowdot"):
-        n, ms = rep[k]; print("p_drop=%.1f %-14s %.4f ms" % (pd, k, ms / n))
+Pb = P.to(torch.bfloat16)
+res = {}
+for mode, Pm, kw in (("fp32 P", P, {}), ("bf16 P/dP", Pb, {"dp_bf16": True})):
+    for pd in (0.1, 0.0):
+        for coal in ("0", "1"):
+            os.environ["VQF_FUSE_COAL"] = coal
+            ops.prof_reset(); ops.prof_enable(True)
+            for _ in range(6):
+                Y, norm, inv, _ = ops.mfb_fuse_fwd(Pm, q, N, L, O, seed=123, p_drop=pd, pbias=pb)
+                dY = torch.randn_like(Y)
+                out = ops.mfb_fuse_bwd(dY, Y, norm, inv, Pm, q, N, L, O, seed=123, p_drop=pd, want_dbias=True, pbias=pb, **kw)
+            torch.cuda.synchronize()
+            rep = ops.prof_report()
+            ops.prof_enable(False)
+            res[(mode, pd, coal)] = (Y.clone(), out[0].clone(), out[1].clone())
+            print("%-10s p_drop=%.1f coalesced=%s  fwd %.4f ms  bwd %.4f ms" % (
+                mode, pd, coal, rep["mfb_fuse_fwd"][1] / rep["mfb_fuse_fwd"][0], rep["mfb_fuse_bwd"][1] / rep["mfb_fuse_bwd"][0]), flush=True)
+        a, b = res[(mode, pd, "0")], res[(mode, pd, "1")]
+        print("   identical results: Y %s dP %s dq %s" % (torch.equal(a[0], b[0]), torch.equal(a[1].view(torch.uint8), b[1].view(torch.uint8)), torch.equal(a[2], b[2])))

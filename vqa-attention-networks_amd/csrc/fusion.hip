@@ -15,6 +15,7 @@
 // 40 quarter-rate 32-bit multiplies of a call made these kernels VALU-bound (0.5 ms of SIMD time per pass over the
 // 5e8 elements -- the bf16-P forward took as long as the fp32-P one); 16-bit draws halve that.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -55,6 +56,92 @@ __device__ __forceinline__ void store20(__bf16* __restrict__ p, const float (&v)
   }
 }
 
+// ---- coalesced access to the projection rows through a wave-private LDS transpose --------------------------------
+// A thread owns 20 consecutive elements of a row, so a direct load / store instruction touches 16 (8) bytes every 80 (40)
+// bytes: each 128-byte line is visited by five different instructions, and with ~100 KB of rows in flight per CU the
+// 32 KB L1 no longer holds a line until its fifth visit (the kernels sat at 4.6-4.7 TB/s with the dropout arithmetic
+// removed).  Here a wave's 64 threads (1280 consecutive elements) move their span as lane-linear 16-byte pieces
+// -- every line is touched by exactly one instruction -- and redistribute it through 5 KB of LDS of their own:
+// ds_write_b128 lane-linear, ds_read_b128 at an 80-byte lane stride (both conflict-free), no barrier (the LDS executes
+// one wave's instructions in order).
+// The exchange is between LANES of one wave, which the compiler's per-thread view does not see: without a fence hipcc
+// proves that a thread's own stores cannot alias its reads of other lanes' slots and hoists those reads out of the row
+// loop.  A wavefront-scope fence emits no instruction and pins the order.
+#define VQF_WAVE_FENCE() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
+constexpr int WSPAN = 64 * CPT;                        // elements of a row owned by one wave
+constexpr int WLDS = WSPAN * 4;                        // bytes of a wave's transpose buffer
+template <typename PT> struct Raw;
+template <> struct Raw<float> { f32x4 v[5]; };         // 320 pieces of 4 floats per wave span
+template <> struct Raw<__bf16> { uint4 v[3]; };        // 160 pieces of 8 bf16: the third instruction only in lanes 0-31
+
+__device__ __forceinline__ void raw_load(const float* __restrict__ rowp, int W5, int wave, int lane, Raw<float>& r) {
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int el = wave * WSPAN + (64 * k + lane) * 4;
+    r.v[k] = el < W5 ? *reinterpret_cast<const f32x4*>(rowp + el) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+__device__ __forceinline__ void raw_load(const __bf16* __restrict__ rowp, int W5, int wave, int lane, Raw<__bf16>& r) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int pc = 64 * k + lane, el = wave * WSPAN + pc * 8;
+    r.v[k] = (pc < 160 && el < W5) ? *reinterpret_cast<const uint4*>(rowp + el) : make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+__device__ __forceinline__ void raw_to_own(const Raw<float>& r, char* wl, int lane, float (&p)[CPT]) {
+  VQF_WAVE_FENCE();
+#pragma unroll
+  for (int k = 0; k < 5; ++k) *reinterpret_cast<f32x4*>(wl + (64 * k + lane) * 16) = r.v[k];
+  VQF_WAVE_FENCE();
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const f32x4 x = *reinterpret_cast<const f32x4*>(wl + lane * 80 + 16 * i);
+    p[4 * i] = x[0]; p[4 * i + 1] = x[1]; p[4 * i + 2] = x[2]; p[4 * i + 3] = x[3];
+  }
+}
+__device__ __forceinline__ void raw_to_own(const Raw<__bf16>& r, char* wl, int lane, float (&p)[CPT]) {
+  VQF_WAVE_FENCE();
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    if (64 * k + lane < 160) *reinterpret_cast<uint4*>(wl + (64 * k + lane) * 16) = r.v[k];
+  VQF_WAVE_FENCE();
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const uint2 x = *reinterpret_cast<const uint2*>(wl + lane * 40 + 8 * i);
+    p[4 * i] = __uint_as_float(x.x << 16); p[4 * i + 1] = __uint_as_float(x.x & 0xffff0000u);
+    p[4 * i + 2] = __uint_as_float(x.y << 16); p[4 * i + 3] = __uint_as_float(x.y & 0xffff0000u);
+  }
+}
+// the reverse: every thread's 20 values -> the wave's span of a row, stored as lane-linear 16-byte pieces
+__device__ __forceinline__ void own_store(float* __restrict__ rowp, int W5, int wave, int lane, char* wl,
+                                          const float (&v)[CPT]) {
+  VQF_WAVE_FENCE();
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+    *reinterpret_cast<f32x4*>(wl + lane * 80 + 16 * i) = f32x4{v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
+  VQF_WAVE_FENCE();
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int pc = 64 * k + lane, el = wave * WSPAN + pc * 4;
+    if (el < W5) *reinterpret_cast<f32x4*>(rowp + el) = *reinterpret_cast<const f32x4*>(wl + pc * 16);
+  }
+}
+__device__ __forceinline__ void own_store(__bf16* __restrict__ rowp, int W5, int wave, int lane, char* wl,
+                                          const float (&v)[CPT]) {
+  VQF_WAVE_FENCE();
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    __bf16 h[4] = {(__bf16)v[4 * i], (__bf16)v[4 * i + 1], (__bf16)v[4 * i + 2], (__bf16)v[4 * i + 3]};
+    *reinterpret_cast<uint2*>(wl + lane * 40 + 8 * i) = *reinterpret_cast<const uint2*>(h);
+  }
+  VQF_WAVE_FENCE();
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int pc = 64 * k + lane, el = wave * WSPAN + pc * 8;
+    if (pc < 160 && el < W5) *reinterpret_cast<uint4*>(rowp + el) = *reinterpret_cast<const uint4*>(wl + pc * 16);
+  }
+}
+
 // scale[i] = keep ? 1/(1-p) : 0 for the 20 elements starting at flat index e0 (e0 % 4 == 0)
 __device__ __forceinline__ void keep_scale20(const uint8_t* __restrict__ keep, uint64_t seed,
                                              uint32_t thr, float inv_keep, long long e0,
@@ -91,7 +178,7 @@ __device__ __forceinline__ void keep_scale20(const uint8_t* __restrict__ keep, u
 // 20 q values and the 20 projection biases of its columns held in registers (one row per block re-read
 // both for every row: 3x the load instructions); the next row's P chunk is fetched before the current
 // row is reduced.  Dropout keys on the flat element index, so the masks do not depend on this mapping.
-template <typename PT>
+template <typename PT, bool COAL>
 __global__ void __launch_bounds__(256)
 mfb_fuse_fwd_kernel(const PT* __restrict__ P, const float* __restrict__ pbias,
                     const float* __restrict__ q,
@@ -99,28 +186,37 @@ mfb_fuse_fwd_kernel(const PT* __restrict__ P, const float* __restrict__ pbias,
                     uint64_t seed, uint32_t thr, float inv_keep, int L, int O, int LS,
                     float* __restrict__ R, float* __restrict__ rowssq, float* __restrict__ zdrop) {
   __shared__ float red[2][4];
+  __shared__ __attribute__((aligned(16))) char tl[COAL ? 4 * WLDS : 16];
   const int n = blockIdx.x, ls = blockIdx.y;
   const int W5 = KP * O;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int nt = O / TPT;                       // active threads (250 at O = 1000); O / TPT <= 256
   const bool act = tid < nt;
   float qq[CPT], pb[CPT], p[CPT], pn[CPT];
+  Raw<PT> rn;                                   // COAL: the next row's span of this wave, lane-linear pieces
 #pragma unroll
-  for (int i = 0; i < CPT; ++i) { qq[i] = 0.f; pb[i] = 0.f; pn[i] = 0.f; }
+  for (int i = 0; i < CPT; ++i) { qq[i] = 0.f; pb[i] = 0.f; pn[i] = 0.f; p[i] = 0.f; }
   if (act) {
     load20(q + (long long)n * W5 + CPT * tid, qq);
     if (pbias) load20(pbias + CPT * tid, pb);
-    if (ls < L) load20(P + ((long long)n * L + ls) * W5 + CPT * tid, pn);
+    if (!COAL && ls < L) load20(P + ((long long)n * L + ls) * W5 + CPT * tid, pn);
   }
+  if (COAL && ls < L) raw_load(P + ((long long)n * L + ls) * W5, W5, wave, lane, rn);     // every lane of the wave
   int it = 0;
   for (int l = ls; l < L; l += LS, ++it) {
     const long long row = (long long)n * L + l;
     const long long e0 = row * W5 + (long long)CPT * tid;
     float ssq = 0.f;
+    if (COAL) {
+      raw_to_own(rn, tl + wave * WLDS, lane, p);
+      if (l + LS < L) raw_load(P + (row + LS) * W5, W5, wave, lane, rn);   // prefetch the next row of this block
+    }
     if (act) {
+      if (!COAL) {
 #pragma unroll
-      for (int i = 0; i < CPT; ++i) p[i] = pn[i];
-      if (l + LS < L) load20(P + (row + LS) * W5 + CPT * tid, pn);      // prefetch the next row of this block
+        for (int i = 0; i < CPT; ++i) p[i] = pn[i];
+        if (l + LS < L) load20(P + (row + LS) * W5 + CPT * tid, pn);      // prefetch the next row of this block
+      }
       float sc[CPT], cc[CPT];
       keep_scale20(keep, seed, thr, inv_keep, e0, sc);
 #pragma unroll
@@ -152,7 +248,7 @@ mfb_fuse_fwd_kernel(const PT* __restrict__ P, const float* __restrict__ pbias,
 }
 
 // grid (N, LS); block 256.  Each block walks rows l = ls, ls+LS, ... of sample n.
-template <bool CASC, bool DBIAS, typename DPT, typename PT>
+template <bool CASC, bool DBIAS, typename DPT, typename PT, bool COAL>
 __global__ void __launch_bounds__(256)
 mfb_fuse_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ dzdrop,
                     const float* __restrict__ Y,
@@ -163,57 +259,85 @@ mfb_fuse_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ dzdr
                     const uint8_t* __restrict__ keep, uint64_t seed, uint32_t thr, float inv_keep,
                     int L, int O, int LS, DPT* __restrict__ dP, float* __restrict__ dq_part,
                     float* __restrict__ dcascade, float* __restrict__ db_part) {
+  __shared__ __attribute__((aligned(16))) char tl[COAL ? 4 * WLDS : 16];
   const int n = blockIdx.x, ls = blockIdx.y;
   const int W5 = KP * O;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const float ca = coefA[n], cb = coefB[n], hi = 0.5f * inv[n];
-  for (int t = threadIdx.x; t < O / TPT; t += 256) {
+  // COAL (O / 4 <= 256: one pass): every lane of a wave takes part in the coalesced P loads / dP stores, threads past
+  // O / 4 only skip the arithmetic
+  for (int t = threadIdx.x; COAL ? t < 256 : t < O / TPT; t += 256) {
+    const bool act = t < O / TPT;
     float qq[CPT], dq[CPT], db[CPT], pb[CPT];
-    load20(q + (long long)n * W5 + CPT * t, qq);
-    if (pbias) load20(pbias + CPT * t, pb);
 #pragma unroll
-    for (int i = 0; i < CPT; ++i) { dq[i] = 0.f; db[i] = 0.f; }
+    for (int i = 0; i < CPT; ++i) { qq[i] = 0.f; pb[i] = 0.f; dq[i] = 0.f; db[i] = 0.f; }
+    if (act) {
+      load20(q + (long long)n * W5 + CPT * t, qq);
+      if (pbias) load20(pbias + CPT * t, pb);
+    }
     for (int l = ls; l < L; l += LS) {
       const long long row = (long long)n * L + l;
       const long long e0 = row * W5 + (long long)CPT * t;
-      const f32x4 dy = *reinterpret_cast<const f32x4*>(dY + row * O + TPT * t);
-      const f32x4 y = *reinterpret_cast<const f32x4*>(Y + row * O + TPT * t);
-      float p[CPT], sc[CPT], cc[CPT];
-      load20(P + e0, p);
-      if (pbias) {
+      float p[CPT], sc[CPT], cc[CPT], dp[CPT], dc[CPT], dzx[CPT];
 #pragma unroll
-        for (int i = 0; i < CPT; ++i) p[i] += pb[i];
+      for (int i = 0; i < CPT; ++i) { p[i] = 0.f; dp[i] = 0.f; }
+      if (COAL) {
+        Raw<PT> rw;
+        raw_load(P + row * W5, W5, wave, lane, rw);
+        raw_to_own(rw, tl + wave * WLDS, lane, p);
       }
-      if (CASC) load20(cascade + e0, cc);
-      keep_scale20(keep, seed, thr, inv_keep, e0, sc);
-      float ds[TPT];
+      if (act) {
+        const f32x4 dy = *reinterpret_cast<const f32x4*>(dY + row * O + TPT * t);
+        const f32x4 y = *reinterpret_cast<const f32x4*>(Y + row * O + TPT * t);
+        if (!COAL) load20(P + e0, p);
+        if (pbias) {
 #pragma unroll
-      for (int j = 0; j < TPT; ++j) {
-        const float ay = fabsf(y[j]);
-        // d sqrt(relu(s)) - sqrt(relu(-s)) = 0.5/|R| for R != 0, and 0 at 0 (relu'(0) = 0)
-        ds[j] = ay > 0.f ? (ca * dy[j] - cb * y[j]) * (hi / ay) : 0.f;
-      }
-      float dp[CPT], dc[CPT], dzx[CPT];
-      if (dzdrop) load20(dzdrop + e0, dzx);
-#pragma unroll
-      for (int i = 0; i < CPT; ++i) {
-        const float dz = (dzdrop ? ds[i / KP] + dzx[i] : ds[i / KP]) * sc[i];
-        if (CASC) {
-          dp[i] = dz * qq[i] * cc[i];
-          dq[i] += dz * p[i] * cc[i];
-          dc[i] = dz * p[i] * qq[i];
-        } else {
-          dp[i] = dz * qq[i];
-          dq[i] += dz * p[i];
+          for (int i = 0; i < CPT; ++i) p[i] += pb[i];
         }
-        if (DBIAS) db[i] += dp[i];
+        if (CASC) load20(cascade + e0, cc);
+        keep_scale20(keep, seed, thr, inv_keep, e0, sc);
+        float ds[TPT];
+#pragma unroll
+        for (int j = 0; j < TPT; ++j) {
+          const float ay = fabsf(y[j]);
+          // d sqrt(relu(s)) - sqrt(relu(-s)) = 0.5/|R| for R != 0, and 0 at 0 (relu'(0) = 0)
+          ds[j] = ay > 0.f ? (ca * dy[j] - cb * y[j]) * (hi / ay) : 0.f;
+        }
+        if (dzdrop) load20(dzdrop + e0, dzx);
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+          const float dz = (dzdrop ? ds[i / KP] + dzx[i] : ds[i / KP]) * sc[i];
+          if (CASC) {
+            dp[i] = dz * qq[i] * cc[i];
+            dq[i] += dz * p[i] * cc[i];
+            dc[i] = dz * p[i] * qq[i];
+          } else {
+            dp[i] = dz * qq[i];
+            dq[i] += dz * p[i];
+          }
+          if (DBIAS) db[i] += dp[i];
+        }
+        if (!COAL) store20(dP + e0, dp);
+        if (CASC) store20(dcascade + e0, dc);
       }
-      store20(dP + e0, dp);
-      if (CASC) store20(dcascade + e0, dc);
+      if (COAL) own_store(dP + row * W5, W5, wave, lane, tl + wave * WLDS, dp);
     }
-    const long long po = ((long long)n * LS + ls) * W5 + CPT * t;
-    store20(dq_part + po, dq);
-    if (DBIAS) store20(db_part + po, db);
+    if (act) {
+      const long long po = ((long long)n * LS + ls) * W5 + CPT * t;
+      store20(dq_part + po, dq);
+      if (DBIAS) store20(db_part + po, db);
+    }
   }
+}
+
+// Coalesced (LDS-transposed) P / dP access: measured at the headline shape it pays for the fp32 backward only (1.10 ->
+// 0.985 ms: the strided dP stores go away); the forward is unchanged (0.486 vs 0.483 ms without dropout) and the bf16
+// kernels lose occupancy to the extra registers (0.44 -> 0.51 ms).  VQF_FUSE_COAL=0 / 1 forces it off / on everywhere.
+bool fuse_coalesced(bool fp32_backward) {
+  const char* e = getenv("VQF_FUSE_COAL");
+  if (e && e[0] == '0') return false;
+  if (e && e[0] == '1') return true;
+  return fp32_backward;
 }
 
 int pick_ls_fwd(int N, int L) {
@@ -262,15 +386,19 @@ static int fuse_bwd_impl(const float* dY, const float* dzdrop, const float* Y, c
   const float inv_keep = (keep || p_drop > 0.f) ? 1.0f / (1.0f - p_drop) : 1.0f;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(N, LS);
-#define VQF_BWD(C_, D_, T_, PT_)                                                               \
-  VQF_LAUNCH(KID_MFB_FUSE_BWD, (mfb_fuse_bwd_kernel<C_, D_, T_, PT_>), grid, dim3(256), 0, s, dY, dzdrop, Y, inv, \
+  // coalesced P / dP access through the LDS transpose: one pass of 256 threads over the row, whole 16-byte pieces
+  const bool coal = fuse_coalesced(!p_bf16 && !dp_bf16) && O / TPT <= 256 && (W5 % ((p_bf16 || dp_bf16) ? 8 : 4) == 0);
+#define VQF_BWD1(C_, D_, T_, PT_, CO_)                                                           \
+  VQF_LAUNCH(KID_MFB_FUSE_BWD, (mfb_fuse_bwd_kernel<C_, D_, T_, PT_, CO_>), grid, dim3(256), 0, s, dY, dzdrop, Y, inv, \
              coefA, coefB, (const PT_*)P, pbias, q, cascade, keep, seed, thr, inv_keep, L, O, LS, (T_*)dP, dq_part, \
              dcascade, db_part)
+#define VQF_BWD(C_, D_, T_, PT_) do { if (coal) VQF_BWD1(C_, D_, T_, PT_, true); else VQF_BWD1(C_, D_, T_, PT_, false); } while (0)
   if (p_bf16)       { if (dbiasP) VQF_BWD(false, true, __bf16, __bf16); else VQF_BWD(false, false, __bf16, __bf16); }
   else if (dp_bf16) { if (dbiasP) VQF_BWD(false, true, __bf16, float); else VQF_BWD(false, false, __bf16, float); }
   else if (cascade) { if (dbiasP) VQF_BWD(true, true, float, float); else VQF_BWD(true, false, float, float); }
   else              { if (dbiasP) VQF_BWD(false, true, float, float); else VQF_BWD(false, false, float, float); }
 #undef VQF_BWD
+#undef VQF_BWD1
   int rc = vqf_last_error();
   if (rc) return rc;
   if (!direct) {
@@ -297,12 +425,13 @@ static int fuse_fwd_impl(const void* P, int p_bf16, const float* pbias, const fl
   const uint32_t thr = (keep || p_drop == 0.f) ? 0u : drop_threshold_host(p_drop);
   const float inv_keep = (keep || p_drop > 0.f) ? 1.0f / (1.0f - p_drop) : 1.0f;
   const int LS = pick_ls_fwd(N, L);
-  if (p_bf16)
-    VQF_LAUNCH(KID_MFB_FUSE_FWD, mfb_fuse_fwd_kernel<__bf16>, dim3(N, LS), dim3(256), 0, (hipStream_t)stream,
-               (const __bf16*)P, pbias, q, cascade, keep, seed, thr, inv_keep, L, O, LS, R, rowssq, zdrop);
-  else
-    VQF_LAUNCH(KID_MFB_FUSE_FWD, mfb_fuse_fwd_kernel<float>, dim3(N, LS), dim3(256), 0, (hipStream_t)stream,
-               (const float*)P, pbias, q, cascade, keep, seed, thr, inv_keep, L, O, LS, R, rowssq, zdrop);
+  const bool coal = fuse_coalesced(false) && ((KP * O) % (p_bf16 ? 8 : 4) == 0);
+#define VQF_FWD(PT_, CO_)                                                                                             \
+  VQF_LAUNCH(KID_MFB_FUSE_FWD, (mfb_fuse_fwd_kernel<PT_, CO_>), dim3(N, LS), dim3(256), 0, (hipStream_t)stream,         \
+             (const PT_*)P, pbias, q, cascade, keep, seed, thr, inv_keep, L, O, LS, R, rowssq, zdrop)
+  if (p_bf16) { if (coal) VQF_FWD(__bf16, true); else VQF_FWD(__bf16, false); }
+  else        { if (coal) VQF_FWD(float, true); else VQF_FWD(float, false); }
+#undef VQF_FWD
   return vqf_last_error();
 }
 

@@ -416,6 +416,9 @@ int launch(const BigArgs& g, hipStream_t s) {
   return vqf_last_error();
 }
 
+#ifndef F32BIG_MIN_K
+#define F32BIG_MIN_K 1536
+#endif
 #ifndef F32BIG_WGRAD_MIN_BLOCKS
 #define F32BIG_WGRAD_MIN_BLOCKS 256   // co_att_conv1's wgrad: 16 tiles x 16 splits = one full round, 1.71 -> 1.52 ms
 #endif
@@ -429,7 +432,7 @@ bool big_applies(int ta, int tb, int M, int N, int K, int flags, size_t ws_bytes
   // costs mid-size launches more than the kernel gains (HieCoAtten, 392-tile GEMMs: step 5.57 -> 5.77 ms) ...
   const int tiles = ((M + TM - 1) / TM) * ((N + TN - 1) / TN);
   // (and a K long enough to amortise the tile's prologue / 256 KB epilogue: at K = 1024 the 128x128 kernel is 5 % faster)
-  if (tiles >= 1024) return K >= 1536;
+  if (tiles >= 1024) return K >= F32BIG_MIN_K;
   // ... and the deep-K weight gradients (both operands K-major, few tiles, K = N*L): img_conv1d's 20 x 8 tiles x 8
   // splits of 784 slabs each, co_att_conv1's 4 x 4 tiles x 16 splits (one workgroup per CU, 392 slabs each).
   if (ta && tb && K >= 16384 && tiles * pick_splits(tiles, K, M, N, ws_bytes) >= F32BIG_WGRAD_MIN_BLOCKS) return true;   // needs its slabs
