@@ -13,16 +13,19 @@
 //     XOR (row >> 2) & 3 on the copy's source address and on the ds_read_b128; a lane's 4 floats feed
 //     4 MFMAs: lane (r, h) holds k = 8h + 4ks + e of row r for MFMA (ks, e).
 //   * K-major operand: [k][256] floats (1 KB k-rows, a wave copy = one k-row, whole lines).  The rows of the
-//     wave's strip are INTERLEAVED over its MFMA tiles: A row 4r+i belongs to row-tile i (B column 2c+j to column-tile
-//     j), so ONE ds_read_b128 (ds_read_b64) of a k-row hands lane r the operand value of all 4 (2) tiles: per k-pair
-//     and wave 2 LDS instructions feed 8 MFMAs, conflict-free without a swizzle (32 lanes read 512 contiguous
+//     wave's strip are INTERLEAVED over its MFMA tiles: A row 2r+i belongs to row-tile i (B column 4c+j to column-tile
+//     j), so ONE ds_read_b64 (ds_read_b128) of a k-row hands lane r the operand value of all 2 (4) tiles: per k-pair
+//     and wave 2 LDS instructions feed 8 MFMAs, conflict-free without a swizzle (32 lanes read 256 / 512 contiguous
 //     bytes).  The accumulator -> output map follows: tile (i, j), MFMA row rm, MFMA column cm is output row
-//     4 rm + i (K-major A) and column 2 cm + j (K-major B), so a lane's two column-tiles are 8 contiguous bytes.
-//     (Round 1 read these fragments as 4 ds_read_b32 per tile and kept the weight gradients on the 128x128 kernel.)
+//     2 rm + i (K-major A) and column 4 cm + j.  (Round 1 read these fragments as 4 ds_read_b32 per tile and kept the
+//     weight gradients on the 128x128 kernel.)
+//   * K-contiguous B: the same column interleave, by a row permutation on the copy's per-lane source address (LDS row
+//     32j + c of a wave strip holds column 4c + j; the loop is unchanged).  Either way a lane's four column tiles are 16
+//     contiguous output bytes: the epilogue issues 32 global_store_dwordx4 per lane and tile instead of 128 dword stores.
 //   * deterministic split-K for few-tile / long-K shapes (the weight gradient).
-//   * two loop forms: the lockstep loop (default: fragment reads one k-step ahead of the MFMAs, one barrier per slab)
-//     and the ping-pong loop of gemm_bf16_big.hip (VQF_GEMM_F32_PP=1, for A/Bs: with 64-cycle MFMAs the lockstep
-//     form is 5 % faster here).
+//   * three loop forms (gemm_f32_big_kernel's MODE, VQF_GEMM_F32_PP): lockstep (0), the ping-pong loop of
+//     gemm_bf16_big.hip (1: 5 % slower with 64-cycle MFMAs) and, the default, lockstep with waves 4-7 half a slab behind
+//     waves 0-3 (2).
 // Preconditions (else the caller uses gemm_f32.hip): K % 16 == 0, M >= 256, N >= 128, >= 1024 workgroups (tiles x
 // splits), no accumulate flag, 16-byte aligned bases, lda/ldb % 4 == 0, a K-major operand's row extent % 4 == 0.
 #include "common.h"
