@@ -342,6 +342,7 @@ bool fuse_coalesced(bool fp32_backward) {
 
 int pick_ls_fwd(int N, int L) {
   // forward: 8 blocks per CU worth of (sample, row-subset) pairs, at least ~8 rows per block
+  if (const char* e = getenv("VQF_FUSE_LS")) { const int v = atoi(e); if (v >= 1 && v <= L) return v; }   // tuning probe
   int ls = 1;
   while ((long long)N * ls < 4096 && ls * 16 <= L) ls *= 2;
   return ls;
@@ -349,6 +350,7 @@ int pick_ls_fwd(int N, int L) {
 
 int pick_ls(int N, int L) {
   // enough blocks to cover 256 CUs x 4, but never more splits than rows
+  if (const char* e = getenv("VQF_FUSE_LS_BWD")) { const int v = atoi(e); if (v >= 1 && v <= L && v <= 16) return v; }   // tuning probe
   int ls = 1;
   while ((long long)N * ls < 2048 && ls * 2 <= L && ls < 16) ls *= 2;
   return ls;
