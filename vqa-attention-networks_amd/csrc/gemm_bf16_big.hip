@@ -140,6 +140,32 @@ __device__ __forceinline__ bf16x8 read_frag(const char* s, int row0, int ks, int
   return __builtin_bit_cast(bf16x8, v);
 }
 
+// ---- tile order: split index slowest; bijective XCD remap (blocks b and b + 8 share an XCD's L2: each XCD walks a
+// contiguous run of the linear order), then groups of GROUP_M row tiles x all column tiles, row tile fastest
+struct TileCoord { int z, m0, n0, kbeg; };
+__device__ __forceinline__ TileCoord tile_coord(const BigArgs& g) {
+  const int ntiles = g.tiles_m * g.tiles_n;
+  const int z = blockIdx.x / ntiles;
+  int id = blockIdx.x % ntiles;
+  {
+    const int q8 = ntiles / 8, r8 = ntiles % 8, xcd = id % 8, k = id / 8;
+    id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
+  }
+  const int per_group = GROUP_M * g.tiles_n;
+  const int grp = id / per_group, in = id % per_group;
+  const int gm0 = grp * GROUP_M;
+  const int gsz = min(GROUP_M, g.tiles_m - gm0);
+  return TileCoord{z, (gm0 + in % gsz) * TM, (in / gsz) * TN, z * g.kchunk};
+}
+
+// all but the 4 * later youngest LDS-DMA copies of this wave have landed (4 copies per thread and slab)
+__device__ __forceinline__ void wait_copies(int later) {
+  if (later >= 3)      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if (later == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 template <bool GUARD_M, typename OT>
 __device__ __forceinline__ void store_tile(const BigArgs& g, OT* C, const f32x16 (&acc)[4][2], const float (&bv)[2],
                                            int row_base, int col0, bool relu) {
@@ -169,20 +195,8 @@ __global__ void __launch_bounds__(NT, 2) gemm_bf16_big_kernel(const BigArgs g) {
   const int wr = wave >> 2, wc = wave & 3;             // rows wr*128 .. +127, columns wc*64 .. +63
 
   // ---- tile order: split index slowest; bijective XCD remap, then groups of GROUP_M row tiles, m fastest
-  const int ntiles = g.tiles_m * g.tiles_n;
-  const int z = blockIdx.x / ntiles;
-  int id = blockIdx.x % ntiles;
-  {
-    const int q8 = ntiles / 8, r8 = ntiles % 8, xcd = id % 8, k = id / 8;
-    id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
-  }
-  const int per_group = GROUP_M * g.tiles_n;
-  const int grp = id / per_group, in = id % per_group;
-  const int gm0 = grp * GROUP_M;
-  const int gsz = min(GROUP_M, g.tiles_m - gm0);
-  const int tm = gm0 + in % gsz, tn = in / gsz;
-  const int m0 = tm * TM, n0 = tn * TN;
-  const int kbeg = z * g.kchunk;
+  const TileCoord tc = tile_coord(g);
+  const int z = tc.z, m0 = tc.m0, n0 = tc.n0, kbeg = tc.kbeg;
   const int S = (min(g.K, kbeg + g.kchunk) - kbeg) / TK;       // slabs of this split
 
   gbf16* qa[NG];
@@ -207,10 +221,7 @@ __global__ void __launch_bounds__(NT, 2) gemm_bf16_big_kernel(const BigArgs g) {
   int slot = 0;                                        // slot of slab s
   for (int s = 0; s < S; ++s) {
     const int later = min(NSLOT - 2, S - 1 - s);       // slabs issued after slab s that may stay in flight
-    if (later >= 3)      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // 2 * NG = 4 copies per thread per slab
-    else if (later == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wait_copies(later);
     __builtin_amdgcn_s_barrier();
     const char* sA = smem + slot * SLOT_BYTES;
     const char* sB = sA + OP_BYTES;
@@ -289,20 +300,8 @@ __global__ void __launch_bounds__(NT, 2) gemm_bf16_pp_kernel(const BigArgs g) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;             // rows wr*128 .. +127, columns wc*64 .. +63
 
-  const int ntiles = g.tiles_m * g.tiles_n;
-  const int z = blockIdx.x / ntiles;
-  int id = blockIdx.x % ntiles;
-  {
-    const int q8 = ntiles / 8, r8 = ntiles % 8, xcd = id % 8, k = id / 8;
-    id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
-  }
-  const int per_group = GROUP_M * g.tiles_n;
-  const int grp = id / per_group, in = id % per_group;
-  const int gm0 = grp * GROUP_M;
-  const int gsz = min(GROUP_M, g.tiles_m - gm0);
-  const int tm = gm0 + in % gsz, tn = in / gsz;
-  const int m0 = tm * TM, n0 = tn * TN;
-  const int kbeg = z * g.kchunk;
+  const TileCoord tc = tile_coord(g);
+  const int z = tc.z, m0 = tc.m0, n0 = tc.n0, kbeg = tc.kbeg;
   const int S = (min(g.K, kbeg + g.kchunk) - kbeg) / TK;       // slabs of this split (uniform over the workgroup)
 
   gbf16* qa[NG];
@@ -326,10 +325,7 @@ __global__ void __launch_bounds__(NT, 2) gemm_bf16_pp_kernel(const BigArgs g) {
     }
   {                                                    // my copies of slab 0 (4 per slab and thread)
     const int later = min(NSLOT - 1, S) - 1;
-    if (later >= 3)      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if (later == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wait_copies(later);
   }
   __builtin_amdgcn_s_barrier();                        // #0: every wave's copies of slab 0 have landed
   if (wr) __builtin_amdgcn_s_barrier();                // waves 4-7 fall half a slab behind (wave-uniform branch)
@@ -362,10 +358,7 @@ __global__ void __launch_bounds__(NT, 2) gemm_bf16_pp_kernel(const BigArgs g) {
     VQF_STAMP(t2);
     {                                                  // my copies of slab s+1; later slabs stay in flight
       const int later = min(s + NSLOT - 1 - VQF_PP_GLDS_M, S - 1) - (s + 1);
-      if (later >= 3)      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-      else if (later == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      wait_copies(later);
     }
     VQF_STAMP(t3);
     __builtin_amdgcn_s_waitcnt(0xC07F);                // lgkmcnt(0): fragments in registers, slot s no longer read by me
@@ -518,20 +511,8 @@ __global__ void __launch_bounds__(NT, 2) gemm_bf16_pp16_kernel(const BigArgs g) 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;             // rows wr*128 .. +127, column strip wc*64 .. +63
 
-  const int ntiles = g.tiles_m * g.tiles_n;
-  const int z = blockIdx.x / ntiles;
-  int id = blockIdx.x % ntiles;
-  {
-    const int q8 = ntiles / 8, r8 = ntiles % 8, xcd = id % 8, k = id / 8;
-    id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
-  }
-  const int per_group = GROUP_M * g.tiles_n;
-  const int grp = id / per_group, in = id % per_group;
-  const int gm0 = grp * GROUP_M;
-  const int gsz = min(GROUP_M, g.tiles_m - gm0);
-  const int tm = gm0 + in % gsz, tn = in / gsz;
-  const int m0 = tm * TM, n0 = tn * TN;
-  const int kbeg = z * g.kchunk;
+  const TileCoord tc = tile_coord(g);
+  const int z = tc.z, m0 = tc.m0, n0 = tc.n0, kbeg = tc.kbeg;
   const int S = (min(g.K, kbeg + g.kchunk) - kbeg) / TK;       // slabs of this split (uniform over the workgroup)
 
   gbf16* qa[NG];
@@ -553,10 +534,7 @@ __global__ void __launch_bounds__(NT, 2) gemm_bf16_pp16_kernel(const BigArgs g) 
     }
   {                                                    // my copies of slab 0 (4 per slab and thread)
     const int later = min(NSLOT - 1, S) - 1;
-    if (later >= 3)      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if (later == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wait_copies(later);
   }
   __builtin_amdgcn_s_barrier();                        // #0: every wave's copies of slab 0 have landed
   if (wr) __builtin_amdgcn_s_barrier();                // waves 4-7 fall half a slab behind (wave-uniform branch)
@@ -579,10 +557,7 @@ __global__ void __launch_bounds__(NT, 2) gemm_bf16_pp16_kernel(const BigArgs g) 
     }
     {                                                  // my copies of slab s+1; later slabs stay in flight
       const int later = min(s + NSLOT - 1 - VQF_PP_GLDS_M, S - 1) - (s + 1);
-      if (later >= 3)      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-      else if (later == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      wait_copies(later);
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);                // lgkmcnt(0): fragments in registers, slot s no longer read by me
     __builtin_amdgcn_sched_barrier(0);
