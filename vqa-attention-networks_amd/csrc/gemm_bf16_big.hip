@@ -67,6 +67,7 @@ struct BigArgs {
   const float* bias;
   int M, N, K, lda, ldb, ldc, flags;
   int tiles_m, tiles_n, kchunk, splits;
+  int group_m;           // row tiles per group of the tile order (pick_group_m)
 #ifdef VQF_PP_STAMPS
   unsigned long long* dbg;   // diagnostic build only (tools/pp_stamps.py): per workgroup and wave, 8 cycle sums
 #endif
@@ -151,10 +152,10 @@ __device__ __forceinline__ TileCoord tile_coord(const BigArgs& g) {
     const int q8 = ntiles / 8, r8 = ntiles % 8, xcd = id % 8, k = id / 8;
     id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
   }
-  const int per_group = GROUP_M * g.tiles_n;
+  const int per_group = g.group_m * g.tiles_n;
   const int grp = id / per_group, in = id % per_group;
-  const int gm0 = grp * GROUP_M;
-  const int gsz = min(GROUP_M, g.tiles_m - gm0);
+  const int gm0 = grp * g.group_m;
+  const int gsz = min(g.group_m, g.tiles_m - gm0);
   return TileCoord{z, (gm0 + in % gsz) * TM, (in / gsz) * TN, z * g.kchunk};
 }
 
@@ -622,6 +623,22 @@ int pick_splits(int tiles, int K, int M, int N, size_t ws_bytes) {
   return best;
 }
 
+// Row tiles per group of the tile order.  An XCD (private L2) works on a contiguous run of the order: the ~32 tiles
+// resident at a time when one split covers the chip, or its tiles / 8 share of EACH split for the few-tile split-K
+// launches (the image projection's weight gradient: 160 tiles -> 20 per XCD and split).  A run of `share` tiles
+// walked row-tile-fastest in groups of gm covers gm A panels + share / gm B panels: pick the gm in 4..8 that minimises
+// that, preferring one that divides the run (5 x 4 for the weight gradient: 12.3 -> 10.0 GB beyond L2, PMC).
+int pick_group_m(int tiles_m, int tiles_n, int splits) {
+  const int ntiles = tiles_m * tiles_n;
+  const int share = (splits > 1 && ntiles / 8 < 32) ? (ntiles / 8 > 0 ? ntiles / 8 : 1) : 32;
+  int best = GROUP_M, best_cost = 1 << 30;
+  for (int gm = 8; gm >= 4; --gm) {
+    const int cost = 4 * (gm + (share + gm - 1) / gm) + (share % gm ? 2 : 0) + (tiles_m % gm ? 1 : 0);
+    if (cost < best_cost) { best_cost = cost; best = gm; }
+  }
+  return best;
+}
+
 template <bool TA, bool TB>
 int launch(const BigArgs& g, hipStream_t s) {
   // > 64 KB of dynamic LDS needs the attribute, once per device and instantiation (common.h)
@@ -685,6 +702,7 @@ int vqf_gemm_bf16_big_try(int ta, int tb, int M, int N, int K, const void* A, in
   splits = (K + g.kchunk - 1) / g.kchunk;
   g.splits = splits;
   if (splits > 1) { g.C = (float*)ws; g.ldc = N; }
+  g.group_m = pick_group_m(g.tiles_m, g.tiles_n, splits);
 #ifdef VQF_PP_STAMPS
   g.dbg = (splits == 1 && ws && ws_bytes >= (size_t)tiles * 8 * 8 * 8) ? (unsigned long long*)ws : nullptr;
 #endif
