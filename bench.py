@@ -179,8 +179,9 @@ def main():
                     help="BASELINE config 1 shape of work: forward pass only (eval mode, no_grad); not the headline")
     ap.add_argument("--model", default="mfb", choices=["mfb", "mhb_coAtt", "hieCoAtten"],
                     help="mfb = the headline (BASELINE config 2/5); the others time configs 3 and 4")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
-                    help="operand type of the two large GEMM families (bf16 = BASELINE config 3 mode)")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "bf16-all"],
+                    help="bf16 = bf16 operands in the two large GEMM families (BASELINE config 3 mode); bf16-all = in every "
+                         "projection GEMM (ques_proj*, img_proj*, question attention too)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); "
                     "'gloo' lets several ranks share one GPU for rehearsals")
     args = ap.parse_args()
@@ -214,7 +215,7 @@ def main():
     init_like_reference(model)
     model = model.to(dev).train()
     if args.model != "hieCoAtten":
-        model.gemm_dtype = "bf16" if args.dtype == "bf16" else "fp32"
+        model.gemm_dtype = {"f32": "fp32", "bf16": "bf16", "bf16-all": "bf16-all"}[args.dtype]
     if args.miopen_lstm and hasattr(model, "use_hip_lstm"):
         model.use_hip_lstm = False
     if args.pruned and hasattr(model, "pruned"):
@@ -231,7 +232,7 @@ def main():
     opt = vqa_amd.Adam(model.parameters(), lr=7e-4)
     criterion = vqa_amd.train_step.criterion_for(args.model)
     img, q, a = synth_batch(B, rank, dev)
-    if args.dtype == "bf16" and args.model != "hieCoAtten":
+    if args.dtype != "f32" and args.model != "hieCoAtten":
         # the image grid is stored in bf16 (vqf_cast_f32_bf16 == what
         # FeatureStager(bf16=True) delivers); products accumulate in fp32
         img = ops.cast_bf16(img.view(-1, img.shape[-1])).view(img.shape)
@@ -352,11 +353,11 @@ def main():
                       else "QA-pairs/sec forward only, %s batch %d" % (args.model, B),
             "value": round(value, 2), "unit": "QA-pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.dtype != "f32" else "f32", "data": "synthetic",
             "config": {"workload": ("forward pass only (eval), " if args.forward_only else "") + (
                                    "MFB-baseline train step (fwd+loss+bwd+grad all-reduce+Adam), "
                                    "batch %d per GPU, 196x2048 image grid, 14 tokens, %s, mode=%s"
-                                   % (B, "fp32" if args.dtype == "f32" else "bf16 operands / fp32 accumulate",
+                                   % (B, "fp32" if args.dtype == "f32" else ("bf16 operands / fp32 accumulate" + (" in every projection GEMM" if args.dtype == "bf16-all" else "")),
                                       "pruned (NOT the headline: provably dead work skipped)" if args.pruned else "faithful")
                                    if args.model == "mfb" else "%s train step, batch %d per GPU, %s" % (args.model, B, args.dtype)),
                        "global_batch": B * world, "parallelism": "dp%d" % world,

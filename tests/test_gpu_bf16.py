@@ -119,6 +119,46 @@ def test_models_in_bf16_mode_track_the_fp32_oracle(mhb):
         assert float((gb[k] - g_ref).norm()) <= 0.1 * float(g_ref.norm()) + 1e-9, k
 
 
+@pytest.mark.parametrize("mhb", [False, True])
+def test_models_in_bf16_all_mode(mhb):
+    """gemm_dtype='bf16-all': bf16 operands also in ques_proj1, the final blocks' ques_proj* / img_proj* and the
+    question-attention conv (forward, dgrad, weight gradient).  Outputs within the stated bf16 tolerance 3e-2 of the
+    fp32 mode (which is parity-proven against the oracle); every gradient finite; the classifier's gradient (the one
+    tensor downstream of every signed square root) within 10 %; the other deviations are reported."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import vqa_amd, recipe
+    from cases import MFB_CASES, MHBCOATT_CASES
+    from golden_util import mfb_inputs
+    case = dict((MHBCOATT_CASES if mhb else MFB_CASES)[-1 if mhb else -2], N=8)      # full-size dims, N = 8 (bf16 GEMMs need M % 8 == 0)
+    cfg, img, q, glove, hard, soft = mfb_inputs(case, "cuda")
+    model = (vqa_amd.MHBCoAtt if mhb else vqa_amd.MFB)(cfg)
+    model.load_state_dict({k: torch.from_numpy(recipe.weight_for(k, tuple(v.shape), case["salt"]))
+                           for k, v in model.state_dict().items()})
+    model = model.cuda().train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    if not mhb:
+        model.unit_softmax = False
+    res = {}
+    for mode in ("fp32", "bf16", "bf16-all"):
+        model.gemm_dtype = mode
+        model.zero_grad(set_to_none=True)
+        out = model.forward(img, q)
+        loss = torch.nn.KLDivLoss()(out, soft) if mhb else torch.nn.CrossEntropyLoss()(out, hard)
+        loss.backward()
+        res[mode] = (out.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters()})
+    ref, gref = res["fp32"]
+    out, gb = res["bf16-all"]
+    assert _rel(out, ref) <= 3e-2
+    assert not torch.equal(out, res["bf16"][0])              # the additional bf16 GEMMs really ran
+    assert all(torch.isfinite(g).all() for g in gb.values())
+    dev = {k: float((gb[k] - g).norm() / (g.norm() + 1e-30)) for k, g in gref.items() if float(g.norm()) > 1e-9}
+    print("bf16-all vs fp32 gradients (relative deviation): " + " ".join("%s=%.3f" % kv for kv in dev.items()))
+    assert dev["linear_pred.weight"] <= 0.1 and dev["linear_pred.bias"] <= 0.1
+
+
 # ---- bf16 FEATURE STORAGE (SURVEY 8f rank 3): the image grid kept in bf16 in HBM ------------------
 @pytest.mark.parametrize("G,unit", [(2, False), (2, True), (1, False)])
 @pytest.mark.parametrize("N,S,C", [(3, 196, 2048), (2, 20, 96), (2, 7, 52)])

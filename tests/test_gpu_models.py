@@ -271,7 +271,7 @@ def test_config3_mhbcoatt_full_batch_512_prefix_causality():
     assert rel_err(out[:4].detach().cpu().numpy(), ref.numpy()) <= OUT_TOL
 
 
-@pytest.mark.parametrize("mhb,dtype", [(False, "fp32"), (True, "fp32"), (True, "bf16")])
+@pytest.mark.parametrize("mhb,dtype", [(False, "fp32"), (True, "fp32"), (True, "bf16"), (True, "bf16-all"), (False, "bf16-all")])
 def test_training_step_is_bitwise_reproducible(mhb, dtype):
     """No atomics on data anywhere on the path (split-K slabs, two-stage column reductions, fixed-order
     sums in the LSTM / glimpse / loss kernels) and Philox dropout keyed by torch's CPU generator: the same
@@ -365,7 +365,8 @@ def test_config2_mfb_batch_512_gradients_vs_oracle_live_softmax():
     grad_parity(grads, res[0][1], res[1][1])
 
 
-def test_config3_mhbcoatt_batch_512_bf16_mode():
+@pytest.mark.parametrize("bf16_mode", ["bf16", "bf16-all"])
+def test_config3_mhbcoatt_batch_512_bf16_mode(bf16_mode):
     """BASELINE config 3 as stated: MHBCoAtt, B=512, gemm_dtype='bf16' (bf16 operands in img_conv1d /
     co_att_conv1 through gemm_bf16_big.hip incl. its weight-gradient layout, bf16 image / projection storage,
     bf16 dP), fwd+bwd.  Rows 0..3 against the fp32 oracle on the 4-sample prefix (the batch-axis recursion is
@@ -382,15 +383,15 @@ def test_config3_mhbcoatt_batch_512_bf16_mode():
     soft = torch.softmax(torch.randn((512, 1000), generator=torch.Generator().manual_seed(1236)), 1)
     img_d, q_d, soft_d = img.cuda(), q.cuda(), soft.cuda()
     res = {}
-    for mode in ("bf16", "fp32"):
+    for mode in (bf16_mode, "fp32"):
         model.gemm_dtype = mode
         model.zero_grad(set_to_none=True)
-        x = vqa.ops.cast_bf16(img_d.view(-1, 2048)).view(img_d.shape) if mode == "bf16" else img_d   # bf16 feature storage
+        x = vqa.ops.cast_bf16(img_d.view(-1, 2048)).view(img_d.shape) if mode != "fp32" else img_d   # bf16 feature storage
         out = model.forward(x, q_d)
         torch.nn.KLDivLoss()(out, soft_d).backward()
         torch.cuda.synchronize()
         res[mode] = (out.detach().clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters()})
-    out, gb = res["bf16"]
+    out, gb = res[bf16_mode]
     assert torch.allclose(out.exp().sum(1).cpu(), torch.ones(512), atol=1e-4)
     assert all(torch.isfinite(v).all() for v in gb.values())
     sd = recipe_sd(O.mfb_shapes(cfg, mhb=True), case["salt"])
@@ -419,4 +420,4 @@ def test_config3_mhbcoatt_batch_512_bf16_mode():
                 worst, worst_k = d, k
             assert d <= 0.1, (k, d)
     print("config 3 bf16 vs fp32 gradients at B=512 (relative deviation per tensor): " + " ".join(info))
-    _report_parity("test_config3_mhbcoatt_batch_512_bf16_mode (bf16 vs fp32 grads, bound 0.1)", worst / 0.1, worst_k)
+    _report_parity("test_config3_mhbcoatt_batch_512_bf16_mode[%s] (bf16 vs fp32 grads, bound 0.1)" % bf16_mode, worst / 0.1, worst_k)

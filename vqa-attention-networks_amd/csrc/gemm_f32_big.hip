@@ -320,7 +320,7 @@ __global__ void __launch_bounds__(NT, 2) gemm_f32_big_kernel(const BigArgs g) {
       slot = (slot + 1 == NSLOT) ? 0 : slot + 1;
     }
   } else {
-    static_assert(!PP || (2 * NG == 4 && NSLOT == 5 && TK == 16), "the ping-pong loop assumes 4 copies per thread per slab, 5 slots");
+    static_assert(!PP || (2 * NG == 4 && NSLOT >= 3 && TK == 16), "the ping-pong loop assumes 4 copies per thread per slab and at least 3 slots");
     wait_copies(min(NSLOT - 1, S) - 1);                // my copies of slab 0
     __builtin_amdgcn_s_barrier();                      // #0: every wave's copies of slab 0 have landed
     if (late) __builtin_amdgcn_s_barrier();            // waves 4-7 fall half a slab behind (wave-uniform branch)

@@ -22,22 +22,36 @@ def _w2d(w):
     return _c(w.reshape(w.shape[0], -1))
 
 
+def _bf16_ok(*dims):
+    """bf16 GEMM entry point: every extent that becomes a K or a K-major row extent must be a multiple of 8."""
+    return all(d % 8 == 0 for d in dims)
+
+
 class LinearFn(torch.autograd.Function):
-    """y = x @ W^T + b  (optionally relu).  x (M,K), W (N,K)."""
+    """y = x @ W^T + b  (optionally relu).  x (M,K), W (N,K).
+    bf16 (gemm_dtype "bf16-all"): bf16 operands / fp32 accumulate in the forward, the dgrad and the weight gradient
+    (operands cast once per use by vqf_cast_f32_bf16; bias, ReLU and every reduction stay fp32)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, relu=False):
+    def forward(ctx, x, w, b, relu=False, bf16=False):
         x = _c(x)
         w2 = _w2d(w)
-        y = ops.gemm(x, w2, bias=b, relu=relu)
-        ctx.save_for_backward(x, w, y if relu else None)
+        bf16 = bool(bf16) and _bf16_ok(x.shape[0], x.shape[1], w2.shape[0])
+        if bf16:
+            xb, wb = ops.cast_bf16(x), ops.cast_bf16(w2)
+            y = ops.gemm_bf16(xb, wb, bias=b, relu=relu)
+            ctx.save_for_backward(xb, w, y if relu else None, wb)
+        else:
+            y = ops.gemm(x, w2, bias=b, relu=relu)
+            ctx.save_for_backward(x, w, y if relu else None, None)
         ctx.has_bias = b is not None
         ctx.relu = relu
+        ctx.bf16 = bf16
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w, y = ctx.saved_tensors
+        x, w, y, wb = ctx.saved_tensors
         w2 = _w2d(w)
         dy = _c(dy)
         db = None
@@ -46,11 +60,18 @@ class LinearFn(torch.autograd.Function):
         elif ctx.has_bias and ctx.needs_input_grad[2]:
             db = ops.colsum(dy)
         dx = dw = None
+        if ctx.bf16:
+            dyb = ops.cast_bf16(dy)
+            if ctx.needs_input_grad[0]:
+                dx = ops.gemm_bf16(dyb, wb, tb=True)                         # dX = dY W      (M,K)
+            if ctx.needs_input_grad[1]:
+                dw = ops.gemm_bf16(dyb, x, ta=True, tb=True).view_as(w)      # dW = dY^T X    (N,K)
+            return dx, dw, db, None, None
         if ctx.needs_input_grad[0]:
             dx = ops.gemm(dy, w2, tb=True)                       # dX = dY W      (M,K)
         if ctx.needs_input_grad[1]:
             dw = ops.gemm(dy, x, ta=True, tb=True).view_as(w)    # dW = dY^T X    (N,K)
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
 class AttHeadFn(torch.autograd.Function):
@@ -222,37 +243,52 @@ class FinalMfbFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, qa, va, wq, bq, wv, bv, keep, seed, p_drop, cascade=None, want_zdrop=False):
+    def forward(ctx, qa, va, wq, bq, wv, bv, keep, seed, p_drop, cascade=None, want_zdrop=False, bf16=False):
         qa, va = _c(qa), _c(va)
         N = qa.shape[0]
         O = wq.shape[0] // ops.POOL_K
-        qq = ops.gemm(qa, _w2d(wq), bias=bq)
-        vv = ops.gemm(va, _w2d(wv), bias=bv)
+        wq2, wv2 = _w2d(wq), _w2d(wv)
+        bf16 = bool(bf16) and _bf16_ok(N, qa.shape[1], va.shape[1], wq2.shape[0])
+        if bf16:            # "bf16-all": both projections with bf16 operands, fp32 accumulate
+            qa_s, va_s, wqb, wvb = ops.cast_bf16(qa), ops.cast_bf16(va), ops.cast_bf16(wq2), ops.cast_bf16(wv2)
+            qq = ops.gemm_bf16(qa_s, wqb, bias=bq)
+            vv = ops.gemm_bf16(va_s, wvb, bias=bv)
+        else:
+            qa_s, va_s, wqb, wvb = qa, va, None, None
+            qq = ops.gemm(qa, wq2, bias=bq)
+            vv = ops.gemm(va, wv2, bias=bv)
         if cascade is not None:
             cascade = _c(cascade)
         y, norm, inv, zdrop = ops.mfb_fuse_fwd(vv, qq, N, 1, O, keep=keep, seed=seed, p_drop=p_drop,
                                                cascade=cascade, want_zdrop=want_zdrop)
-        ctx.save_for_backward(qa, va, wq, wv, qq, vv, y, norm, inv, keep, cascade)
-        ctx.seed, ctx.p_drop, ctx.dims = seed, p_drop, (N, O)
+        ctx.save_for_backward(qa_s, va_s, wq, wv, qq, vv, y, norm, inv, keep, cascade, wqb, wvb)
+        ctx.seed, ctx.p_drop, ctx.dims, ctx.bf16 = seed, p_drop, (N, O), bf16
         if want_zdrop:
             return y, zdrop
         return y
 
     @staticmethod
     def backward(ctx, dy, dz=None):
-        qa, va, wq, wv, qq, vv, y, norm, inv, keep, cascade = ctx.saved_tensors
+        qa, va, wq, wv, qq, vv, y, norm, inv, keep, cascade, wqb, wvb = ctx.saved_tensors
         N, O = ctx.dims
         dvv, dqq, dcasc, _ = ops.mfb_fuse_bwd(_c(dy), y, norm, inv, vv, qq, N, 1, O, keep=keep,
                                               seed=ctx.seed, p_drop=ctx.p_drop, cascade=cascade,
                                               dzdrop=None if dz is None else _c(dz))
-        wq2, wv2 = _w2d(wq), _w2d(wv)
-        dqa = ops.gemm(dqq, wq2, tb=True) if ctx.needs_input_grad[0] else None
-        dva = ops.gemm(dvv, wv2, tb=True) if ctx.needs_input_grad[1] else None
-        dwq = ops.gemm(dqq, qa, ta=True, tb=True).view_as(wq)
-        dwv = ops.gemm(dvv, va, ta=True, tb=True).view_as(wv)
+        if ctx.bf16:
+            dqb, dvb = ops.cast_bf16(dqq), ops.cast_bf16(dvv)
+            dqa = ops.gemm_bf16(dqb, wqb, tb=True) if ctx.needs_input_grad[0] else None
+            dva = ops.gemm_bf16(dvb, wvb, tb=True) if ctx.needs_input_grad[1] else None
+            dwq = ops.gemm_bf16(dqb, qa, ta=True, tb=True).view_as(wq)
+            dwv = ops.gemm_bf16(dvb, va, ta=True, tb=True).view_as(wv)
+        else:
+            wq2, wv2 = _w2d(wq), _w2d(wv)
+            dqa = ops.gemm(dqq, wq2, tb=True) if ctx.needs_input_grad[0] else None
+            dva = ops.gemm(dvv, wv2, tb=True) if ctx.needs_input_grad[1] else None
+            dwq = ops.gemm(dqq, qa, ta=True, tb=True).view_as(wq)
+            dwv = ops.gemm(dvv, va, ta=True, tb=True).view_as(wv)
         dbq = ops.colsum(dqq)
         dbv = ops.colsum(dvv)
-        return dqa, dva, dwq, dbq, dwv, dbv, None, None, None, dcasc, None
+        return dqa, dva, dwq, dbq, dwv, dbv, None, None, None, dcasc, None, None
 
 
 # ---------------------------------------------------------------------------------------------

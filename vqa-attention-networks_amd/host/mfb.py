@@ -23,7 +23,7 @@ def _image_is_data(img, gemm_dtype="fp32"):
     if not img.is_cuda:
         raise VqfError("vqa fusion modules need GPU tensors (HIP extension is the only path; no CPU fallback)")
     if img.dtype == torch.bfloat16:
-        if gemm_dtype not in ("bf16", "bf16-img"):
+        if gemm_dtype not in ("bf16", "bf16-img", "bf16-all"):
             raise VqfError("bf16 img_features need model.gemm_dtype = 'bf16' (or 'bf16-img'); "
                            "the fp32 path takes fp32 features")
         if img.shape[-1] % 8:
@@ -147,7 +147,10 @@ class MFB(nn.Module):
         # the pruned mode skips that work (96 % of the FLOPs) and returns bit-identical logits and gradients.
         self.pruned = False
         # "fp32" (default, parity 1e-4) or "bf16": bf16 operands / fp32 accumulate for the two large
-        # GEMM families (img_conv1d and co_att_conv1, 96 % of the FLOPs); everything else stays fp32
+        # GEMM families (img_conv1d and co_att_conv1, 96 % of the FLOPs); everything else stays fp32.
+        # "bf16-all": additionally ques_proj1, the final blocks' ques_proj* / img_proj* and the question-attention
+        # conv take bf16 operands (forward, dgrad and weight gradient); the classifier, the LSTM input projection
+        # (K = 300), the fusion / attention / normalisation arithmetic and every reduction stay fp32
         self.gemm_dtype = "fp32"
         # True: run img_conv1d (and, through autograd, its weight gradient) on a side stream, concurrently
         # with the question encoder / question attention (and their backward + gradient all-reduce).
@@ -192,7 +195,8 @@ class MFB(nn.Module):
 
     def forward(self, img_features, questions, is_training=True):
         _image_is_data(img_features, self.gemm_dtype)
-        bf16_img = self.gemm_dtype in ("bf16", "bf16-img")
+        bf16_img = self.gemm_dtype in ("bf16", "bf16-img", "bf16-all")
+        bf16_all = self.gemm_dtype == "bf16-all"          # also ques_proj*, img_proj*, the question-attention conv
         # a5 starts first, on the side stream: it only needs the image and its weights
         # bf16 mode keeps projection + fusion in one autograd node (ImgFuseFn): its backward hands dP to the
         # weight-gradient GEMM in bf16 without an fp32 round trip, which is worth more than the stream overlap
@@ -201,7 +205,7 @@ class MFB(nn.Module):
                                   self.overlap_streams == "same-stream") if side else None
         # a2: question encoder                                               mfb.py:68-70
         que_embedded = torch.tanh(self.word_embedding(questions))
-        lstm_o = batch_first_lstm(self.lstm, que_embedded, self.use_hip_lstm, self.gemm_dtype == "bf16")
+        lstm_o = batch_first_lstm(self.lstm, que_embedded, self.use_hip_lstm, self.gemm_dtype in ("bf16", "bf16-all"))
         ques_feature = self.dropout_l(lstm_o).contiguous()                 # (N,T,H)
         N, T, H = ques_feature.shape
         L = img_features.shape[1]
@@ -213,9 +217,9 @@ class MFB(nn.Module):
         wm, bm = self._mc('ques_att_multiconv')
         qa = AttHeadFn.apply(ques_feature.view(N * T, H), ques_feature,
                              self.ques_att_conv1.weight, self.ques_att_conv1.bias, wm, bm,
-                             self.ques_att_conv2.weight, self.ques_att_conv2.bias, self.unit_softmax)
+                             self.ques_att_conv2.weight, self.ques_att_conv2.bias, self.unit_softmax, bf16_all)
         # a4: ques_proj1                                                     mfb.py:92-93
-        qp = LinearFn.apply(qa, self.ques_proj1.weight, self.ques_proj1.bias)
+        qp = LinearFn.apply(qa, self.ques_proj1.weight, self.ques_proj1.bias, False, bf16_all)
         # a5+a6: image projection + MFB fusion over the regions             mfb.py:95-106
         pm = self.dropout_m.p
         seed, p = self._seeds.next(self.training, pm)
@@ -230,12 +234,12 @@ class MFB(nn.Module):
         wm, bm = self._mc('co_att_multiconv')
         va = AttHeadFn.apply(Y, img_features, self.co_att_conv1.weight, self.co_att_conv1.bias, wm, bm,
                              self.co_att_conv2.weight, self.co_att_conv2.bias, self.unit_softmax,
-                             self.gemm_dtype in ("bf16", "bf16-att"))
+                             self.gemm_dtype in ("bf16", "bf16-att", "bf16-all"))
         # a9: final MFB block                                                mfb.py:126-135
         seed, p = self._seeds.next(self.training, pm)
         k2 = keep.get('m2')
         y = FinalMfbFn.apply(qa, va, self.ques_proj2.weight, self.ques_proj2.bias,
                              self.img_proj2.weight, self.img_proj2.bias, k2, seed,
-                             pm if k2 is not None else p)
+                             pm if k2 is not None else p, None, False, bf16_all)
         # a10: classifier; the reference computes a softmax and discards it  mfb.py:137-140
         return LinearFn.apply(y, self.linear_pred.weight, self.linear_pred.bias)

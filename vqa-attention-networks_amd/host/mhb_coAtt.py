@@ -50,7 +50,8 @@ class MHBCoAtt(nn.Module):
         _image_is_data(img_features, self.gemm_dtype)
         N, L, D = img_features.shape
         keep = self._seeds.keep
-        bf16_img = self.gemm_dtype in ("bf16", "bf16-img")
+        bf16_img = self.gemm_dtype in ("bf16", "bf16-img", "bf16-all")
+        bf16_all = self.gemm_dtype == "bf16-all"          # also ques_proj*, img_proj*, the question-attention conv
         # bf16 mode keeps projection + fusion in one autograd node (ImgFuseFn): its backward hands dP to the
         # weight-gradient GEMM in bf16 without an fp32 round trip, which is worth more than the stream overlap
         side = self.overlap_streams and not (bf16_img and self.fuse_bf16_dp)
@@ -61,7 +62,7 @@ class MHBCoAtt(nn.Module):
             assert glove_matrix is not None, 'glove should not be NoneType.'
             que_embedded = torch.cat((que_embedded, glove_matrix), dim=2)
         if self.fix_lstm_orientation:
-            lstm_o = batch_first_lstm(self.lstm, que_embedded, self.use_hip_lstm, self.gemm_dtype == "bf16")   # (N,T,H)
+            lstm_o = batch_first_lstm(self.lstm, que_embedded, self.use_hip_lstm, self.gemm_dtype in ("bf16", "bf16-all"))   # (N,T,H)
             ques_feature = self.dropout_l(lstm_o).contiguous()
         elif (self.use_hip_lstm and self.lstm.num_layers == 1 and que_embedded.is_cuda
               and ops.lstm_seq_supported(que_embedded.shape[1], self.cfg.hidden_dim)):
@@ -70,7 +71,7 @@ class MHBCoAtt(nn.Module):
             # reference's lstm_o.permute(1,0,2).
             hs = LstmSeqFn.apply(que_embedded, self.lstm.weight_ih_l0, self.lstm.weight_hh_l0,
                                  self.lstm.bias_ih_l0, self.lstm.bias_hh_l0,
-                                 self.gemm_dtype == "bf16")     # bf16 mode: bf16 operands in the recurrent product
+                                 self.gemm_dtype in ("bf16", "bf16-all"))     # bf16 modes: bf16 operands in the recurrent product
             ques_feature = self.dropout_l(hs).contiguous()
         else:
             if self.use_hip_lstm:
@@ -84,8 +85,8 @@ class MHBCoAtt(nn.Module):
 
         qa = AttHeadFn.apply(ques_feature.view(N * T, H), ques_feature,
                              self.ques_att_conv1.weight, self.ques_att_conv1.bias, None, None,
-                             self.ques_att_conv2.weight, self.ques_att_conv2.bias, False)
-        qp = LinearFn.apply(qa, self.ques_proj1.weight, self.ques_proj1.bias)
+                             self.ques_att_conv2.weight, self.ques_att_conv2.bias, False, bf16_all)
+        qp = LinearFn.apply(qa, self.ques_proj1.weight, self.ques_proj1.bias, False, bf16_all)
         pm = self.dropout_m.p
         seed, p = self._seeds.next(self.training, pm)
         k1 = keep.get('m1')
@@ -97,13 +98,13 @@ class MHBCoAtt(nn.Module):
                                 k1, seed, pm if k1 is not None else p, bf16_img)
         va = AttHeadFn.apply(Y, img_features, self.co_att_conv1.weight, self.co_att_conv1.bias, None, None,
                              self.co_att_conv2.weight, self.co_att_conv2.bias, False,
-                             self.gemm_dtype in ("bf16", "bf16-att"))
+                             self.gemm_dtype in ("bf16", "bf16-att", "bf16-all"))
         ys = []
         for tag, qpj, ipj in (('m2', self.ques_proj2, self.img_proj2), ('m3', self.ques_proj3, self.img_proj3)):
             seed, p = self._seeds.next(self.training, pm)
             kk = keep.get(tag)
             ys.append(FinalMfbFn.apply(qa, va, qpj.weight, qpj.bias, ipj.weight, ipj.bias, kk, seed,
-                                       pm if kk is not None else p))
+                                       pm if kk is not None else p, None, False, bf16_all))
         att_normed_23 = torch.cat(ys, 1)                                     # (N,2000)  :147
         logits = LinearFn.apply(att_normed_23, self.linear_pred.weight, self.linear_pred.bias)
         return LogSoftmaxRowsFn.apply(logits)                                # :149-151 (implicit dim = 1 on the 2-D logits)
