@@ -10,23 +10,30 @@ ap.add_argument("--dtype", default="f32")
 args = ap.parse_args()
 ops = vqa_amd.ops
 vqa_amd.lib.load()
-cfg = bench.full_cfg(args.model)
-model = (vqa_amd.MFB if args.model == "mfb" else vqa_amd.MHBCoAtt)(cfg)
+HIE = args.model == "hieCoAtten"
+B = 256 if HIE else 512
+if HIE:
+    model = vqa_amd.HieCoAtten(block_num=196, word_num=14, img_size=2048, vocab_size=1000, embed_size=512,
+                               output_size=1000)
+else:
+    model = (vqa_amd.MFB if args.model == "mfb" else vqa_amd.MHBCoAtt)(bench.full_cfg(args.model))
 bench.init_like_reference(model)
 model = model.cuda().train()
-model.gemm_dtype = "bf16" if args.dtype == "bf16" else "fp32"
-model.overlap_streams = "same-stream"
+if not HIE:
+    model.gemm_dtype = "bf16" if args.dtype == "bf16" else "fp32"
+    model.overlap_streams = "same-stream"
 opt = vqa_amd.Adam(model.parameters(), lr=7e-4)
 crit = vqa_amd.train_step.criterion_for(args.model)
-img, q, a = bench.synth_batch(512, 0, "cuda")
-soft = torch.softmax(torch.randn((512, 1000)), 1).cuda()
+img, q, a = bench.synth_batch(B, 0, "cuda")
+soft = torch.softmax(torch.randn((B, 1000)), 1).cuda()
 if args.dtype == "bf16":
     img = ops.cast_bf16(img.view(-1, 2048)).view(img.shape)
 
 
 def step():
     opt.zero_grad(set_to_none=True)
-    loss = crit(model.forward(img, q), soft if args.model == "mhb_coAtt" else a)
+    out = model.forward(img, q)
+    loss = crit(out[0] if HIE else out, soft if args.model == "mhb_coAtt" else a)
     loss.backward()
     opt.step()
 
