@@ -315,3 +315,29 @@ def test_config4_hiecoatten_full_batch_256_row_pairing():
         ox, oav, _ = O.hiecoatten_forward(sd, img[2 * i:2 * i + 2], q[2 * i:2 * i + 2])
         assert rel_err(x[i].detach().cpu().numpy(), ox[0].numpy()) <= OUT_TOL
         assert rel_err(av[2 * i:2 * i + 2].detach().cpu().numpy(), oav.numpy()) <= OUT_TOL
+
+
+def test_config4_hiecoatten_full_batch_256_gradients_vs_oracle():
+    """BASELINE config 4 at its full batch, every output and every gradient: HieCoAtten, B=256, 196 regions x 2048,
+    fp32, dropout off, against the oracle run on the same batch in fp32 and fp64 (forward 1e-4, gradients by
+    grad_parity).  These are the shapes of the bench line for this model: the 50176-row img_emb GEMM, its
+    K = 50176 weight gradient and the 50176 x 512 x 512 ladder products."""
+    vqa = _vqa()
+    N, L, T = 256, 196, 14
+    case = dict(salt=26, img_size=2048, V=1000, E=512, A=1000)
+    model = _load(vqa.HieCoAtten(block_num=L, word_num=T, img_size=2048, vocab_size=1000, embed_size=512,
+                                 output_size=1000), case["salt"])
+    model.drop_p = 0.0
+    img = torch.relu(torch.randn((N, L, 2048), generator=torch.Generator().manual_seed(4331)))
+    q = torch.randint(1, 1000, (N, T), generator=torch.Generator().manual_seed(4332))
+    ans = torch.randint(0, 1000, (N,), generator=torch.Generator().manual_seed(4333))
+    x, av, aq = model.forward(img.cuda(), q.cuda())
+    torch.nn.CrossEntropyLoss()(x, ans.cuda()).backward()
+    torch.cuda.synchronize()
+    (ox, oav, oaq), g32, g64 = _hie_oracle_pair(case, img, q, ans)
+    assert rel_err(x.detach().cpu().numpy(), ox.numpy()) <= OUT_TOL
+    assert rel_err(av.detach().cpu().numpy(), oav.numpy()) <= OUT_TOL
+    assert rel_err(aq.detach().cpu().numpy(), oaq.numpy()) <= OUT_TOL
+    grads = _grads(model)
+    assert float(grads["img_emb.weight"].abs().max()) > 0.0 and model.fc_Wbq.weight.grad is None
+    grad_parity(grads, g32, g64)
