@@ -365,6 +365,37 @@ def test_config2_mfb_batch_512_gradients_vs_oracle_live_softmax():
     grad_parity(grads, res[0][1], res[1][1])
 
 
+def test_config3_shapes_mhbcoatt_batch_512_fp32_gradients_vs_oracle():
+    """MHBCoAtt at the full B=512 in fp32, every output row and every gradient against the oracle run on the SAME
+    512-sample batch in fp32 and fp64 (the batch-axis LSTM recursion, mhb_coAtt.py:72-74, makes row n depend on rows
+    0..n-1, so only the whole batch exercises the 512-step chain and its backward): forward 1e-4, gradients by
+    grad_parity.  Live softmax over T and L (MHBCoAtt normalises over the right axes), KLDiv loss as solver.py:27.
+    The oracle needs ~40 GB of host memory and 1-2 minutes."""
+    vqa = _vqa()
+    case = dict(name="c3g", salt=83, N=512, model_name="mhb_coAtt", glove=False,
+                H=1024, E=300, D=2048, L=196, V=1000, A=1000, T=14)
+    cfg = make_cfg(case)
+    model = _no_dropout_train(_load(vqa.MHBCoAtt(cfg), case["salt"]))
+    img = torch.relu(torch.randn((512, 196, 2048), generator=torch.Generator().manual_seed(1234)))
+    q = torch.randint(1, 1000, (512, 14), generator=torch.Generator().manual_seed(1235))
+    soft = torch.softmax(torch.randn((512, 1000), generator=torch.Generator().manual_seed(1236)), 1)
+    out = model.forward(img.cuda(), q.cuda())
+    torch.nn.KLDivLoss()(out, soft.cuda()).backward()
+    torch.cuda.synchronize()
+    grads = _named_grads(model)
+    res = []
+    for dt in (torch.float32, torch.float64):
+        sd = {k: v.to(dt).requires_grad_(True) for k, v in recipe_sd(O.mfb_shapes(cfg, mhb=True), case["salt"]).items()}
+        o = O.mhbcoatt_forward(sd, cfg, img.to(dt), q)
+        O.kldiv_loss(o, soft.to(dt)).backward()
+        res.append((o.detach(), {k: v.grad for k, v in sd.items()}))
+        del sd, o
+    assert rel_err(out.detach().cpu().numpy(), res[0][0].numpy()) <= OUT_TOL
+    assert rel_err(out.detach().cpu().numpy(), res[1][0].float().numpy()) <= OUT_TOL
+    assert float(grads["img_conv1d.weight"].abs().max()) > 0.0 and float(grads["lstm.weight_hh_l0"].abs().max()) > 0.0
+    grad_parity(grads, res[0][1], res[1][1])
+
+
 @pytest.mark.parametrize("bf16_mode", ["bf16", "bf16-all"])
 def test_config3_mhbcoatt_batch_512_bf16_mode(bf16_mode):
     """BASELINE config 3 as stated: MHBCoAtt, B=512, gemm_dtype='bf16' (bf16 operands in img_conv1d /
