@@ -413,6 +413,23 @@ class LogSoftmaxRowsFn(torch.autograd.Function):
         return ops.log_softmax_rows_bwd(_c(dy), y)
 
 
+def _lstm_in_proj(x2, w_ih, bias, bf16_proj):
+    """Input projection of a whole sequence, x2 (S*B, I) @ w_ih^T (+ b_ih + b_hh).  bf16_proj (gemm_dtype "bf16-all"):
+    bf16 operands, columns zero-padded to a multiple of 8 by the cast (I = 300 -> 304); returns the casts for the
+    backward."""
+    if not bf16_proj:
+        return ops.gemm(x2, _c(w_ih), bias=bias), None, None
+    xb, wb = ops.cast_bf16(x2), ops.cast_bf16(_c(w_ih))
+    return ops.gemm_bf16(xb, wb, bias=bias), xb, wb
+
+
+def _lstm_in_proj_bwd(dgb, xb, wb, I, need_dx):
+    """dX = dG W_ih and dW_ih = dG^T X with the bf16 operands of _lstm_in_proj (padded columns come back as zeros)."""
+    dx = ops.gemm_bf16(dgb, wb, tb=True)[:, :I].contiguous() if need_dx else None
+    dw = ops.gemm_bf16(dgb, xb, ta=True, tb=True)[:, :I].contiguous()
+    return dx, dw
+
+
 class LstmSeqFn(torch.autograd.Function):
     """Single-layer LSTM over dim 0 of x (S,B,I) -> hs (S,B,H), zero initial state.
 
@@ -427,21 +444,23 @@ class LstmSeqFn(torch.autograd.Function):
         S, B, I = x.shape
         H = w_hh.shape[1]
         bias = (b_ih + b_hh) if b_ih is not None else None
-        xw = ops.gemm(x.view(S * B, I), _c(w_ih), bias=bias).view(S, B, 4 * H)
-        ctx.bf16 = bool(bf16)          # bf16 operands in the recurrent product (bf16 mode), fp32 everywhere else
+        ctx.bf16 = bool(bf16)          # bf16 operands in the recurrent product (bf16 modes)
+        ctx.bf16_proj = bf16 == "all" and H % 8 == 0       # "bf16-all": also in the input projection and its gradients
+        xw, xb, wb = _lstm_in_proj(x.view(S * B, I), w_ih, bias, ctx.bf16_proj)
+        xw = xw.view(S, B, 4 * H)
         persist = (not ctx.bf16) and bool(ops.LSTM_PERSISTENT) and ops.lstm_persist_supported(B, H)
         ctx.persist_bwd = persist and ops.LSTM_PERSISTENT != "fwd"
         if persist:
             hs, cs, gates = ops.lstm_seq_fwd_persist(xw, _c(w_hh))
         else:
             hs, cs, gates = ops.lstm_seq_fwd(xw, _c(w_hh), bf16=ctx.bf16)
-        ctx.save_for_backward(x, w_ih, w_hh, hs, cs, gates)
+        ctx.save_for_backward(x, w_ih, w_hh, hs, cs, gates, xb, wb)
         ctx.has_bias = b_ih is not None
         return hs
 
     @staticmethod
     def backward(ctx, dhs):
-        x, w_ih, w_hh, hs, cs, gates = ctx.saved_tensors
+        x, w_ih, w_hh, hs, cs, gates, xb, wb = ctx.saved_tensors
         S, B, I = x.shape
         H = w_hh.shape[1]
         if ctx.persist_bwd:
@@ -449,12 +468,16 @@ class LstmSeqFn(torch.autograd.Function):
         else:
             dg = ops.lstm_seq_bwd(_c(dhs), gates, cs, _c(w_hh), bf16=ctx.bf16)
         dg2 = dg.view(S * B, 4 * H)
-        dx = ops.gemm(dg2, _c(w_ih), tb=True).view(S, B, I) if ctx.needs_input_grad[0] else None
-        dw_ih = ops.gemm(dg2, x.view(S * B, I), ta=True, tb=True)
+        dgb = ops.cast_bf16(dg2) if ctx.bf16 and H % 8 == 0 else None      # one cast serves every bf16 gradient product
+        if ctx.bf16_proj:
+            dx, dw_ih = _lstm_in_proj_bwd(dgb, xb, wb, I, ctx.needs_input_grad[0])
+            dx = dx.view(S, B, I) if dx is not None else None
+        else:
+            dx = ops.gemm(dg2, _c(w_ih), tb=True).view(S, B, I) if ctx.needs_input_grad[0] else None
+            dw_ih = ops.gemm(dg2, x.view(S * B, I), ta=True, tb=True)
         if S > 1:
-            if ctx.bf16 and H % 8 == 0:      # bf16 mode: the 60-GFLOP recurrent weight gradient takes bf16 operands too
-                dw_hh = ops.gemm_bf16(ops.cast_bf16(dg[1:].reshape((S - 1) * B, 4 * H)),
-                                      ops.cast_bf16(hs[:-1].reshape((S - 1) * B, H)), ta=True, tb=True)
+            if dgb is not None:              # bf16 modes: the 60-GFLOP recurrent weight gradient takes bf16 operands too
+                dw_hh = ops.gemm_bf16(dgb[B:], ops.cast_bf16(hs[:-1].reshape((S - 1) * B, H)), ta=True, tb=True)
             else:
                 dw_hh = ops.gemm(dg[1:].reshape((S - 1) * B, 4 * H), hs[:-1].reshape((S - 1) * B, H), ta=True, tb=True)
         else:
@@ -478,8 +501,10 @@ class LstmBatchFn(torch.autograd.Function):
         H = w_hh.shape[1]
         bias = (b_ih + b_hh) if b_ih is not None else None
         ctx.bf16 = bool(bf16) and H % 8 == 0
+        ctx.bf16_proj = ctx.bf16 and bf16 == "all"          # "bf16-all": input projection and every weight gradient too
         whh = ops.cast_bf16(_c(w_hh)) if ctx.bf16 else _c(w_hh)
-        gates = ops.gemm(x.view(T * B, I), _c(w_ih), bias=bias).view(T, B, 4 * H)   # pre-activations -> activated in place
+        gates, xb, wb = _lstm_in_proj(x.view(T * B, I), w_ih, bias, ctx.bf16_proj)
+        gates = gates.view(T, B, 4 * H)                     # pre-activations -> activated in place
         hs = torch.empty((T, B, H), dtype=torch.float32, device=x.device)
         cs = torch.empty_like(hs)
         for t in range(T):
@@ -489,13 +514,13 @@ class LstmBatchFn(torch.autograd.Function):
                 else:
                     ops.gemm(hs[t - 1], whh, out=gates[t], accumulate=True)
             ops.lstm_cell_fwd(gates[t], cs[t - 1] if t else None, cs[t], hs[t])
-        ctx.save_for_backward(x, w_ih, w_hh, hs, cs, gates)
+        ctx.save_for_backward(x, w_ih, w_hh, hs, cs, gates, xb, wb)
         ctx.has_bias = b_ih is not None
         return hs
 
     @staticmethod
     def backward(ctx, dhs):
-        x, w_ih, w_hh, hs, cs, gates = ctx.saved_tensors
+        x, w_ih, w_hh, hs, cs, gates, xb, wb = ctx.saved_tensors
         T, B, I = x.shape
         H = w_hh.shape[1]
         dhs = _c(dhs)
@@ -508,9 +533,16 @@ class LstmBatchFn(torch.autograd.Function):
             if t > 0:                                                               # dG_t W_hh  (B,H)
                 dh = ops.gemm_bf16(ops.cast_bf16(dG[t]), whh, tb=True) if ctx.bf16 else ops.gemm(dG[t], whh, tb=True)
         dG2 = dG.view(T * B, 4 * H)
-        dx = ops.gemm(dG2, _c(w_ih), tb=True).view(T, B, I) if ctx.needs_input_grad[0] else None
-        dw_ih = ops.gemm(dG2, x.view(T * B, I), ta=True, tb=True)
-        if T > 1:
+        if ctx.bf16_proj:
+            dGb = ops.cast_bf16(dG2)
+            dx, dw_ih = _lstm_in_proj_bwd(dGb, xb, wb, I, ctx.needs_input_grad[0])
+            dx = dx.view(T, B, I) if dx is not None else None
+        else:
+            dx = ops.gemm(dG2, _c(w_ih), tb=True).view(T, B, I) if ctx.needs_input_grad[0] else None
+            dw_ih = ops.gemm(dG2, x.view(T * B, I), ta=True, tb=True)
+        if T > 1 and ctx.bf16_proj and B % 8 == 0:
+            dw_hh = ops.gemm_bf16(dGb[B:], ops.cast_bf16(hs[:-1].reshape((T - 1) * B, H)), ta=True, tb=True)
+        elif T > 1:
             dw_hh = ops.gemm(dG[1:].reshape((T - 1) * B, 4 * H), hs[:-1].reshape((T - 1) * B, H), ta=True, tb=True)
         else:
             dw_hh = torch.zeros_like(w_hh)

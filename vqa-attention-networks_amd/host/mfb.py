@@ -47,6 +47,12 @@ def warn_once(key, msg):
         warnings.warn("vqa fusion path: " + msg, RuntimeWarning, stacklevel=3)
 
 
+def _lstm_bf16(gemm_dtype):
+    """LSTM precision flag of the functions.Lstm*Fn: False (fp32), True ("bf16": bf16 operands in the recurrent
+    products) or "all" ("bf16-all": also in the input projection and the weight gradients)."""
+    return "all" if gemm_dtype == "bf16-all" else gemm_dtype == "bf16"
+
+
 def batch_first_lstm(lstm, x, use_hip=True, bf16=False):
     """nn.LSTM(batch_first=True) forward of x (N,T,E) -> (N,T,H) with zero initial state (mfb.py:69).  The
     recursion runs on the HIP path (MFMA GEMMs + one point-wise kernel per step, functions.LstmBatchFn) with
@@ -205,7 +211,7 @@ class MFB(nn.Module):
                                   self.overlap_streams == "same-stream") if side else None
         # a2: question encoder                                               mfb.py:68-70
         que_embedded = torch.tanh(self.word_embedding(questions))
-        lstm_o = batch_first_lstm(self.lstm, que_embedded, self.use_hip_lstm, self.gemm_dtype in ("bf16", "bf16-all"))
+        lstm_o = batch_first_lstm(self.lstm, que_embedded, self.use_hip_lstm, _lstm_bf16(self.gemm_dtype))
         ques_feature = self.dropout_l(lstm_o).contiguous()                 # (N,T,H)
         N, T, H = ques_feature.shape
         L = img_features.shape[1]

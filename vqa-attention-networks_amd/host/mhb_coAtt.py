@@ -9,7 +9,7 @@ import torch.nn as nn
 
 from . import ops
 from .functions import LinearFn, AttHeadFn, ImgFuseFn, MfbFuseFn, FinalMfbFn, LstmSeqFn, LstmBatchFn, LogSoftmaxRowsFn
-from .mfb import _DropSeeds, _image_is_data, _SideStream, batch_first_lstm, warn_once
+from .mfb import _DropSeeds, _image_is_data, _SideStream, _lstm_bf16, batch_first_lstm, warn_once
 
 
 class MHBCoAtt(nn.Module):
@@ -62,7 +62,7 @@ class MHBCoAtt(nn.Module):
             assert glove_matrix is not None, 'glove should not be NoneType.'
             que_embedded = torch.cat((que_embedded, glove_matrix), dim=2)
         if self.fix_lstm_orientation:
-            lstm_o = batch_first_lstm(self.lstm, que_embedded, self.use_hip_lstm, self.gemm_dtype in ("bf16", "bf16-all"))   # (N,T,H)
+            lstm_o = batch_first_lstm(self.lstm, que_embedded, self.use_hip_lstm, _lstm_bf16(self.gemm_dtype))   # (N,T,H)
             ques_feature = self.dropout_l(lstm_o).contiguous()
         elif (self.use_hip_lstm and self.lstm.num_layers == 1 and que_embedded.is_cuda
               and ops.lstm_seq_supported(que_embedded.shape[1], self.cfg.hidden_dim)):
@@ -71,7 +71,7 @@ class MHBCoAtt(nn.Module):
             # reference's lstm_o.permute(1,0,2).
             hs = LstmSeqFn.apply(que_embedded, self.lstm.weight_ih_l0, self.lstm.weight_hh_l0,
                                  self.lstm.bias_ih_l0, self.lstm.bias_hh_l0,
-                                 self.gemm_dtype in ("bf16", "bf16-all"))     # bf16 modes: bf16 operands in the recurrent product
+                                 _lstm_bf16(self.gemm_dtype))     # bf16 modes: bf16 operands in the recurrent product
             ques_feature = self.dropout_l(hs).contiguous()
         else:
             if self.use_hip_lstm:
