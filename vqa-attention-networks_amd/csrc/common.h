@@ -100,6 +100,19 @@ static inline int vqf_set_dyn_lds(const void* fn, int bytes, VqfDynLdsFlags& f) 
   return VQF_OK;
 }
 
+// compute units of the current device (cached per device; 0 when the query fails)
+static inline int vqf_cu_count() {
+  static int cached[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const bool tracked = dev >= 0 && dev < 64;
+  if (tracked && cached[dev] > 0) return cached[dev];
+  int n = 0;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+  if (tracked) cached[dev] = n;
+  return n;
+}
+
 // ---- device helpers -------------------------------------------------------
 __device__ __forceinline__ bool aligned16_dev(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 __device__ __forceinline__ float wave_sum(float v) {

@@ -64,6 +64,9 @@ struct BigArgs {
   int M, N, K, lda, ldb, ldc, flags;
   int tiles_m, tiles_n, kchunk, splits;
   int group_m;           // row tiles per group of the tile order (pick_group_m)
+#ifdef VQF_F32BIG_CLOCK
+  unsigned long long* dbg;   // diagnostic build only (tools/f32_clock.py): per workgroup and wave half, s_memtime / s_memrealtime stamps
+#endif
 };
 
 // per-lane global source pointers of the NG copies of one operand slab.
@@ -211,27 +214,52 @@ __global__ void __launch_bounds__(NT, 2) gemm_f32_big_kernel(const BigArgs g) {
   const int wr = wave >> 1, wc = wave & 1;             // strip rows wr*64 .. +63, strip columns wc*128 .. +127
   const int late = wave >> 2;                          // waves 4-7: the half that runs behind in the staggered / ping-pong loops
 
-  // ---- tile order: split index slowest; bijective XCD remap, then groups of GROUP_M row tiles, m fastest
+  // ---- PERSISTENT workgroups (one per CU: a tile needs the CU's whole LDS): workgroup b runs work items b, b + gridDim.x,
+  // ... of the order below -- the items the hardware dispatcher would have handed the same XCD (gridDim.x % 8 == 0, or a
+  // single round).  The slab ring runs on across tiles: once a tile's K loop has ended every wave's LDS reads have
+  // returned (they precede the loop's last barrier in every loop form), so each wave issues the NEXT tile's first
+  // NSLOT-1 slabs right behind its own output stores, and the next K loop starts on landed data instead of paying a
+  // workgroup turn-around (7.8 us per 467-us tile of the image projection: tools/f32_clock.py) plus a cold prologue.
+  // ---- work-item order: split index slowest; bijective XCD remap, then groups of GROUP_M row tiles, m fastest
   const int ntiles = g.tiles_m * g.tiles_n;
-  const int z = blockIdx.x / ntiles;
-  int id = blockIdx.x % ntiles;
-  {
-    const int q8 = ntiles / 8, r8 = ntiles % 8, xcd = id % 8, k = id / 8;
-    id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
-  }
-  const int per_group = g.group_m * g.tiles_n;
-  const int grp = id / per_group, in = id % per_group;
-  const int gm0 = grp * g.group_m;
-  const int gsz = min(g.group_m, g.tiles_m - gm0);
-  const int tm = gm0 + in % gsz, tn = in / gsz;
-  const int m0 = tm * TM, n0 = tn * TN;
-  const int kbeg = z * g.kchunk;
-  const int S = (min(g.K, kbeg + g.kchunk) - kbeg) / TK;       // slabs of this split (uniform over the workgroup)
-
+  const int total = ntiles * g.splits;
+  int w = blockIdx.x;
+  int z, m0, n0, kbeg, S;                              // current work item (uniform over the workgroup)
   gfloat* qa[NG];
   gfloat* qb[NG];
-  init_src<TA, false>(qa, g.A, g.lda, m0, g.M, kbeg, wave, lane);
-  init_src<TB, true>(qb, g.B, g.ldb, n0, g.N, kbeg, wave, lane);
+  int slot = 0;                                        // ring slot of the current tile's slab 0, then of slab s
+  auto begin_tile = [&]() {                            // locate work item w, issue its first NSLOT-1 slabs
+    z = w / ntiles;
+    int id = w % ntiles;
+    {
+      const int q8 = ntiles / 8, r8 = ntiles % 8, xcd = id % 8, k = id / 8;
+      id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
+    }
+    const int per_group = g.group_m * g.tiles_n;
+    const int grp = id / per_group, in = id % per_group;
+    const int gm0 = grp * g.group_m;
+    const int gsz = min(g.group_m, g.tiles_m - gm0);
+    const int tm = gm0 + in % gsz, tn = in / gsz;
+    m0 = tm * TM; n0 = tn * TN;
+    kbeg = z * g.kchunk;
+    S = (min(g.K, kbeg + g.kchunk) - kbeg) / TK;       // slabs of this split
+    init_src<TA, false>(qa, g.A, g.lda, m0, g.M, kbeg, wave, lane);
+    init_src<TB, true>(qb, g.B, g.ldb, n0, g.N, kbeg, wave, lane);
+    int sl = slot;
+#pragma unroll
+    for (int p = 0; p < NSLOT - 1; ++p) {
+      if (p < S) {
+        stage_operand<TA>(qa, g.lda, smem + sl * SLOT_BYTES, wave);
+        stage_operand<TB>(qb, g.ldb, smem + sl * SLOT_BYTES + OP_BYTES, wave);
+      }
+      sl = (sl + 1 == NSLOT) ? 0 : sl + 1;
+    }
+  };
+  begin_tile();
+  for (;;) {
+#ifdef VQF_F32BIG_CLOCK
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
   f32x16 acc[2][4];
 #pragma unroll
@@ -241,13 +269,9 @@ __global__ void __launch_bounds__(NT, 2) gemm_f32_big_kernel(const BigArgs g) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-#pragma unroll
-  for (int p = 0; p < NSLOT - 1; ++p)
-    if (p < S) {
-      stage_operand<TA>(qa, g.lda, smem + p * SLOT_BYTES, wave);
-      stage_operand<TB>(qb, g.ldb, smem + p * SLOT_BYTES + OP_BYTES, wave);
-    }
-  int slot = 0;                                        // slot of slab s
+#ifdef VQF_F32BIG_CLOCK
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+#endif
   if (MODE == 0 || (MODE == 2 && late == 0)) {
     for (int s = 0; s < S; ++s) {
       wait_copies(min(NSLOT - 2, S - 1 - s));          // my copies of slab s; later slabs stay in flight
@@ -365,6 +389,9 @@ __global__ void __launch_bounds__(NT, 2) gemm_f32_big_kernel(const BigArgs g) {
     if (!late) __builtin_amdgcn_s_barrier();           // waves 0-3 absorb the barrier waves 4-7 spent on the stagger
   }
 
+#ifdef VQF_F32BIG_CLOCK
+  const unsigned long long c2 = __builtin_amdgcn_s_memtime(), r2 = __builtin_amdgcn_s_memrealtime();
+#endif
   const bool split = g.splits > 1;
   const bool relu = !split && (g.flags & VQF_GEMM_RELU) != 0;
   float* C = split ? g.C + (size_t)z * g.M * g.N : g.C;
@@ -377,6 +404,19 @@ __global__ void __launch_bounds__(NT, 2) gemm_f32_big_kernel(const BigArgs g) {
     else                store_tile<TA, true, true>(g, C, acc, row0, col0, lane, relu, use_bias);
   } else {
     store_tile<TA, true, false>(g, C, acc, row0, col0, lane, relu, use_bias);
+  }
+#ifdef VQF_F32BIG_CLOCK
+  if (g.dbg && lane == 0 && (wave & 3) == 0) {         // one record per wave half: [entry, loop start, loop end, stores issued] cycles,
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // [entry, loop end] 100 MHz ticks, slabs; stores landed at the last stamp
+    const unsigned long long c3 = __builtin_amdgcn_s_memtime();
+    unsigned long long* d = g.dbg + ((size_t)w * 2 + late) * 8;
+    d[0] = c1 - c0; d[1] = c2 - c1; d[2] = c3 - c2; d[3] = r2 - r0; d[4] = c2 - c0; d[5] = (unsigned long long)S;
+    d[6] = r0; d[7] = c0;
+  }
+#endif
+  w += gridDim.x;
+  if (w >= total) break;
+  begin_tile();
   }
 }
 
@@ -422,7 +462,16 @@ int launch(const BigArgs& g, hipStream_t s) {
   const char* ppe = getenv("VQF_GEMM_F32_PP");         // A/B switch, read per launch: 0 lockstep, 1 ping-pong, 2 staggered lockstep
   const int mode = (ppe && ppe[0] >= '0' && ppe[0] <= '2') ? ppe[0] - '0' : VQF_F32BIG_DEFAULT_MODE;
   const int kid = KID_GEMM_A0B0 + 2 * (TA ? 1 : 0) + (TB ? 1 : 0);
-  const dim3 grid(g.tiles_m * g.tiles_n * g.splits);
+  // persistent workgroups: one per CU, each walking its share of the work items (VQF_GEMM_F32_PERSIST=0: one workgroup
+  // per item, as in round 1; read per launch for A/Bs)
+  const int total = g.tiles_m * g.tiles_n * g.splits;
+  const char* pe = getenv("VQF_GEMM_F32_PERSIST");
+  int nwg = total;
+  if (!(pe && pe[0] == '0')) {
+    const int cus = vqf_cu_count() & ~7;               // a multiple of 8 keeps every workgroup's items on its own XCD
+    if (cus >= 8 && total > cus) nwg = cus;
+  }
+  const dim3 grid(nwg);
   if (mode == 1) {
     if (int e = vqf_set_dyn_lds(reinterpret_cast<const void*>(&gemm_f32_big_kernel<TA, TB, 1>), SMEM_BIG, attr_pp)) return e;
     VQF_LAUNCH(kid, (gemm_f32_big_kernel<TA, TB, 1>), grid, dim3(NT), SMEM_BIG, s, g);
@@ -490,6 +539,9 @@ int vqf_gemm_f32_big_try(int ta, int tb, int M, int N, int K, const float* A, in
   g.splits = splits;
   if (splits > 1) { g.C = (float*)ws; g.ldc = N; }
   g.group_m = pick_group_m(g.tiles_m, g.tiles_n, splits);
+#ifdef VQF_F32BIG_CLOCK
+  g.dbg = (splits == 1 && ws && ws_bytes >= (size_t)tiles * 2 * 8 * 8) ? (unsigned long long*)ws : nullptr;
+#endif
   vqf_prof_dims(M, N, K);
   if (ta) *rc = tb ? launch<true, true>(g, s) : launch<true, false>(g, s);
   else    *rc = tb ? launch<false, true>(g, s) : launch<false, false>(g, s);
