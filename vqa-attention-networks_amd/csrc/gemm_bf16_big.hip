@@ -144,10 +144,10 @@ __device__ __forceinline__ bf16x8 read_frag(const char* s, int row0, int ks, int
 // ---- tile order: split index slowest; bijective XCD remap (blocks b and b + 8 share an XCD's L2: each XCD walks a
 // contiguous run of the linear order), then groups of GROUP_M row tiles x all column tiles, row tile fastest
 struct TileCoord { int z, m0, n0, kbeg; };
-__device__ __forceinline__ TileCoord tile_coord(const BigArgs& g) {
+__device__ __forceinline__ TileCoord tile_coord(const BigArgs& g, int w) {    // w: work item (tile x split)
   const int ntiles = g.tiles_m * g.tiles_n;
-  const int z = blockIdx.x / ntiles;
-  int id = blockIdx.x % ntiles;
+  const int z = w / ntiles;
+  int id = w % ntiles;
   {
     const int q8 = ntiles / 8, r8 = ntiles % 8, xcd = id % 8, k = id / 8;
     id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(NT, 2) gemm_bf16_big_kernel(const BigArgs g) {
   const int wr = wave >> 2, wc = wave & 3;             // rows wr*128 .. +127, columns wc*64 .. +63
 
   // ---- tile order: split index slowest; bijective XCD remap, then groups of GROUP_M row tiles, m fastest
-  const TileCoord tc = tile_coord(g);
+  const TileCoord tc = tile_coord(g, blockIdx.x);
   const int z = tc.z, m0 = tc.m0, n0 = tc.n0, kbeg = tc.kbeg;
   const int S = (min(g.K, kbeg + g.kchunk) - kbeg) / TK;       // slabs of this split
 
@@ -301,15 +301,34 @@ __global__ void __launch_bounds__(NT, 2) gemm_bf16_pp_kernel(const BigArgs g) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;             // rows wr*128 .. +127, columns wc*64 .. +63
 
-  const TileCoord tc = tile_coord(g);
-  const int z = tc.z, m0 = tc.m0, n0 = tc.n0, kbeg = tc.kbeg;
-  const int S = (min(g.K, kbeg + g.kchunk) - kbeg) / TK;       // slabs of this split (uniform over the workgroup)
-
+  // PERSISTENT workgroups (gemm_f32_big.hip has the argument): workgroup b runs work items b, b + gridDim.x, ...; the
+  // slab ring runs on across tiles, each wave issues the next tile's first NSLOT-1 slabs behind its own output stores
+  // (every LDS read of a tile is retired before the barrier its last L segment ends with, and both wave halves have
+  // passed that barrier when either leaves the loop).  The barrier pattern below is balanced per tile.
+  const int total = g.tiles_m * g.tiles_n * g.splits;
+  int w = blockIdx.x;
+  int z, m0, n0, kbeg, S;                              // current work item (uniform over the workgroup)
   gbf16* qa[NG];
   gbf16* qb[NG];
-  init_src<TA>(qa, g.A, g.lda, m0, g.M, kbeg, wave, lane);
-  init_src<TB>(qb, g.B, g.ldb, n0, g.N, kbeg, wave, lane);
-
+  int slot = 0;                                        // ring slot of the tile's slab 0, then of slab s
+  auto begin_tile = [&]() {
+    const TileCoord tc = tile_coord(g, w);
+    z = tc.z; m0 = tc.m0; n0 = tc.n0; kbeg = tc.kbeg;
+    S = (min(g.K, kbeg + g.kchunk) - kbeg) / TK;       // slabs of this split
+    init_src<TA>(qa, g.A, g.lda, m0, g.M, kbeg, wave, lane);
+    init_src<TB>(qb, g.B, g.ldb, n0, g.N, kbeg, wave, lane);
+    int sl = slot;
+#pragma unroll
+    for (int p = 0; p < NSLOT - 1; ++p) {
+      if (p < S) {
+        stage_operand<TA>(qa, g.lda, smem + sl * SLOT_BYTES, wave);
+        stage_operand<TB>(qb, g.ldb, smem + sl * SLOT_BYTES + OP_BYTES, wave);
+      }
+      sl = (sl + 1 == NSLOT) ? 0 : sl + 1;
+    }
+  };
+  begin_tile();
+  for (;;) {
   f32x16 acc[4][2];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -318,12 +337,6 @@ __global__ void __launch_bounds__(NT, 2) gemm_bf16_pp_kernel(const BigArgs g) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-#pragma unroll
-  for (int p = 0; p < NSLOT - 1; ++p)
-    if (p < S) {
-      stage_operand<TA>(qa, g.lda, smem + p * SLOT_BYTES, wave);
-      stage_operand<TB>(qb, g.ldb, smem + p * SLOT_BYTES + OP_BYTES, wave);
-    }
   {                                                    // my copies of slab 0 (4 per slab and thread)
     const int later = min(NSLOT - 1, S) - 1;
     wait_copies(later);
@@ -331,7 +344,6 @@ __global__ void __launch_bounds__(NT, 2) gemm_bf16_pp_kernel(const BigArgs g) {
   __builtin_amdgcn_s_barrier();                        // #0: every wave's copies of slab 0 have landed
   if (wr) __builtin_amdgcn_s_barrier();                // waves 4-7 fall half a slab behind (wave-uniform branch)
 
-  int slot = 0;                                        // slot of slab s
 #ifdef VQF_PP_STAMPS
   unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0, t7 = 0, acc_t[7] = {0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -404,7 +416,7 @@ __global__ void __launch_bounds__(NT, 2) gemm_bf16_pp_kernel(const BigArgs g) {
   if (!wr) __builtin_amdgcn_s_barrier();               // waves 0-3 absorb the barrier waves 4-7 spent on the stagger
 #ifdef VQF_PP_STAMPS
   if (g.dbg && lane == 0) {
-    unsigned long long* d = g.dbg + ((size_t)blockIdx.x * 8 + wave) * 8;
+    unsigned long long* d = g.dbg + ((size_t)w * 8 + wave) * 8;
 #pragma unroll
     for (int i = 0; i < 7; ++i) d[i] = acc_t[i];
     d[7] = (unsigned long long)S;
@@ -431,6 +443,10 @@ __global__ void __launch_bounds__(NT, 2) gemm_bf16_pp_kernel(const BigArgs g) {
   } else {
     if (m0 + TM <= g.M) store_tile<false>(g, C, acc, bv, row_base, n0 + wc * 64 + r, relu);
     else                store_tile<true>(g, C, acc, bv, row_base, n0 + wc * 64 + r, relu);
+  }
+  w += gridDim.x;
+  if (w >= total) break;
+  begin_tile();
   }
 }
 
@@ -512,27 +528,37 @@ __global__ void __launch_bounds__(NT, 2) gemm_bf16_pp16_kernel(const BigArgs g) 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;             // rows wr*128 .. +127, column strip wc*64 .. +63
 
-  const TileCoord tc = tile_coord(g);
-  const int z = tc.z, m0 = tc.m0, n0 = tc.n0, kbeg = tc.kbeg;
-  const int S = (min(g.K, kbeg + g.kchunk) - kbeg) / TK;       // slabs of this split (uniform over the workgroup)
-
+  // persistent workgroups, the slab ring running on across tiles (see gemm_bf16_pp_kernel)
+  const int total = g.tiles_m * g.tiles_n * g.splits;
+  int w = blockIdx.x;
+  int z, m0, n0, kbeg, S;                              // current work item (uniform over the workgroup)
   gbf16* qa[NG];
   gbf16* qb[NG];
-  init_src16<false>(qa, g.A, g.lda, m0, g.M, kbeg, wave, lane);
-  init_src16<true>(qb, g.B, g.ldb, n0, g.N, kbeg, wave, lane);
-
+  int slot = 0;                                        // ring slot of the tile's slab 0, then of slab s
+  auto begin_tile = [&]() {
+    const TileCoord tc = tile_coord(g, w);
+    z = tc.z; m0 = tc.m0; n0 = tc.n0; kbeg = tc.kbeg;
+    S = (min(g.K, kbeg + g.kchunk) - kbeg) / TK;       // slabs of this split
+    init_src16<false>(qa, g.A, g.lda, m0, g.M, kbeg, wave, lane);
+    init_src16<true>(qb, g.B, g.ldb, n0, g.N, kbeg, wave, lane);
+    int sl = slot;
+#pragma unroll
+    for (int p = 0; p < NSLOT - 1; ++p) {
+      if (p < S) {
+        stage_operand<false>(qa, g.lda, smem + sl * SLOT_BYTES, wave);
+        stage_operand<false>(qb, g.ldb, smem + sl * SLOT_BYTES + OP_BYTES, wave);
+      }
+      sl = (sl + 1 == NSLOT) ? 0 : sl + 1;
+    }
+  };
+  begin_tile();
+  for (;;) {
   f32x4 acc[8][4];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-#pragma unroll
-  for (int p = 0; p < NSLOT - 1; ++p)
-    if (p < S) {
-      stage_operand<false>(qa, g.lda, smem + p * SLOT_BYTES, wave);
-      stage_operand<false>(qb, g.ldb, smem + p * SLOT_BYTES + OP_BYTES, wave);
-    }
   {                                                    // my copies of slab 0 (4 per slab and thread)
     const int later = min(NSLOT - 1, S) - 1;
     wait_copies(later);
@@ -540,7 +566,6 @@ __global__ void __launch_bounds__(NT, 2) gemm_bf16_pp16_kernel(const BigArgs g) 
   __builtin_amdgcn_s_barrier();                        // #0: every wave's copies of slab 0 have landed
   if (wr) __builtin_amdgcn_s_barrier();                // waves 4-7 fall half a slab behind (wave-uniform branch)
 
-  int slot = 0;                                        // slot of slab s
   for (int s = 0; s < S; ++s) {
     // ---------------- L(s) ----------------
     __builtin_amdgcn_sched_barrier(0);
@@ -606,6 +631,10 @@ __global__ void __launch_bounds__(NT, 2) gemm_bf16_pp16_kernel(const BigArgs g) 
                else      store_tile16<true, true>(g, C, acc, row0, col0, lane, relu, use_bias); }
     else     { store_tile16<true, false>(g, C, acc, row0, col0, lane, relu, use_bias); }
   }
+  w += gridDim.x;
+  if (w >= total) break;
+  begin_tile();
+  }
 }
 
 int pick_splits(int tiles, int K, int M, int N, size_t ws_bytes) {
@@ -645,16 +674,23 @@ int launch(const BigArgs& g, hipStream_t s) {
   static VqfDynLdsFlags attr = {}, attr_pp = {};
   const char* ppe = getenv("VQF_GEMM_BF16_PP");        // A/B switch, read per launch (tools/gemm_bf16_ab.py flips it
   const bool pingpong = !(ppe && ppe[0] == '0');       // in one process): 0 selects the lockstep kernel of round 1
+  // the ping-pong kernels run as persistent workgroups, one per CU (VQF_GEMM_BF16_PERSIST=0: one workgroup per item)
+  const int total = g.tiles_m * g.tiles_n * g.splits;
+  const char* pe = getenv("VQF_GEMM_BF16_PERSIST");
+  int nwg = total;
+  if (!(pe && pe[0] == '0')) {
+    const int cus = vqf_cu_count() & ~7;               // a multiple of 8 keeps every workgroup's items on its own XCD
+    if (cus >= 8 && total > cus) nwg = cus;
+  }
   if (pingpong && !TA && !TB && !(ppe && ppe[0] == '3')) {   // VQF_GEMM_BF16_PP=3: the 32x32x16 ping-pong loop also for (0,0)
     static VqfDynLdsFlags attr16 = {};
     if (int e = vqf_set_dyn_lds(reinterpret_cast<const void*>(&gemm_bf16_pp16_kernel), SMEM_BIG, attr16)) return e;
-    VQF_LAUNCH(KID_GEMM_BF16, gemm_bf16_pp16_kernel, dim3(g.tiles_m * g.tiles_n * g.splits), dim3(NT), SMEM_BIG, s, g);
+    VQF_LAUNCH(KID_GEMM_BF16, gemm_bf16_pp16_kernel, dim3(nwg), dim3(NT), SMEM_BIG, s, g);
     return vqf_last_error();
   }
   if (pingpong) {
     if (int e = vqf_set_dyn_lds(reinterpret_cast<const void*>(&gemm_bf16_pp_kernel<TA, TB>), SMEM_BIG, attr_pp)) return e;
-    VQF_LAUNCH(KID_GEMM_BF16, (gemm_bf16_pp_kernel<TA, TB>), dim3(g.tiles_m * g.tiles_n * g.splits), dim3(NT), SMEM_BIG,
-               s, g);
+    VQF_LAUNCH(KID_GEMM_BF16, (gemm_bf16_pp_kernel<TA, TB>), dim3(nwg), dim3(NT), SMEM_BIG, s, g);
     return vqf_last_error();
   }
   if (int e = vqf_set_dyn_lds(reinterpret_cast<const void*>(&gemm_bf16_big_kernel<TA, TB>), SMEM_BIG, attr)) return e;
