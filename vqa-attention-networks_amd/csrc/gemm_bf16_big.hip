@@ -264,7 +264,7 @@ __global__ void __launch_bounds__(NT, 2) gemm_bf16_big_kernel(const BigArgs g) {
     const int col = n0 + wc * 64 + j * 32 + r;
     bv[j] = (!split && g.bias && col < g.N) ? g.bias[col] : 0.f;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the biases, once: no wait may sit between the stores
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // the biases, once: no wait may sit between the stores
   const int row_base = m0 + wr * 128 + 4 * h;
   if (g.flags & VQF_GEMM_OUT_BF16) {                 // bf16 storage of the result (round-to-nearest-even), never with split-K
     __bf16* Cb = reinterpret_cast<__bf16*>(g.C);
@@ -434,7 +434,7 @@ __global__ void __launch_bounds__(NT, 2) gemm_bf16_pp_kernel(const BigArgs g) {
     const int col = n0 + wc * 64 + j * 32 + r;
     bv[j] = (!split && g.bias && col < g.N) ? g.bias[col] : 0.f;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0x0F70);
   const int row_base = m0 + wr * 128 + 4 * h;
   if (g.flags & VQF_GEMM_OUT_BF16) {
     __bf16* Cb = reinterpret_cast<__bf16*>(g.C);
@@ -479,7 +479,19 @@ __device__ __forceinline__ void init_src16(gbf16* (&q)[NG], const bf16_t* base, 
 
 __device__ __forceinline__ bf16x8 read_frag16(const char* s, int row0, int lane) {
   const int row = row0 + (lane & 15);
-  return *reinterpret_cast<const bf16x8*>(s + row * 64 + (((lane >> 4) ^ swz16(row)) << 4));
+  const char* p = s + row * 64 + (((lane >> 4) ^ swz16(row)) << 4);
+#ifdef VQF_ASM_LDS_READ
+  // hipcc cannot tell a fragment read from a slot that an LDS-DMA copy in flight is filling and puts s_waitcnt vmcnt(0)
+  // in front of the first read of every slab -- the copies of the NEXT three slabs included.  An opaque read keeps them
+  // in flight; the caller's own lgkmcnt(0) (in front of the barrier that ends the L segment) covers its completion.
+  typedef __attribute__((address_space(3))) const char lds_cchar;
+  const unsigned a = (unsigned)(uintptr_t)(lds_cchar*)p;
+  bf16x8 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(a) : "memory");
+  return v;
+#else
+  return *reinterpret_cast<const bf16x8*>(p);
+#endif
 }
 
 template <bool GUARD_M, bool VEC, typename OT>
@@ -490,7 +502,7 @@ __device__ __forceinline__ void store_tile16(const BigArgs& g, OT* C, const f32x
   float bv[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) bv[j] = (use_bias && col + j < g.N) ? g.bias[col + j] : 0.f;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the biases, once: no wait may sit between the stores
+  __builtin_amdgcn_s_waitcnt(0x0F70);               // the biases, once: no wait may sit between the stores
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
 #pragma unroll

@@ -160,7 +160,9 @@ __device__ __forceinline__ void store_tile(const BigArgs& g, float* C, const f32
   float bv[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) bv[j] = (use_bias && col + j < g.N) ? g.bias[col + j] : 0.f;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the biases, once: no wait may sit between the stores
+  // vmcnt(0) for the biases, once (no wait may sit between the stores) -- as a BUILTIN: hipcc does not see through an asm
+  // wait, would carry "bias loads pending" around the persistent tile loop and re-wait with vmcnt(0) at every slab
+  __builtin_amdgcn_s_waitcnt(0x0F70);
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
