@@ -27,6 +27,22 @@ def main(path):
         wg = r.get("Workgroup_Size_X", "?")
         key = (short(r["Kernel_Name"]), grid, wg, r.get("VGPR_Count", "?"), r.get("LDS_Block_Size", "?"))
         groups[key].append(dur)
+    # persistent kernels launch one workgroup per CU whatever the shape, so one (kernel, grid) may hold several shapes:
+    # split a group where consecutive sorted durations jump by more than 3x
+    split = {}
+    for key, v in groups.items():
+        v = sorted(v)
+        parts, cur = [], [v[0]]
+        for d in v[1:]:
+            if d > 3 * cur[-1]:
+                parts.append(cur)
+                cur = []
+            cur.append(d)
+        parts.append(cur)
+        for i, part in enumerate(parts):
+            k = key if len(parts) == 1 else (key[0] + " [duration cluster %d of %d]" % (i + 1, len(parts)),) + key[1:]
+            split[k] = part
+    groups = split
     total = sum(sum(v) for v in groups.values())
     print("| kernel | grid (threads) | wg | VGPR | LDS B | calls | avg ms | min ms | max ms | total ms | % |")
     print("|---|---|---|---|---|---|---|---|---|---|---|")

@@ -480,18 +480,7 @@ __device__ __forceinline__ void init_src16(gbf16* (&q)[NG], const bf16_t* base, 
 __device__ __forceinline__ bf16x8 read_frag16(const char* s, int row0, int lane) {
   const int row = row0 + (lane & 15);
   const char* p = s + row * 64 + (((lane >> 4) ^ swz16(row)) << 4);
-#ifdef VQF_ASM_LDS_READ
-  // hipcc cannot tell a fragment read from a slot that an LDS-DMA copy in flight is filling and puts s_waitcnt vmcnt(0)
-  // in front of the first read of every slab -- the copies of the NEXT three slabs included.  An opaque read keeps them
-  // in flight; the caller's own lgkmcnt(0) (in front of the barrier that ends the L segment) covers its completion.
-  typedef __attribute__((address_space(3))) const char lds_cchar;
-  const unsigned a = (unsigned)(uintptr_t)(lds_cchar*)p;
-  bf16x8 v;
-  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(a) : "memory");
-  return v;
-#else
   return *reinterpret_cast<const bf16x8*>(p);
-#endif
 }
 
 template <bool GUARD_M, bool VEC, typename OT>
