@@ -365,6 +365,8 @@ def main():
                        "ranks_seen": dist.get_world_size() if dist.is_initialized() else 1,
                        "backend": (dist.get_backend() if dist.is_initialized() else "none (single process)"),
                        "streams": stream_mode,
+                       "gemm_workgroups": ("one per tile (data-parallel default: CUs free up for the collective)"
+                                           if os.environ.get("VQF_GEMM_F32_PERSIST") == "0" else "persistent, one per CU"),
                        "allreduce_bucket_bytes": reducer.bucket_bytes_list(),
                        "allreduce_exposed_ms": exposed},
             "loss": round(float(loss.item()), 5),

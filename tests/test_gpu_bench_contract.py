@@ -40,6 +40,7 @@ def test_bench_prints_one_contract_line():
     assert abs(d["value"] - 512 * 1000.0 / d["ms_per_step"]) / d["value"] < 1e-3
     cfg = d["config"]
     assert cfg["ranks_seen"] == 1 and cfg["allreduce_exposed_ms"] == [] and "one compute stream" in cfg["streams"]
+    assert cfg["gemm_workgroups"].startswith("persistent")
 
 
 def test_bench_refuses_a_rank_count_that_is_not_there():
@@ -69,6 +70,7 @@ def test_bench_two_ranks_on_one_gpu_gloo_rehearsal(tmp_path):
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 1024
     assert d["config"]["grad_allreduce_bytes"] == 240124080
     assert d["config"]["ranks_seen"] == 2 and d["config"]["backend"] == "gloo"
+    assert d["config"]["gemm_workgroups"].startswith("one per tile")      # host/parallel.py: the collective needs CUs
     assert sum(d["config"]["allreduce_bucket_bytes"]) == 240124080
     ex = d["config"]["allreduce_exposed_ms"]
     assert len(ex) == len(d["config"]["allreduce_bucket_bytes"]) and all(b >= a - 1e-3 for a, b in zip(ex, ex[1:]))

@@ -75,6 +75,12 @@ class GradientAllReducer:
         self.timing = False
         self._marks = []
         if self.world > 1:
+            # The large-tile GEMMs normally run as PERSISTENT workgroups (one per CU, holding all of its LDS for the whole
+            # launch: csrc/gemm_f32_big.hip).  The collective's kernels could then not get onto a CU before the 14-ms
+            # weight-gradient GEMM they are meant to overlap with has ended.  Data-parallel runs therefore launch one
+            # workgroup per tile (a CU frees up every ~0.5 ms; costs the GEMMs ~0.7 %) unless the user set the switches.
+            os.environ.setdefault("VQF_GEMM_F32_PERSIST", "0")
+            os.environ.setdefault("VQF_GEMM_BF16_PERSIST", "0")
             self._build_buckets(bucket_bytes)
             self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
 
