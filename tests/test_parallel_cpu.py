@@ -43,7 +43,11 @@ def _worker_body(rank, world, store, bucket_bytes, q):
         with torch.no_grad():
             for p in model.parameters():
                 p.add_(1.0)
+    os.environ.pop("VQF_GEMM_F32_PERSIST", None)
+    os.environ["VQF_GEMM_BF16_PERSIST"] = "1"            # a user's explicit choice survives (setdefault)
     red = par.GradientAllReducer(model, bucket_bytes=bucket_bytes)
+    # data parallel: GEMMs launch one workgroup per tile so that the collective's kernels get onto CUs (host/parallel.py)
+    assert os.environ["VQF_GEMM_F32_PERSIST"] == "0" and os.environ["VQF_GEMM_BF16_PERSIST"] == "1"
     g = torch.Generator().manual_seed(11)
     X = torch.randn(16, 12, generator=g)
     Y = torch.randint(0, 7, (16,), generator=g)
