@@ -50,10 +50,34 @@ extern "C" {
 #define VQF_GEMM_OUT_BF16 4    /* vqf_gemm_bf16 only: C points to bf16 storage (ldc in elements), result rounded
                                   to nearest even; VQF_E_UNSUPPORTED unless the 256x256-tile kernel applies */
 
-/* ABI version (2: LSTM entry points take a workspace and flags, large-tile GEMMs, solver tail, staging) and build
- * information ("libvqa_fusion gfx950 fp32-mfma(...) tiles ...") */
+/* ABI version (2: LSTM entry points take a workspace and flags, large-tile GEMMs, solver tail, staging; 4: library
+ * options, row-scaled GEMM) and build information ("libvqa_fusion gfx950 fp32-mfma(...) tiles ...") */
 int vqf_abi_version(void);
 const char* vqf_build_info(void);
+
+/* --------------------------------------------------------------------------
+ * Library options: process-wide launch policy, an int per option, read by the launchers as a plain load (no
+ * getenv on the launch path).  -1 = the library's default.  The initial value of each option is taken ONCE, when
+ * the library is loaded, from the environment variable of the same name (VQF_GEMM_F32_PERSIST=0 python bench.py
+ * still works for command-line A/Bs); after that only vqf_set_option changes it.
+ * vqf_set_option stores `value` (negative = back to the default) and, if `previous` != NULL, hands back the value
+ * it replaced so that a caller can restore it; both return VQF_OK or VQF_E_BADARG (unknown id / NULL out pointer).
+ */
+#define VQF_OPT_GEMM_F32_PERSIST 0   /* large-tile fp32 GEMM: 1 = persistent workgroups, one per CU (default); 0 = one per tile */
+#define VQF_OPT_GEMM_BF16_PERSIST 1  /* the same for the large-tile bf16 GEMM */
+#define VQF_OPT_GEMM_F32_LOOP 2      /* fp32 large-tile loop form: 0 lockstep, 1 ping-pong, 2 staggered halves (default) */
+#define VQF_OPT_GEMM_BF16_LOOP 3     /* bf16 large-tile loop form: 0 lockstep (r01), 1 ping-pong (default), 3 = 32x32x16 also for (0,0) */
+#define VQF_OPT_GEMM_F32_BIG 4       /* 0 = never use the 256x256-tile fp32 kernel */
+#define VQF_OPT_GEMM_BF16_BIG 5      /* 0 = never use the 256x256-tile bf16 kernel */
+#define VQF_OPT_GEMM_F32_WAVE 6      /* 0 = never use the small-M per-wave-tile kernel */
+#define VQF_OPT_FUSE_COAL 7          /* MFB fusion kernels: 0 / 1 force the LDS-transposed P / dP access off / on */
+#define VQF_OPT_FUSE_LS 8            /* MFB fusion forward: row splits per sample (>= 1), tuning probe */
+#define VQF_OPT_FUSE_LS_BWD 9        /* MFB fusion backward: row splits per sample (1..16), tuning probe */
+#define VQF_OPT_GEMM_CU_LIMIT 10     /* persistent large-tile GEMMs use at most this many CUs (multiple of 8; leaves the rest
+                                        of the chip to kernels of other streams); <= 0 or -1 = all */
+#define VQF_OPT_COUNT 11
+int vqf_set_option(int option, int value, int* previous);
+int vqf_get_option(int option, int* value);
 
 /* --------------------------------------------------------------------------
  * Dense projections on the fp32 MFMA pipe (v_mfma_f32_32x32x2_f32).

@@ -276,12 +276,8 @@ def test_gemm_small_m_wave_kernel(ops, tb, M, N, K, what):
     Ad, Bd = A.float().cuda(), B.float().cuda()
     out = ops.gemm(Ad, Bd, tb=bool(tb))
     assert _rel(out, ref) <= tol, (what, _rel(out, ref))
-    import os
-    os.environ["VQF_GEMM_F32_WAVE"] = "0"                      # the 128x128 split-K path on the same operands
-    try:
+    with ops.options(gemm_f32_wave=0):                         # the 128x128 split-K path on the same operands
         old = ops.gemm(Ad, Bd, tb=bool(tb))
-    finally:
-        del os.environ["VQF_GEMM_F32_WAVE"]
     assert _rel(old, ref) <= tol and not torch.equal(old, out), "the wave kernel did not take this shape"
     assert torch.equal(out, ops.gemm(Ad, Bd, tb=bool(tb)))      # fixed-order in-workgroup K reduction
     # bias + relu, and accumulate into a row-strided output view (LstmBatchFn adds into xw[t])

@@ -43,11 +43,16 @@ def _worker_body(rank, world, store, bucket_bytes, q):
         with torch.no_grad():
             for p in model.parameters():
                 p.add_(1.0)
-    os.environ.pop("VQF_GEMM_F32_PERSIST", None)
-    os.environ["VQF_GEMM_BF16_PERSIST"] = "1"            # a user's explicit choice survives (setdefault)
+    ops = import_module("vqa-attention-networks_amd.host.ops")
+    env_before = dict(os.environ)
+    ops.set_option("gemm_f32_persist", None)
+    ops.set_option("gemm_bf16_persist", 1)               # a user's explicit choice survives
     red = par.GradientAllReducer(model, bucket_bytes=bucket_bytes)
-    # data parallel: GEMMs launch one workgroup per tile so that the collective's kernels get onto CUs (host/parallel.py)
-    assert os.environ["VQF_GEMM_F32_PERSIST"] == "0" and os.environ["VQF_GEMM_BF16_PERSIST"] == "1"
+    # data parallel: GEMMs launch one workgroup per tile so that the collective's kernels get onto CUs (host/parallel.py);
+    # an explicit library option, no environment mutation
+    assert ops.get_option("gemm_f32_persist") == 0 and ops.get_option("gemm_bf16_persist") == 1
+    assert red.gemm_workgroups() == {"f32": "one per tile", "bf16": "persistent, one per CU"}
+    assert dict(os.environ) == env_before
     g = torch.Generator().manual_seed(11)
     X = torch.randn(16, 12, generator=g)
     Y = torch.randint(0, 7, (16,), generator=g)
@@ -61,6 +66,8 @@ def _worker_body(rank, world, store, bucket_bytes, q):
         outs.append([None if p.grad is None else p.grad.clone().numpy() for p in model.parameters()])
     # numpy, not torch tensors: a tensor travels through the queue as a shared-memory handle that can be
     # gone by the time the parent unpickles it if this process has already exited (seen as a flaky None)
+    red.close()                                          # restores what the reducer changed, leaves the user's choice alone
+    assert ops.get_option("gemm_f32_persist") == -1 and ops.get_option("gemm_bf16_persist") == 1
     q.put((rank, [p.detach().clone().numpy() for p in model.parameters()], outs, len(red.buckets)))
     dist.barrier()
     dist.destroy_process_group()

@@ -1,5 +1,5 @@
 """Timing of the MFB fusion kernels alone at the headline shape (N=512, L=196, O=1000): direct (strided) vs coalesced
-(LDS-transposed) P / dP access (VQF_FUSE_COAL), fp32 and bf16 projection storage, with and without Philox dropout."""
+(LDS-transposed) P / dP access (library option fuse_coal), fp32 and bf16 projection storage, with and without Philox dropout."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, vqa_amd
@@ -7,15 +7,15 @@ ops = vqa_amd.ops
 N, L, O = 512, 196, 1000
 P = torch.randn(N * L, 5 * O, device="cuda"); q = torch.randn(N, 5 * O, device="cuda"); pb = torch.randn(5 * O, device="cuda")
 Pb = P.to(torch.bfloat16)
+dY = torch.randn((N * L, O), device="cuda", generator=torch.Generator(device="cuda").manual_seed(7))   # ONE seeded dY for every variant
 res = {}
 for mode, Pm, kw in (("fp32 P", P, {}), ("bf16 P/dP", Pb, {"dp_bf16": True})):
     for pd in (0.1, 0.0):
         for coal in ("0", "1"):
-            os.environ["VQF_FUSE_COAL"] = coal
+            ops.set_option("fuse_coal", int(coal))
             ops.prof_reset(); ops.prof_enable(True)
             for _ in range(6):
                 Y, norm, inv, _ = ops.mfb_fuse_fwd(Pm, q, N, L, O, seed=123, p_drop=pd, pbias=pb)
-                dY = torch.randn_like(Y)
                 out = ops.mfb_fuse_bwd(dY, Y, norm, inv, Pm, q, N, L, O, seed=123, p_drop=pd, want_dbias=True, pbias=pb, **kw)
             torch.cuda.synchronize()
             rep = ops.prof_report()

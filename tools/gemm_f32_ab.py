@@ -1,5 +1,5 @@
 """Same-process A/B of the fp32 GEMM kernels on the hot shapes (random, LIVE operands), interleaved rounds:
-  small = 128x128 kernel (VQF_GEMM_F32_BIG=0), lock = 256x256 lockstep loop, pp = 256x256 ping-pong loop,
+  small = 128x128 kernel (library option gemm_f32_big=0), lock = 256x256 lockstep loop, pp = 256x256 ping-pong loop,
   stag = lockstep loop with waves 4-7 half a slab behind.          python tools/gemm_f32_ab.py [--rounds 5] [--shapes fwd,wgrad]"""
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,8 +10,13 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--shapes", default="fwd,wgrad,coatt_fwd,coatt_dgrad,sq")
 args = ap.parse_args()
-ENV = {"small": {"VQF_GEMM_F32_BIG": "0", "VQF_GEMM_F32_PP": "1"}, "lock": {"VQF_GEMM_F32_BIG": "1", "VQF_GEMM_F32_PP": "0"},
-       "pp": {"VQF_GEMM_F32_BIG": "1", "VQF_GEMM_F32_PP": "1"}, "stag": {"VQF_GEMM_F32_BIG": "1", "VQF_GEMM_F32_PP": "2"}}
+ENV = {"small": {"gemm_f32_big": 0, "gemm_f32_loop": 1}, "lock": {"gemm_f32_big": 1, "gemm_f32_loop": 0},
+       "pp": {"gemm_f32_big": 1, "gemm_f32_loop": 1}, "stag": {"gemm_f32_big": 1, "gemm_f32_loop": 2}}
+
+
+def _set(e):
+    for k, v in e.items():
+        ops.set_option(k, v)
 SH = {"fwd": (0, 0, 100352, 5000, 2048), "wgrad": (1, 1, 5000, 2048, 100352), "coatt_fwd": (0, 0, 100352, 1024, 1024),
       "coatt_dgrad": (0, 1, 100352, 1024, 1024), "sq": (0, 0, 8192, 8192, 8192), "sq_tn": (1, 0, 8192, 8192, 8192),
       "coatt_wgrad": (1, 1, 1024, 1000, 100352), "coatt1000": (0, 0, 100352, 1024, 1000)}
@@ -25,13 +30,13 @@ for name in args.shapes.split(","):
     out = torch.empty((M, N), device="cuda")
     res, times = {}, {v: [] for v in ENV}
     for v, e in ENV.items():
-        os.environ.update(e)
+        _set(e)
         ops.gemm(A, B, ta=bool(ta), tb=bool(tb), out=out)
         torch.cuda.synchronize()
         res[v] = out.clone()
     for r in range(args.rounds):
         for v, e in ENV.items():
-            os.environ.update(e)
+            _set(e)
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             for _ in range(2):

@@ -1,5 +1,5 @@
 """Small-M fp32 products (the LSTM's recurrent GEMMs and the M = 512 projections): gemm_f32_wave.hip on / off
-(VQF_GEMM_F32_WAVE), same process, interleaved rounds, incl. the split-K reduce launch of the old path."""
+(library option gemm_f32_wave), same process, interleaved rounds, incl. the split-K reduce launch of the old path."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, vqa_amd
@@ -14,12 +14,12 @@ for name, tb, M, N, K, acc in SH:
     out = torch.zeros((M, N), device="cuda")
     t = {"0": [], "1": []}
     for v in ("0", "1"):
-        os.environ["VQF_GEMM_F32_WAVE"] = v
+        ops.set_option("gemm_f32_wave", int(v))
         ops.gemm(A, B, tb=bool(tb), out=out, accumulate=acc)
     torch.cuda.synchronize()
     for r in range(7):
         for v in ("0", "1"):
-            os.environ["VQF_GEMM_F32_WAVE"] = v
+            ops.set_option("gemm_f32_wave", int(v))
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             for _ in range(20):

@@ -46,6 +46,10 @@ enum VqfKernelId {
 };
 
 extern int g_vqf_prof_on;
+// library options (include/vqa_fusion.h, VQF_OPT_*): -1 = default; set from the environment once at load, then only by
+// vqf_set_option.  The launchers read them as plain loads.
+extern int g_vqf_opt[VQF_OPT_COUNT];
+static inline int vqf_opt(int id, int dflt) { const int v = g_vqf_opt[id]; return v < 0 ? dflt : v; }
 void vqf_prof_begin(int id, hipStream_t s);
 void vqf_prof_end(int id, hipStream_t s);
 void vqf_prof_dims(int d0, int d1, int d2);   // shape tag attached to the next launches of this thread

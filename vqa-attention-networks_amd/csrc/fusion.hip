@@ -334,15 +334,13 @@ mfb_fuse_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ dzdr
 // 0.985 ms: the strided dP stores go away); the forward is unchanged (0.486 vs 0.483 ms without dropout) and the bf16
 // kernels lose occupancy to the extra registers (0.44 -> 0.51 ms).  VQF_FUSE_COAL=0 / 1 forces it off / on everywhere.
 bool fuse_coalesced(bool fp32_backward) {
-  const char* e = getenv("VQF_FUSE_COAL");
-  if (e && e[0] == '0') return false;
-  if (e && e[0] == '1') return true;
-  return fp32_backward;
+  const int v = g_vqf_opt[VQF_OPT_FUSE_COAL];
+  return v < 0 ? fp32_backward : v != 0;
 }
 
 int pick_ls_fwd(int N, int L) {
   // forward: 8 blocks per CU worth of (sample, row-subset) pairs, at least ~8 rows per block
-  if (const char* e = getenv("VQF_FUSE_LS")) { const int v = atoi(e); if (v >= 1 && v <= L) return v; }   // tuning probe
+  { const int v = g_vqf_opt[VQF_OPT_FUSE_LS]; if (v >= 1 && v <= L) return v; }   // tuning probe
   int ls = 1;
   while ((long long)N * ls < 4096 && ls * 16 <= L) ls *= 2;
   return ls;
@@ -350,7 +348,7 @@ int pick_ls_fwd(int N, int L) {
 
 int pick_ls(int N, int L) {
   // enough blocks to cover 256 CUs x 4, but never more splits than rows
-  if (const char* e = getenv("VQF_FUSE_LS_BWD")) { const int v = atoi(e); if (v >= 1 && v <= L && v <= 16) return v; }   // tuning probe
+  { const int v = g_vqf_opt[VQF_OPT_FUSE_LS_BWD]; if (v >= 1 && v <= L && v <= 16) return v; }   // tuning probe
   int ls = 1;
   while ((long long)N * ls < 2048 && ls * 2 <= L && ls < 16) ls *= 2;
   return ls;

@@ -673,17 +673,18 @@ template <bool TA, bool TB>
 int launch(const BigArgs& g, hipStream_t s) {
   // > 64 KB of dynamic LDS needs the attribute, once per device and instantiation (common.h)
   static VqfDynLdsFlags attr = {}, attr_pp = {};
-  const char* ppe = getenv("VQF_GEMM_BF16_PP");        // A/B switch, read per launch (tools/gemm_bf16_ab.py flips it
-  const bool pingpong = !(ppe && ppe[0] == '0');       // in one process): 0 selects the lockstep kernel of round 1
+  const int loopf = vqf_opt(VQF_OPT_GEMM_BF16_LOOP, 1);  // A/B switch (tools/gemm_bf16_ab.py flips it in one process):
+  const bool pingpong = loopf != 0;                    // 0 selects the lockstep kernel of round 1
   // the ping-pong kernels run as persistent workgroups, one per CU (VQF_GEMM_BF16_PERSIST=0: one workgroup per item)
   const int total = g.tiles_m * g.tiles_n * g.splits;
-  const char* pe = getenv("VQF_GEMM_BF16_PERSIST");
   int nwg = total;
-  if (!(pe && pe[0] == '0')) {
-    const int cus = vqf_cu_count() & ~7;               // a multiple of 8 keeps every workgroup's items on its own XCD
+  if (vqf_opt(VQF_OPT_GEMM_BF16_PERSIST, 1) != 0) {
+    int cus = vqf_cu_count() & ~7;                     // a multiple of 8 keeps every workgroup's items on its own XCD
+    const int lim = vqf_opt(VQF_OPT_GEMM_CU_LIMIT, 0) & ~7;
+    if (lim >= 8 && lim < cus) cus = lim;
     if (cus >= 8 && total > cus) nwg = cus;
   }
-  if (pingpong && !TA && !TB && !(ppe && ppe[0] == '3')) {   // VQF_GEMM_BF16_PP=3: the 32x32x16 ping-pong loop also for (0,0)
+  if (pingpong && !TA && !TB && loopf != 3) {          // VQF_OPT_GEMM_BF16_LOOP = 3: the 32x32x16 ping-pong loop also for (0,0)
     static VqfDynLdsFlags attr16 = {};
     if (int e = vqf_set_dyn_lds(reinterpret_cast<const void*>(&gemm_bf16_pp16_kernel), SMEM_BIG, attr16)) return e;
     VQF_LAUNCH(KID_GEMM_BF16, gemm_bf16_pp16_kernel, dim3(nwg), dim3(NT), SMEM_BIG, s, g);
@@ -701,8 +702,7 @@ int launch(const BigArgs& g, hipStream_t s) {
 }
 
 bool big_applies(int ta, int tb, int M, int N, int K, int flags) {
-  const char* e = getenv("VQF_GEMM_BF16_BIG");        // A/B switch, read per launch: 0 selects the 128x128 kernel everywhere
-  const bool enabled = !(e && e[0] == '0');
+  const bool enabled = vqf_opt(VQF_OPT_GEMM_BF16_BIG, 1) != 0;   // A/B switch: 0 selects the 128x128 kernel everywhere
   if (!enabled || (K % TK) || M < TM || N < 128 || (flags & VQF_GEMM_ACCUM)) return false;
   if (ta && (M % 8)) return false;
   if (tb && (N % 8)) return false;

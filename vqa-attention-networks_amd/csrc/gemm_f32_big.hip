@@ -461,16 +461,17 @@ template <bool TA, bool TB>
 int launch(const BigArgs& g, hipStream_t s) {
   // > 64 KB of dynamic LDS needs the attribute, once per device and instantiation (common.h)
   static VqfDynLdsFlags attr = {}, attr_pp = {};
-  const char* ppe = getenv("VQF_GEMM_F32_PP");         // A/B switch, read per launch: 0 lockstep, 1 ping-pong, 2 staggered lockstep
-  const int mode = (ppe && ppe[0] >= '0' && ppe[0] <= '2') ? ppe[0] - '0' : VQF_F32BIG_DEFAULT_MODE;
+  const int lo = vqf_opt(VQF_OPT_GEMM_F32_LOOP, VQF_F32BIG_DEFAULT_MODE);   // A/B switch: 0 lockstep, 1 ping-pong, 2 staggered lockstep
+  const int mode = (lo >= 0 && lo <= 2) ? lo : VQF_F32BIG_DEFAULT_MODE;
   const int kid = KID_GEMM_A0B0 + 2 * (TA ? 1 : 0) + (TB ? 1 : 0);
-  // persistent workgroups: one per CU, each walking its share of the work items (VQF_GEMM_F32_PERSIST=0: one workgroup
-  // per item, as in round 1; read per launch for A/Bs)
+  // persistent workgroups: one per CU, each walking its share of the work items (VQF_OPT_GEMM_F32_PERSIST = 0: one
+  // workgroup per item, as in round 1); VQF_OPT_GEMM_CU_LIMIT leaves part of the chip to other streams
   const int total = g.tiles_m * g.tiles_n * g.splits;
-  const char* pe = getenv("VQF_GEMM_F32_PERSIST");
   int nwg = total;
-  if (!(pe && pe[0] == '0')) {
-    const int cus = vqf_cu_count() & ~7;               // a multiple of 8 keeps every workgroup's items on its own XCD
+  if (vqf_opt(VQF_OPT_GEMM_F32_PERSIST, 1) != 0) {
+    int cus = vqf_cu_count() & ~7;                     // a multiple of 8 keeps every workgroup's items on its own XCD
+    const int lim = vqf_opt(VQF_OPT_GEMM_CU_LIMIT, 0) & ~7;
+    if (lim >= 8 && lim < cus) cus = lim;
     if (cus >= 8 && total > cus) nwg = cus;
   }
   const dim3 grid(nwg);
@@ -497,8 +498,7 @@ int launch(const BigArgs& g, hipStream_t s) {
 #define F32BIG_WGRAD_MIN_BLOCKS 256   // co_att_conv1's wgrad: 16 tiles x 16 splits = one full round, 1.71 -> 1.52 ms
 #endif
 bool big_applies(int ta, int tb, int M, int N, int K, int flags, size_t ws_bytes) {
-  const char* e = getenv("VQF_GEMM_F32_BIG");        // A/B switch, read per launch: 0 selects the 128x128 kernel everywhere
-  const bool enabled = !(e && e[0] == '0');
+  const bool enabled = vqf_opt(VQF_OPT_GEMM_F32_BIG, 1) != 0;   // A/B switch: 0 selects the 128x128 kernel everywhere
   if (!enabled || (K % TK) || M < TM || N < 128 || (flags & VQF_GEMM_ACCUM)) return false;
   if (ta && (M % 4)) return false;
   if (tb && (N % 4)) return false;

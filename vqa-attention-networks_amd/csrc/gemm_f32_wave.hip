@@ -244,8 +244,7 @@ int launch(const WaveArgs& g, int nwg, hipStream_t s) {
 // 0 = this kernel does not apply (caller continues with gemm_f32.hip), 1 = launched (rc holds the status)
 int vqf_gemm_f32_wave_try(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
                           int ldc, const float* bias, int flags, hipStream_t s, int* rc) {
-  const char* e = getenv("VQF_GEMM_F32_WAVE");         // A/B switch, read per launch: 0 disables this kernel
-  if (e && e[0] == '0') return 0;
+  if (vqf_opt(VQF_OPT_GEMM_F32_WAVE, 1) == 0) return 0;   // A/B switch: 0 disables this kernel
   if (ta || M > 1024 || (K % TK) || K < 256 || !aligned16(A) || !aligned16(B) || (lda % 4) || (ldb % 4)) return 0;
   if (tb && (N % 4)) return 0;
   // only where the 128x128 kernel cannot fill the chip without split-K slabs

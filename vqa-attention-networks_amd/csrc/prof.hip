@@ -1,9 +1,26 @@
-// Opt-in hipEvent profiler + ABI/version entry points.
+// Opt-in hipEvent profiler, library options, ABI/version entry points.
 #include "common.h"
 #include <mutex>
+#include <stdlib.h>
 #include <vector>
 
 int g_vqf_prof_on = 0;
+int g_vqf_opt[VQF_OPT_COUNT];
+
+namespace {
+const char* const kOptEnv[VQF_OPT_COUNT] = {
+    "VQF_GEMM_F32_PERSIST", "VQF_GEMM_BF16_PERSIST", "VQF_GEMM_F32_PP", "VQF_GEMM_BF16_PP", "VQF_GEMM_F32_BIG",
+    "VQF_GEMM_BF16_BIG", "VQF_GEMM_F32_WAVE", "VQF_FUSE_COAL", "VQF_FUSE_LS", "VQF_FUSE_LS_BWD", "VQF_GEMM_CU_LIMIT"};
+// the environment is read ONCE, when the library is loaded (command-line A/Bs); never on a launch path
+struct OptInit {
+  OptInit() {
+    for (int i = 0; i < VQF_OPT_COUNT; ++i) {
+      const char* e = getenv(kOptEnv[i]);
+      g_vqf_opt[i] = (e && ((e[0] >= '0' && e[0] <= '9') || e[0] == '-')) ? atoi(e) : -1;
+    }
+  }
+} g_opt_init;
+}  // namespace
 
 namespace {
 struct Pair { hipEvent_t a, b; int id; int d[3]; };
@@ -46,7 +63,18 @@ void vqf_prof_end(int id, hipStream_t s) {
 void vqf_prof_dims(int d0, int d1, int d2) { t_dims[0] = d0; t_dims[1] = d1; t_dims[2] = d2; }
 
 extern "C" {
-int vqf_abi_version(void) { return 3; }
+int vqf_abi_version(void) { return 4; }
+int vqf_set_option(int option, int value, int* previous) {
+  if (option < 0 || option >= VQF_OPT_COUNT) return VQF_E_BADARG;
+  if (previous) *previous = g_vqf_opt[option];
+  g_vqf_opt[option] = value < 0 ? -1 : value;
+  return VQF_OK;
+}
+int vqf_get_option(int option, int* value) {
+  if (option < 0 || option >= VQF_OPT_COUNT || !value) return VQF_E_BADARG;
+  *value = g_vqf_opt[option];
+  return VQF_OK;
+}
 const char* vqf_build_info(void) {
   return "libvqa_fusion gfx950 fp32-mfma(v_mfma_f32_32x32x2_f32) tiles 128x128x16 + 256x256x16(lds-dma, staggered) + "
          "32x64-per-wave(small M) bf16-mfma(v_mfma_f32_16x16x32_bf16 / 32x32x16) tiles 128x128x32 + "

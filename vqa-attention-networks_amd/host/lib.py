@@ -18,7 +18,7 @@ if os.environ.get("VQF_LIB"):          # A/B builds (tools/build_variant.sh); ne
 HEADER_PATH = os.path.join(os.path.dirname(PKG_DIR), "include", "vqa_fusion.h")
 
 # The one place the expected ABI number lives (csrc/prof.hip returns it from vqf_abi_version()).
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lock = threading.Lock()
 _lib = None
@@ -33,6 +33,8 @@ c_p = ctypes.c_void_p
 SIGNATURES = {
     "vqf_abi_version": (c_i, []),
     "vqf_build_info": (ctypes.c_char_p, []),
+    "vqf_set_option": (c_i, [c_i, c_i, ctypes.POINTER(c_i)]),
+    "vqf_get_option": (c_i, [c_i, ctypes.POINTER(c_i)]),
     "vqf_gemm_f32_ws_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i]),
     "vqf_gemm_f32": (c_i, [c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_i, c_f, c_i, c_f, c_i, c_p, c_sz, c_p]),
     "vqf_gemm_f32_batched": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, ctypes.c_longlong,

@@ -65,6 +65,42 @@ def workspace(device, nbytes):
 
 
 # ---------------------------------------------------------------------------
+# library options (include/vqa_fusion.h VQF_OPT_*): process-wide launch policy, cached in the library
+OPTIONS = {"gemm_f32_persist": 0, "gemm_bf16_persist": 1, "gemm_f32_loop": 2, "gemm_bf16_loop": 3, "gemm_f32_big": 4,
+           "gemm_bf16_big": 5, "gemm_f32_wave": 6, "fuse_coal": 7, "fuse_ls": 8, "fuse_ls_bwd": 9, "gemm_cu_limit": 10}
+
+
+def set_option(name, value):
+    """Set a library option (None / negative = the library's default); returns the value it replaced (-1 = default)."""
+    prev = ctypes.c_int(0)
+    _l.check(_lib().vqf_set_option(OPTIONS[name], -1 if value is None else int(value), ctypes.byref(prev)),
+             "vqf_set_option(%s)" % name)
+    return prev.value
+
+
+def get_option(name):
+    v = ctypes.c_int(0)
+    _l.check(_lib().vqf_get_option(OPTIONS[name], ctypes.byref(v)), "vqf_get_option(%s)" % name)
+    return v.value
+
+
+class options:
+    """with ops.options(gemm_f32_persist=0): ...   sets the options for the block and restores what was there."""
+
+    def __init__(self, **kw):
+        self.kw, self.prev = kw, {}
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            self.prev[k] = set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.prev.items():
+            set_option(k, v)
+        return False
+
+
 def gemm(a, b, ta=False, tb=False, bias=None, relu=False, out=None, accumulate=False,
          M=None, N=None, K=None, splitk=True):
     """C[M,N] = Aop @ Bop^T (+bias) ; a/b are 2-D contiguous.

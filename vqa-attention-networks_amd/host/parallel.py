@@ -58,9 +58,11 @@ class GradientAllReducer:
         opt.zero_grad(set_to_none=True); loss.backward(); reducer.finish(); opt.step()
     After finish(), every p.grad is a view into a flat bucket holding the average
     over ranks.  With world_size == 1 it is a no-op (grads are left untouched).
+    gemm_workgroups: None (default: one workgroup per tile at world > 1 unless the library option was set explicitly),
+    "per-tile" or "persistent" -- how the large-tile GEMMs launch while this reducer is alive (see __init__).
     """
 
-    def __init__(self, module, bucket_bytes=64 << 20, process_group=None, broadcast=True):
+    def __init__(self, module, bucket_bytes=64 << 20, process_group=None, broadcast=True, gemm_workgroups=None):
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -74,15 +76,68 @@ class GradientAllReducer:
         # (the part of the all-reduce the backward did NOT hide)
         self.timing = False
         self._marks = []
+        self._saved_options = None
+        self._hooks = []
         if self.world > 1:
             # The large-tile GEMMs normally run as PERSISTENT workgroups (one per CU, holding all of its LDS for the whole
             # launch: csrc/gemm_f32_big.hip).  The collective's kernels could then not get onto a CU before the 14-ms
             # weight-gradient GEMM they are meant to overlap with has ended.  Data-parallel runs therefore launch one
-            # workgroup per tile (a CU frees up every ~0.5 ms; costs the GEMMs ~0.7 %) unless the user set the switches.
-            os.environ.setdefault("VQF_GEMM_F32_PERSIST", "0")
-            os.environ.setdefault("VQF_GEMM_BF16_PERSIST", "0")
+            # workgroup per tile (a CU frees up every ~0.5 ms; costs the GEMMs ~0.7 %) unless the option was set explicitly
+            # (vqf_set_option / the environment at load time).  An explicit library option, not an environment mutation:
+            # close() (or leaving the `with` block, or the reducer's collection) restores what was there.
+            if gemm_workgroups is not None and gemm_workgroups not in ("per-tile", "persistent"):
+                raise ValueError("gemm_workgroups: 'per-tile', 'persistent' or None")
+            from . import ops, lib as _l
+            try:
+                self._saved_options = {}
+                for name in ("gemm_f32_persist", "gemm_bf16_persist"):
+                    cur = ops.get_option(name)
+                    if gemm_workgroups is None and cur >= 0:
+                        continue                        # set explicitly by the user: respected
+                    want = 1 if gemm_workgroups == "persistent" else 0
+                    self._saved_options[name] = ops.set_option(name, want)
+            except _l.VqfError:
+                # library not built: only a CPU rehearsal of the reducer (gloo) may go on without it
+                self._saved_options = None
+                if any(p.is_cuda for p in self.params):
+                    raise
             self._build_buckets(bucket_bytes)
             self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+
+    def close(self):
+        """Remove the gradient hooks and restore the library options this reducer changed."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        if self._saved_options:
+            from . import ops
+            for name, prev in self._saved_options.items():
+                ops.set_option(name, prev)
+        self._saved_options = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def gemm_workgroups(self):
+        """{'f32': ..., 'bf16': ...}: how the large-tile GEMMs of each family launch right now."""
+        out = {}
+        try:
+            from . import ops
+            for fam, name in (("f32", "gemm_f32_persist"), ("bf16", "gemm_bf16_persist")):
+                out[fam] = "one per tile" if ops.get_option(name) == 0 else "persistent, one per CU"
+        except Exception as e:      # no library (CPU-only rehearsal of the reducer)
+            out = {"f32": "n/a", "bf16": "n/a", "note": str(e)[:80]}
+        return out
 
     # -- setup ---------------------------------------------------------------
     def broadcast_parameters(self, src=0):
@@ -172,6 +227,8 @@ class GradientAllReducer:
             b["handle"] = None
         if marks:
             self._marks.append(marks)
+            if len(self._marks) > 1024:                # timing is a bench-only switch; never grow without bound
+                del self._marks[:512]
 
     def exposed_ms(self):
         """Mean over the timed steps of [ms from the end of the backward kernels to bucket i's completion],
@@ -179,12 +236,13 @@ class GradientAllReducer:
         if not self._marks:
             return []
         torch.cuda.synchronize()
-        n = len(self._marks[0]) - 1
+        marks_all, self._marks = self._marks, []      # a bench-only switch: the window is consumed here, nothing accumulates
+        n = min(len(m) for m in marks_all) - 1
         acc = [0.0] * n
-        for marks in self._marks:
+        for marks in marks_all:
             for i in range(n):
                 acc[i] += marks[0].elapsed_time(marks[i + 1])
-        return [round(a / len(self._marks), 4) for a in acc]
+        return [round(a / len(marks_all), 4) for a in acc]
 
     def bucket_bytes_list(self):
         return [b["flat"].numel() * b["flat"].element_size() for b in self.buckets]
