@@ -18,8 +18,15 @@ too -- including the image-projection GEMM and its weight-gradient GEMM whose
 results cannot reach the logits/gradients in MFB-baseline because mfb.py:84,118
 take their softmax over a singleton axis.  roofline.achieved
 counts only FLOPs actually executed by the measured kernel.
+
+After the headline (BASELINE config 2) a default 1-GPU run frees the model and
+times, in the same process, BASELINE config 3 (MHBCoAtt, bf16 operands, B=512)
+and config 4 (HieCoAtten, fp32, B=256): `secondary.config3 / .config4`, each
+with its own ms_per_step, value, dtype and roofline object.  The headline keys
+are unaffected (`--no-secondary` skips them).
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -33,10 +40,12 @@ for _p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golde
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
-import torch.nn.functional as F  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 matrix peak (= vector peak)
+BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 matrix peak (no sparsity)
 HBM_PEAK_GBS = 8000.0
+# algorithmic GEMM FLOPs of one train step per QA pair (SURVEY 8d / BASELINE.md section 4), forward + backward
+STEP_MFLOP_PER_QA = {"mfb": 10034.0, "mhb_coAtt": 9578.0, "hieCoAtten": 1515.0}
 
 
 def full_cfg(model_name="mfb"):
@@ -72,11 +81,13 @@ def host_cores():
     return n
 
 
-def cpu_baseline(batch=512, timed=3, config1_timed=5):
+def cpu_baseline(batch=512, warmups=2, timed=5, config1_warmups=3, config1_timed=5):
     """The oracle (CPU restatement, PyTorch CPU ops) on the host cores, on the metric's own configuration
-    (BASELINE.md section 3): the MFB train step (fwd + loss + bwd + Adam, dropout masks supplied) at B=512,
-    1 warm-up + `timed` steps, median; plus BASELINE config 1 (MFB forward, eval, B=32) as `config1`.
-    About 45 s on the 16 cores of a GPU box; `--cpu-batch` shrinks the sample for quick runs."""
+    (BASELINE.md section 3): the MFB train step (fwd + loss + bwd + Adam) at B=512, `warmups` warm-ups + `timed`
+    steps, median; plus BASELINE config 1 (MFB forward, eval, B=32) as `config1`.  The dropout keep-masks are drawn
+    per step like the reference's nn.Dropout does (33 % of the reference's CPU step); `value` is the
+    CONSERVATIVE rate with the mask draws outside the timed region, `with_mask_generation` the rate with them inside.
+    About 75 s on the 16 cores of a GPU box; `--cpu-batch` shrinks the sample for quick runs."""
     from oracle import ref_torch as O
     cores = host_cores()
     torch.set_num_threads(cores)
@@ -95,6 +106,7 @@ def cpu_baseline(batch=512, timed=3, config1_timed=5):
 
     def one_step(img, q, a):
         Bs = img.shape[0]
+        tm = time.perf_counter()
         drop = dict(l=(torch.rand((Bs, 14, 1024), generator=gen) >= 0.3),
                     m1=(torch.rand((Bs, 196, 5000), generator=gen) >= 0.1),
                     m2=(torch.rand((Bs, 5000), generator=gen) >= 0.1))
@@ -104,7 +116,8 @@ def cpu_baseline(batch=512, timed=3, config1_timed=5):
         loss = O.ce_loss(logits, a)
         loss.backward()
         opt.step()
-        return time.perf_counter() - t0
+        t1 = time.perf_counter()
+        return t1 - t0, t1 - tm
 
     def fwd_only(img, q):
         t0 = time.perf_counter()
@@ -114,10 +127,13 @@ def cpu_baseline(batch=512, timed=3, config1_timed=5):
 
     img, q, a = synth_batch(batch, 0, "cpu")
     one_step(img[:16], q[:16], a[:16])                      # page-in / thread-pool warm-up
-    one_step(img, q, a)                                     # 1 warm-up at the full batch
-    times = sorted(one_step(img, q, a) for _ in range(timed))
-    t = times[len(times) // 2]
-    fwd_only(img[:32], q[:32])
+    for _ in range(warmups):
+        one_step(img, q, a)                                 # warm-ups at the full batch
+    runs = [one_step(img, q, a) for _ in range(timed)]
+    t = sorted(r[0] for r in runs)[timed // 2]
+    tmask = sorted(r[1] for r in runs)[timed // 2]
+    for _ in range(config1_warmups):
+        fwd_only(img[:32], q[:32])
     t1s = sorted(fwd_only(img[:32], q[:32]) for _ in range(config1_timed))
     t1 = t1s[len(t1s) // 2]
     try:
@@ -125,12 +141,15 @@ def cpu_baseline(batch=512, timed=3, config1_timed=5):
     except Exception:
         model = "unknown"
     return {"value": round(batch / t, 3), "unit": "QA-pairs/s", "cores": cores, "kind": "port",
-            "sample": "oracle MFB train step (fwd+loss+bwd+Adam, dropout masks supplied), B=%d, "
-                      "1 warm-up + %d timed steps, median %.2f s/step, %d threads; CPU: %s"
-                      % (batch, timed, t, cores, model),
+            "sample": "oracle MFB train step (fwd+loss+bwd+Adam; dropout keep-masks drawn per step OUTSIDE the timed "
+                      "region), B=%d, %d warm-ups + %d timed steps, median %.2f s/step, %d threads; CPU: %s"
+                      % (batch, warmups, timed, t, cores, model),
+            "with_mask_generation": {"value": round(batch / tmask, 3), "unit": "QA-pairs/s",
+                                     "sample": "the same steps with the three keep-mask draws (torch.rand >= p; the reference "
+                                               "draws them inside nn.Dropout) inside the timed region, median %.2f s/step" % tmask},
             "config1": {"value": round(32 / t1, 3), "unit": "QA-pairs/s",
-                        "sample": "BASELINE config 1: oracle MFB forward, eval, B=32, 1 warm-up + %d timed, "
-                                  "median %.3f s, %d threads" % (config1_timed, t1, cores)}}
+                        "sample": "BASELINE config 1: oracle MFB forward, eval, B=32, %d warm-ups + %d timed, "
+                                  "median %.3f s, %d threads" % (config1_warmups, config1_timed, t1, cores)}}
 
 
 def live_wgrad_probe(ops, B, dev, reps=6):
@@ -158,6 +177,199 @@ def live_wgrad_probe(ops, B, dev, reps=6):
     return n, ms, red
 
 
+def pmc_lookup(dtype, M, N, K):
+    """Beyond-L2 bytes per launch of a GEMM from the committed rocprofv3 --pmc passes (PMC passes cannot run inside
+    the timed process): newest profiles/r*_pmc_*.json whose dtype / M / N / K match.  -> (bytes, note, source) or Nones."""
+    for src in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_*.json")), reverse=True):
+        try:
+            recs = json.load(open(src))
+        except Exception:
+            continue
+        for pmc in (recs if isinstance(recs, list) else [recs]):
+            try:
+                if pmc.get("dtype", "f32") == dtype and (pmc["M"], pmc["N"], pmc["K"]) == (M, N, K):
+                    return pmc["traffic_bytes"], pmc.get("note", "") + "; " + pmc.get("formula", ""), os.path.relpath(src, ROOT)
+            except Exception:
+                continue
+    return None, None, None
+
+
+def pmc_kernel_lookup(name):
+    """The same for the HBM-bound kernels: profiles/r*_pmc_fuse.json holds {kernel: {traffic_bytes, algorithmic_bytes, ...}}."""
+    for src in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fuse.json")), reverse=True):
+        try:
+            rec = json.load(open(src)).get(name)
+            if rec:
+                return rec, os.path.relpath(src, ROOT)
+        except Exception:
+            continue
+    return None, None
+
+
+def gemm_roofline(ops, kernel_id, dtype, M, N, K, what, peak):
+    """roofline object of one GEMM launch family timed by the library's hipEvent profiler (shape-tagged)."""
+    n, ms = ops.prof_shape(kernel_id, M, N, K)
+    if not n:
+        return None
+    flops = 2.0 * M * N * K
+    ach = flops / (ms / n * 1e-3) / 1e12
+    traffic, note, source = pmc_lookup(dtype, M, N, K)
+    return {"bound": "mfma", "kernel": what, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": source, "traffic_note": note,
+            "avg_launch_ms": round(ms / n, 4), "launches": n, "flops_per_launch": flops}
+
+
+class Workload:
+    """One BASELINE configuration on one GPU: model, HIP criterion + Adam (solver.py:25-29), synthetic batch."""
+
+    def __init__(self, vqa_amd, model_name, dtype, B, rank, dev, args=None):
+        ops = vqa_amd.ops
+        self.name, self.dtype, self.B = model_name, dtype, B
+        if model_name == "hieCoAtten":
+            model = vqa_amd.HieCoAtten(block_num=196, word_num=14, img_size=2048, vocab_size=1000,
+                                       embed_size=512, output_size=1000)
+        else:
+            model = (vqa_amd.MFB if model_name == "mfb" else vqa_amd.MHBCoAtt)(full_cfg(model_name))
+        init_like_reference(model)
+        model = model.to(dev).train()
+        if model_name != "hieCoAtten":
+            model.gemm_dtype = {"f32": "fp32", "bf16": "bf16", "bf16-all": "bf16-all"}[dtype]
+        if args is not None and args.miopen_lstm and hasattr(model, "use_hip_lstm"):
+            model.use_hip_lstm = False
+        if args is not None and args.pruned and hasattr(model, "pruned"):
+            model.pruned = True
+        self.forward_only = bool(args is not None and args.forward_only)
+        if self.forward_only:
+            model.eval()
+        no_overlap = bool(args is not None and args.no_overlap)
+        overlap = bool(args is not None and args.overlap)
+        self.stream_mode = "one compute stream (projection + fusion one node)" if no_overlap else (
+            "two streams (projection on a side stream)" if overlap else
+            "one compute stream (projection its own node, weight gradient last)")
+        if hasattr(model, "overlap_streams"):              # the SAME configuration at every N (VERDICT r01 weak #11)
+            model.overlap_streams = False if no_overlap else (True if overlap else "same-stream")
+        self.model = model
+        # solver.py:25-29: criterion + Adam, both on the HIP path (host/train_step.py)
+        self.opt = vqa_amd.Adam(model.parameters(), lr=7e-4)
+        self.criterion = vqa_amd.train_step.criterion_for(model_name)
+        self.img, self.q, self.a = synth_batch(B, rank, dev)
+        if dtype != "f32" and model_name != "hieCoAtten":
+            # SURVEY 8d config 3: the image grid is stored in bf16 (vqf_cast_f32_bf16 == what
+            # FeatureStager(bf16=True) delivers); products accumulate in fp32
+            self.img = ops.cast_bf16(self.img.view(-1, self.img.shape[-1])).view(self.img.shape)
+        self.soft = torch.softmax(torch.randn((B, 1000), generator=torch.Generator().manual_seed(1236 + rank)), 1).to(dev)
+        self.reducer = None
+
+    def step(self):
+        m = self.model
+        if self.forward_only:
+            with torch.no_grad():
+                out = m.forward(self.img, self.q)
+                return (out[0] if self.name == "hieCoAtten" else out).sum()
+        self.opt.zero_grad(set_to_none=True)
+        out = m.forward(self.img, self.q)
+        if self.name == "hieCoAtten":
+            out = out[0]
+        loss = self.criterion(out, self.soft if self.name == "mhb_coAtt" else self.a)
+        loss.backward()
+        if self.reducer is not None:
+            self.reducer.finish()
+        self.opt.step()
+        return loss
+
+    def free(self):
+        if self.reducer is not None:
+            self.reducer.close()
+        self.model = self.opt = self.criterion = self.img = self.q = self.a = self.soft = self.reducer = None
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+
+
+def timed_steps(wl, ops, warmup, steps, fence):
+    for _ in range(warmup):
+        wl.step()
+    if wl.reducer is not None:
+        wl.reducer.timing = True
+    ops.prof_reset()
+    ops.prof_enable(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = wl.step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    ops.prof_enable(False)
+    return elapsed, loss
+
+
+def kernel_table(rep, steps):
+    return {k: {"launches_per_step": round(n / steps, 2), "ms_per_step": round(ms / steps, 4)}
+            for k, (n, ms) in sorted(rep.items(), key=lambda kv: -kv[1][1])}
+
+
+def step_roofline(model_name, B, ms_per_step, dtype):
+    """Whole-step view: algorithmic GEMM FLOPs of the step (SURVEY 8d) / MFMA peak of the dtype the large GEMMs run in."""
+    tflop = STEP_MFLOP_PER_QA[model_name] * B / 1e6
+    peak = BF16_MFMA_PEAK_TFLOPS if dtype != "f32" else FP32_MFMA_PEAK_TFLOPS
+    floor_ms = tflop / peak * 1e3
+    return {"algorithmic_tflop_per_step": round(tflop, 4), "peak_tflops": peak, "floor_ms": round(floor_ms, 3),
+            "frac": round(floor_ms / ms_per_step, 4),
+            "note": "floor = all GEMM FLOPs of the step at the MFMA peak of the dtype of its two large GEMM families"
+                    + ("; 4 % of the FLOPs (small projections, LSTM) and every HBM-bound stage run in fp32 in this mode, "
+                       "and the 512-step batch-axis LSTM recursion is latency-bound: the floor is not attainable"
+                       if dtype != "f32" else "")}
+
+
+def secondary_config(vqa_amd, which, dev, steps, warmup):
+    """BASELINE config 3 / 4, timed in this process after the headline (VERDICT r02 next #1)."""
+    ops = vqa_amd.ops
+    if which == "config3":
+        name, dtype, B = "mhb_coAtt", "bf16", 512
+    else:
+        name, dtype, B = "hieCoAtten", "f32", 256
+    wl = Workload(vqa_amd, name, dtype, B, 0, dev)
+
+    def fence():
+        torch.cuda.synchronize()
+    elapsed, loss = timed_steps(wl, ops, warmup, steps, fence)
+    ms = 1e3 * elapsed / steps
+    rep = ops.prof_report()
+    if which == "config3":
+        M, N, K = B * 196, 5000, 2048
+        roof = gemm_roofline(ops, "gemm_bf16", "bf16", M, N, K,
+                             "img_conv1d forward GEMM, bf16 operands / fp32 accumulate / bf16 output (M=%d,N=%d,K=%d; "
+                             "gemm_bf16_big.hip, 256x256 tiles, LDS-DMA ping-pong, v_mfma_f32_16x16x32_bf16; profiler id "
+                             "gemm_bf16)" % (M, N, K), BF16_MFMA_PEAK_TFLOPS)
+        if roof is not None:
+            w = gemm_roofline(ops, "gemm_bf16", "bf16", N, K, M, "its weight gradient (M=%d,N=%d,K=%d; 32x32x16, K-major "
+                              "operands, split-K)" % (N, K, M), BF16_MFMA_PEAK_TFLOPS)
+            if w is not None:
+                roof["wgrad"] = {k: w[k] for k in ("kernel", "achieved", "frac", "avg_launch_ms", "launches", "traffic", "traffic_source")}
+        workload = ("MHBCoAtt train step (fwd+KLDiv+bwd+Adam), batch 512, 196x2048 image grid stored in bf16, 14 tokens, "
+                    "bf16 operands / fp32 accumulate in the img_conv1d and co_att_conv1 GEMM families, everything else fp32; "
+                    "reference LSTM orientation (512-step batch-axis recursion)")
+    else:
+        M, N, K = B * 196, 512, 2048
+        roof = gemm_roofline(ops, "gemm_f32_a0b0(fwd)", "f32", M, N, K,
+                             "img_emb forward GEMM + bias + ReLU (M=%d,N=%d,K=%d; hieCoAtten.py:25; profiler id "
+                             "gemm_f32_a0b0)" % (M, N, K), FP32_MFMA_PEAK_TFLOPS)
+        if roof is not None:
+            w = gemm_roofline(ops, "gemm_f32_a1b1(wgrad)", "f32", N, K, M, "its weight gradient (M=%d,N=%d,K=%d)" % (N, K, M),
+                              FP32_MFMA_PEAK_TFLOPS)
+            if w is not None:
+                roof["wgrad"] = {k: w[k] for k in ("kernel", "achieved", "frac", "avg_launch_ms", "launches", "traffic", "traffic_source")}
+        workload = ("HieCoAtten train step (fwd+CE+bwd+Adam), batch 256, img_size 2048, embed 512, 14 tokens, fp32, "
+                    "functional dropout always on (reference behaviour)")
+    out = {"metric": "QA-pairs/sec fwd+bwd, %s batch %d" % (name, B), "value": round(B * steps / elapsed, 2),
+           "unit": "QA-pairs/s", "ms_per_step": round(ms, 3), "steps": steps, "warmup": warmup,
+           "dtype": "bf16" if dtype != "f32" else "f32", "config": {"workload": workload, "global_batch": B},
+           "loss": round(float(loss.item()), 5), "roofline": roof, "step_roofline": step_roofline(name, B, ms, dtype),
+           "kernels_ms_per_step": kernel_table(rep, steps)}
+    wl.free()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -166,6 +378,10 @@ def main():
     ap.add_argument("--batch", type=int, default=512, help="QA pairs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=512, help="batch of the cpu_baseline train step (default: the metric's 512)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the in-process runs of BASELINE configs 3 and 4 that follow the headline on a default 1-GPU run")
+    ap.add_argument("--secondary-steps", type=int, default=12)
+    ap.add_argument("--secondary-warmup", type=int, default=4)
     ap.add_argument("--no-overlap", action="store_true", help="A/B: projection + fusion as ONE autograd node")
     ap.add_argument("--overlap", action="store_true",
                     help="A/B: image projection on a side HIP stream.  Default at EVERY N: one compute stream with "
@@ -184,6 +400,8 @@ def main():
                          "projection GEMM (ques_proj*, img_proj*, question attention too)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); "
                     "'gloo' lets several ranks share one GPU for rehearsals")
+    ap.add_argument("--gemm-workgroups", default=None, choices=["per-tile", "persistent"],
+                    help="large-tile GEMM launch form under data parallelism (default: per-tile at N > 1, see host/parallel.py)")
     args = ap.parse_args()
 
     import vqa_amd
@@ -204,75 +422,18 @@ def main():
     dev = torch.device("cuda", local)
 
     B = args.batch
-    if args.model == "hieCoAtten":
-        if args.batch == 512:
-            B = 256                                   # BASELINE config 4
-        model = vqa_amd.HieCoAtten(block_num=196, word_num=14, img_size=2048, vocab_size=1000,
-                                   embed_size=512, output_size=1000)
-    else:
-        cfg = full_cfg(args.model)
-        model = (vqa_amd.MFB if args.model == "mfb" else vqa_amd.MHBCoAtt)(cfg)
-    init_like_reference(model)
-    model = model.to(dev).train()
-    if args.model != "hieCoAtten":
-        model.gemm_dtype = {"f32": "fp32", "bf16": "bf16", "bf16-all": "bf16-all"}[args.dtype]
-    if args.miopen_lstm and hasattr(model, "use_hip_lstm"):
-        model.use_hip_lstm = False
-    if args.pruned and hasattr(model, "pruned"):
-        model.pruned = True
-    if args.forward_only:
-        model.eval()
-    stream_mode = "one compute stream (projection + fusion one node)" if args.no_overlap else (
-        "two streams (projection on a side stream)" if args.overlap else
-        "one compute stream (projection its own node, weight gradient last)")
-    if hasattr(model, "overlap_streams"):                # the SAME configuration at every N
-        model.overlap_streams = False if args.no_overlap else (True if args.overlap else "same-stream")
-    reducer = parallel.GradientAllReducer(model)        # broadcasts rank 0's weights; no-op at world 1
-    # solver.py:25-29: criterion + Adam, both on the HIP path (host/train_step.py)
-    opt = vqa_amd.Adam(model.parameters(), lr=7e-4)
-    criterion = vqa_amd.train_step.criterion_for(args.model)
-    img, q, a = synth_batch(B, rank, dev)
-    if args.dtype != "f32" and args.model != "hieCoAtten":
-        # the image grid is stored in bf16 (vqf_cast_f32_bf16 == what
-        # FeatureStager(bf16=True) delivers); products accumulate in fp32
-        img = ops.cast_bf16(img.view(-1, img.shape[-1])).view(img.shape)
-    soft = torch.softmax(torch.randn((B, 1000), generator=torch.Generator().manual_seed(1236 + rank)), 1).to(dev)
-
-    def fwd_step():
-        with torch.no_grad():
-            out = model.forward(img, q)
-            return (out[0] if args.model == "hieCoAtten" else out).sum()
-
-    def step():
-        if args.forward_only:
-            return fwd_step()
-        opt.zero_grad(set_to_none=True)
-        out = model.forward(img, q)
-        if args.model == "hieCoAtten":
-            out = out[0]
-        loss = criterion(out, soft if args.model == "mhb_coAtt" else a)
-        loss.backward()
-        reducer.finish()
-        opt.step()
-        return loss
+    if args.model == "hieCoAtten" and args.batch == 512:
+        B = 256                                       # BASELINE config 4
+    wl = Workload(vqa_amd, args.model, args.dtype, B, rank, dev, args)
+    reducer = parallel.GradientAllReducer(wl.model, gemm_workgroups=args.gemm_workgroups)   # broadcasts rank 0's weights; no-op at world 1
+    wl.reducer = reducer
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    reducer.timing = True
-    ops.prof_reset()
-    ops.prof_enable(True)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    ops.prof_enable(False)
+    elapsed, loss = timed_steps(wl, ops, args.warmup, args.steps, fence)
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -280,41 +441,34 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     value = B * world * args.steps / elapsed
 
-    # ---- roofline of the dominant kernel: the image-projection GEMM (mfb.py:96) --------------
-    M, N, K = B * 196, 5000, 2048
-    n_f, ms_f = ops.prof_gemm(0, 0, M, N, K)               # forward projection
-    n_w, ms_w = ops.prof_gemm(1, 1, N, K, M)               # its weight gradient (same FLOPs)
+    # ---- roofline of the dominant kernel: the image-projection GEMM (mfb.py:96 / mhb_coAtt.py:98) or, for HieCoAtten,
+    # the img_emb GEMM (hieCoAtten.py:25); fp32 or bf16 launch, whichever this run executed ----------------
+    is_bf16 = args.dtype != "f32" and args.model != "hieCoAtten"
+    Nn = 512 if args.model == "hieCoAtten" else 5000
+    M, N, K = B * 196, Nn, 2048
+    peak = BF16_MFMA_PEAK_TFLOPS if is_bf16 else FP32_MFMA_PEAK_TFLOPS
+    fam = ("gemm_bf16", "gemm_bf16") if is_bf16 else ("gemm_f32_a0b0(fwd)", "gemm_f32_a1b1(wgrad)")
+    proj = "img_emb" if args.model == "hieCoAtten" else "img_conv1d"
+    what = ("%s forward GEMM (M=%d,N=%d,K=%d; gemm_bf16_big.hip, 256x256 tiles, LDS-DMA ping-pong, bf16 operands / fp32 "
+            "accumulate; profiler id gemm_bf16)" % (proj, M, N, K)) if is_bf16 else (
+        "%s forward GEMM (M=%d,N=%d,K=%d; %s; profiler id gemm_f32_a0b0)"
+        % (proj, M, N, K, "gemm_f32_big.hip, 256x256 tiles, LDS-DMA, staggered wave halves" if Nn == 5000
+           else "gemm_f32.hip 128x128 tiles"))
+    roofline = gemm_roofline(ops, fam[0], "bf16" if is_bf16 else "f32", M, N, K, what, peak)
     flops = 2.0 * M * N * K
-    roofline = None
-    if n_f:
-        ach = flops / (ms_f / n_f * 1e-3) / 1e12
-        traffic, traffic_note, traffic_source = None, None, None
-        # PMC passes cannot run inside the timed process: the committed rocprofv3 --pmc result of this launch
-        for src in ("profiles/r02_pmc_gemm.json", "profiles/r01_pmc_gemm.json"):
-            try:
-                pmc = json.load(open(os.path.join(ROOT, src)))
-                if (pmc["M"], pmc["N"], pmc["K"]) == (M, N, K):
-                    traffic, traffic_note, traffic_source = pmc["traffic_bytes"], pmc["note"] + "; " + pmc["formula"], src
-                    break
-            except Exception:
-                pass
-        roofline = {"bound": "mfma", "kernel": "img_conv1d forward GEMM (M=%d,N=%d,K=%d; gemm_f32_big.hip, 256x256 tiles, LDS-DMA, staggered wave halves; profiler id gemm_f32_a0b0)" % (M, N, K),
-                    "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                    "traffic_source": traffic_source, "traffic_note": traffic_note,
-                    "avg_launch_ms": round(ms_f / n_f, 4), "launches": n_f,
-                    "flops_per_launch": flops}
-        if n_w:
-            achw = flops / (ms_w / n_w * 1e-3) / 1e12
-            roofline["wgrad"] = {"kernel": "gemm_f32_a1b1 img_conv1d wgrad (gemm_f32_big.hip, K-major interleaved strips, split-K 8)", "achieved": round(achw, 2),
-                                 "frac": round(achw / FP32_MFMA_PEAK_TFLOPS, 4),
-                                 "avg_launch_ms": round(ms_w / n_w, 4), "launches": n_w,
+    if roofline is not None:
+        w = gemm_roofline(ops, fam[1], "bf16" if is_bf16 else "f32", N, K, M,
+                          "%s img_conv1d wgrad (K-major operands, split-K)" % fam[1], peak)
+        if w is not None:
+            roofline["wgrad"] = {"kernel": w["kernel"], "achieved": w["achieved"], "frac": w["frac"],
+                                 "avg_launch_ms": w["avg_launch_ms"], "launches": w["launches"],
                                  "operands": ("in-step launch; in faithful MFB dP is EXACTLY ZERO (singleton-axis "
                                               "softmax): see wgrad_live for random operands")
                                  if (args.model == "mfb" and not args.pruned) else "in-step launch, live operands"}
     rep = ops.prof_report()
     exposed = reducer.exposed_ms()
-    if roofline is not None and world == 1 and args.dtype == "f32" and not args.forward_only:
+    gemm_wg = reducer.gemm_workgroups()
+    if roofline is not None and world == 1 and args.dtype == "f32" and args.model == "mfb" and not args.forward_only:
         n_l, ms_l, red_l = live_wgrad_probe(ops, B, dev)
         if n_l:
             achl = flops / (ms_l / n_l * 1e-3) / 1e12
@@ -323,29 +477,39 @@ def main():
                                       "achieved": round(achl, 2), "frac": round(achl / FP32_MFMA_PEAK_TFLOPS, 4),
                                       "avg_launch_ms": round(ms_l / n_l, 4), "launches": n_l,
                                       "splitk_reduce_ms_per_launch": round(red_l / n_l, 4)}
-            try:        # beyond-L2 bytes of this launch from the committed rocprofv3 --pmc passes
-                pw = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_wgrad.json")))
-                if (pw["M"], pw["N"], pw["K"]) == (N, K, M):
-                    roofline["wgrad_live"].update(traffic=pw["traffic_bytes"], traffic_source="profiles/r02_pmc_wgrad.json")
-            except Exception:
-                pass
-    kernels = {k: {"launches_per_step": round(n / args.steps, 2), "ms_per_step": round(ms / args.steps, 4)}
-               for k, (n, ms) in sorted(rep.items(), key=lambda kv: -kv[1][1])}
-    # secondary roofline: the HBM-bound MFB fusion kernels (mfb.py:98-106 and its backward).
-    # algorithmic bytes per step: fwd reads P (+q) and writes R for the L=196 stage and the final block;
-    # bwd reads P, dY, Y and writes dP.
+            tr, _, src = pmc_lookup("f32", N, K, M)       # beyond-L2 bytes of this launch from the committed --pmc passes
+            if tr is not None:
+                roofline["wgrad_live"].update(traffic=tr, traffic_source=src)
+    kernels = kernel_table(rep, args.steps)
+    # secondary roofline: the HBM-bound kernels of the step.  algorithmic bytes per step: fusion fwd reads P (+q) and
+    # writes R for the L=196 stage and the final block; bwd reads P, dY, Y and writes dP; the glimpse passes
+    # read the image tensor once; att_logits_bwd reads + writes the co-attention hidden layer.  `traffic` = HBM bytes per
+    # step from the committed rocprofv3 --pmc passes (profiles/r*_pmc_fuse.json), null until such a pass exists.
     rows, o5 = B * 196, 5000
-    fwd_bytes = 4.0 * (rows * o5 + B * o5 + rows * 1000 + rows) + 4.0 * (2 * B * o5 + B * 1000)
-    bwd_bytes = 4.0 * (2 * rows * o5 + 2 * rows * 1000 + 2 * B * o5) + 4.0 * (3 * B * o5 + 2 * B * 1000)
+    pbytes = 2.0 if is_bf16 else 4.0
+    hid = 1024 if args.model == "mfb" else 512
+    alg = {
+        "mfb_fuse_fwd": pbytes * rows * o5 + 4.0 * (B * o5 + rows * 1000 + rows) + 4.0 * (2 * B * o5 + B * 1000),
+        "mfb_fuse_bwd": 2 * pbytes * rows * o5 + 4.0 * (2 * rows * 1000 + 2 * B * o5) + 4.0 * (3 * B * o5 + 2 * B * 1000),
+        "glimpse_pool_fwd": pbytes * rows * 2048 + 4.0 * (B * 14 * 1024),
+        "glimpse_pool_bwd": pbytes * rows * 2048 + 4.0 * (B * 14 * 1024 * 2),
+        "att_logits_bwd": 4.0 * 2 * (rows * hid + B * 14 * hid),
+        "scale_rows": 4.0 * 2 * rows * 1000, "rowdot": 4.0 * 2 * rows * 1000,
+    }
     roofline_hbm = {}
-    for name, nbytes in (("mfb_fuse_fwd", fwd_bytes), ("mfb_fuse_bwd", bwd_bytes)):
-        if name in rep and rep[name][1] > 0:
-            ms_step = rep[name][1] / args.steps
-            gbs = nbytes / (ms_step * 1e-3) / 1e9
-            roofline_hbm[name] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": round(gbs / HBM_PEAK_GBS, 4), "ms_per_step": round(ms_step, 4),
-                                  "algorithmic_bytes_per_step": nbytes}
+    if args.model != "hieCoAtten":
+        for name, nbytes in alg.items():
+            if name in rep and rep[name][1] > 0:
+                ms_step = rep[name][1] / args.steps
+                gbs = nbytes / (ms_step * 1e-3) / 1e9
+                pm, src = pmc_kernel_lookup(name) if (args.model == "mfb" and args.dtype == "f32" and B == 512) else (None, None)
+                roofline_hbm[name] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": round(gbs / HBM_PEAK_GBS, 4), "ms_per_step": round(ms_step, 4),
+                                      "algorithmic_bytes_per_step": nbytes,
+                                      "traffic": pm["traffic_bytes"] if pm else None, "traffic_source": src,
+                                      "traffic_over_algorithmic": round(pm["traffic_bytes"] / nbytes, 3) if pm else None}
 
+    out = None
     if rank == 0:
         out = {
             "metric": ("QA-pairs/sec fwd+bwd, MFB-baseline batch 512" if (args.model == "mfb" and B == 512)
@@ -364,16 +528,30 @@ def main():
                        "grad_allreduce_bytes": reducer.gradient_bytes(),
                        "ranks_seen": dist.get_world_size() if dist.is_initialized() else 1,
                        "backend": (dist.get_backend() if dist.is_initialized() else "none (single process)"),
-                       "streams": stream_mode,
-                       "gemm_workgroups": ("one per tile (data-parallel default: CUs free up for the collective)"
-                                           if os.environ.get("VQF_GEMM_F32_PERSIST") == "0" else "persistent, one per CU"),
+                       "streams": wl.stream_mode,
+                       "gemm_workgroups": ("%s (data-parallel default: CUs free up for the collective)" % gemm_wg["f32"]
+                                           if gemm_wg["f32"].startswith("one per tile") else gemm_wg["f32"]),
+                       "gemm_workgroups_by_family": gemm_wg,
                        "allreduce_bucket_bytes": reducer.bucket_bytes_list(),
                        "allreduce_exposed_ms": exposed},
             "loss": round(float(loss.item()), 5),
             "roofline": roofline,
+            "step_roofline": step_roofline(args.model, B, ms_per_step, args.dtype) if not (args.forward_only or args.pruned) else None,
             "roofline_hbm_kernels": roofline_hbm,
             "kernels_ms_per_step": kernels,
         }
+    headline_default = (args.model == "mfb" and args.dtype == "f32" and B == 512 and not args.pruned
+                        and not args.forward_only and not args.miopen_lstm)
+    if world == 1 and headline_default and not args.no_secondary:
+        wl.free()
+        del reducer
+        out["secondary"] = {}
+        for which in ("config3", "config4"):
+            try:
+                out["secondary"][which] = secondary_config(vqa_amd, which, dev, args.secondary_steps, args.secondary_warmup)
+            except Exception as e:          # the headline line must survive a secondary failure; say what happened
+                out["secondary"][which] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(batch=args.cpu_batch)
             out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)

@@ -14,7 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_prints_one_contract_line():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
-                        "--cpu-batch", "64"],          # the default (the metric's B=512) takes ~45 s of CPU time
+                        "--cpu-batch", "64",           # the default (the metric's B=512) takes ~75 s of CPU time
+                        "--secondary-steps", "2", "--secondary-warmup", "1"],
                        capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
@@ -41,6 +42,24 @@ def test_bench_prints_one_contract_line():
     cfg = d["config"]
     assert cfg["ranks_seen"] == 1 and cfg["allreduce_exposed_ms"] == [] and "one compute stream" in cfg["streams"]
     assert cfg["gemm_workgroups"].startswith("persistent")
+    assert cfg["gemm_workgroups_by_family"] == {"f32": "persistent, one per CU", "bf16": "persistent, one per CU"}
+    assert "with_mask_generation" in c and 0 < c["with_mask_generation"]["value"] <= c["value"] * 1.05
+    assert 0.3 < d["step_roofline"]["frac"] < 1.0
+    # HBM-bound kernels of the step: algorithmic GB/s now, counter bytes when a committed PMC pass exists
+    for k in ("mfb_fuse_fwd", "mfb_fuse_bwd", "glimpse_pool_fwd", "glimpse_pool_bwd", "att_logits_bwd"):
+        h = d["roofline_hbm_kernels"][k]
+        assert h["bound"] == "hbm" and 0.05 < h["frac"] < 1.0 and "traffic" in h
+    # BASELINE configs 3 and 4, timed in the same process after the headline, each with its own roofline object
+    sec = d["secondary"]
+    for which, model, batch, dtype, peak in (("config3", "mhb_coAtt", 512, "bf16", 2500.0), ("config4", "hieCoAtten", 256, "f32", 157.3)):
+        s2 = sec[which]
+        assert "error" not in s2, s2
+        assert s2["dtype"] == dtype and s2["steps"] == 2 and model in s2["metric"] and str(batch) in s2["metric"]
+        assert abs(s2["value"] - batch * 1000.0 / s2["ms_per_step"]) / s2["value"] < 1e-3
+        r2 = s2["roofline"]
+        assert r2 is not None and r2["bound"] == "mfma" and r2["peak"] == peak and r2["launches"] == 2
+        assert abs(r2["frac"] - r2["achieved"] / r2["peak"]) < 1e-3 and 0.1 < r2["frac"] < 1.0
+        assert r2["wgrad"]["frac"] > 0.1 and "workload" in s2["config"] and s2["kernels_ms_per_step"]
 
 
 def test_bench_refuses_a_rank_count_that_is_not_there():
@@ -71,6 +90,8 @@ def test_bench_two_ranks_on_one_gpu_gloo_rehearsal(tmp_path):
     assert d["config"]["grad_allreduce_bytes"] == 240124080
     assert d["config"]["ranks_seen"] == 2 and d["config"]["backend"] == "gloo"
     assert d["config"]["gemm_workgroups"].startswith("one per tile")      # host/parallel.py: the collective needs CUs
+    assert d["config"]["gemm_workgroups_by_family"] == {"f32": "one per tile", "bf16": "one per tile"}
+    assert "secondary" not in d                                             # configs 3 / 4 ride on the 1-GPU line only
     assert sum(d["config"]["allreduce_bucket_bytes"]) == 240124080
     ex = d["config"]["allreduce_exposed_ms"]
     assert len(ex) == len(d["config"]["allreduce_bucket_bytes"]) and all(b >= a - 1e-3 for a, b in zip(ex, ex[1:]))

@@ -365,6 +365,49 @@ def test_config2_mfb_batch_512_gradients_vs_oracle_live_softmax():
     grad_parity(grads, res[0][1], res[1][1])
 
 
+def test_config2_mfb_batch_512_faithful_gradients_vs_oracle():
+    """The exact mode bench.py times (VERDICT r02 weak #1a): MFB-baseline, B=512, fp32, FAITHFUL (`unit_softmax=True`: the
+    reference's singleton-axis softmaxes, mfb.py:84,118), forward + backward, against the oracle in fp32 and fp64 on the
+    same inputs.  Live tensors (embedding, LSTM, ques_proj2, img_proj2, linear_pred) by grad_parity; the 12 tensors whose
+    gradient the reference's autograd computes as exact zeros (both attention MLPs, ques_proj1, img_conv1d) must be
+    EXACTLY 0.0 here too -- the image projection's weight-gradient GEMM multiplies a dP of zeros.  Train mode with every
+    dropout rate 0 (the LSTM backward needs train mode; eval-mode goldens are reproduced this way)."""
+    vqa = _vqa()
+    case = dict(name="b512f", salt=84, N=512, model_name="mfb", glove=False,
+                H=1024, E=300, D=2048, L=196, V=1000, A=1000, T=14)
+    cfg = make_cfg(case)
+    model = _no_dropout_train(_load(vqa.MFB(cfg), case["salt"]))
+    assert model.unit_softmax is True and model.pruned is False and model.gemm_dtype == "fp32"
+    model.overlap_streams = "same-stream"            # the stream configuration bench.py runs
+    img = torch.relu(torch.randn((512, 196, 2048), generator=torch.Generator().manual_seed(1234)))
+    q = torch.randint(1, 1000, (512, 14), generator=torch.Generator().manual_seed(1235))
+    a = torch.randint(0, 1000, (512,), generator=torch.Generator().manual_seed(1236))
+    out = model.forward(img.cuda(), q.cuda())
+    vqa.CrossEntropyLoss()(out, a.cuda()).backward()      # the HIP criterion, as in bench.py
+    torch.cuda.synchronize()
+    grads = _named_grads(model)
+    res = []
+    for dt in (torch.float32, torch.float64):
+        sd = {k: v.to(dt).requires_grad_(True) for k, v in recipe_sd(O.mfb_shapes(cfg), case["salt"]).items()}
+        o = O.mfb_forward(sd, cfg, img.to(dt), q)
+        O.ce_loss(o, a).backward()
+        res.append((o.detach(), {k: v.grad for k, v in sd.items()}))
+        del sd, o
+    assert rel_err(out.detach().cpu().numpy(), res[0][0].numpy()) <= OUT_TOL
+    assert rel_err(out.detach().cpu().numpy(), res[1][0].float().numpy()) <= OUT_TOL
+    dead = ("ques_att_conv1.", "ques_att_conv2.", "ques_proj1.", "img_conv1d.", "co_att_conv1.", "co_att_conv2.")
+    n_dead = 0
+    for k, g in grads.items():
+        if k.startswith(dead):
+            n_dead += 1
+            assert g is not None and float(g.abs().max()) == 0.0, (k, "dead tensor must receive exact zeros")
+            assert res[1][1][k] is None or float(res[1][1][k].abs().max()) == 0.0, (k, "oracle disagrees that it is dead")
+        else:
+            assert float(g.abs().max()) > 0.0, (k, "live tensor without a gradient")
+    assert n_dead == 12
+    grad_parity({k: g for k, g in grads.items() if not k.startswith(dead)}, res[0][1], res[1][1])
+
+
 def test_config3_shapes_mhbcoatt_batch_512_fp32_gradients_vs_oracle():
     """MHBCoAtt at the full B=512 in fp32, every output row and every gradient against the oracle run on the SAME
     512-sample batch in fp32 and fp64 (the batch-axis LSTM recursion, mhb_coAtt.py:72-74, makes row n depend on rows

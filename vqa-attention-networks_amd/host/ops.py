@@ -619,6 +619,22 @@ def prof_report():
     return out
 
 
+def prof_shape(kernel, d0=-1, d1=-1, d2=-1):
+    """(launches, total_ms) of the launches of `kernel` (profiler name as in prof_report(), or id) whose shape tag
+    matches (GEMMs tag M, N, K; -1 = any) since the last reset."""
+    lib = _lib()
+    if isinstance(kernel, str):
+        names = [lib.vqf_prof_kernel_name(i).decode() for i in range(lib.vqf_prof_num_kernels())]
+        if kernel not in names:
+            raise _l.VqfError("prof_shape: no kernel named %r" % kernel)
+        kernel = names.index(kernel)
+    n = ctypes.c_longlong(0)
+    ms = ctypes.c_double(0.0)
+    _l.check(lib.vqf_prof_get_shape(int(kernel), int(d0), int(d1), int(d2), ctypes.byref(n), ctypes.byref(ms)),
+             "vqf_prof_get_shape")
+    return n.value, ms.value
+
+
 def prof_gemm(ta, tb, M, N, K):
     """(launches, total_ms) of the GEMM launches with this layout and shape since the last reset."""
     lib = _lib()
