@@ -75,9 +75,21 @@ const char* vqf_build_info(void);
 #define VQF_OPT_FUSE_LS_BWD 9        /* MFB fusion backward: row splits per sample (1..16), tuning probe */
 #define VQF_OPT_GEMM_CU_LIMIT 10     /* persistent large-tile GEMMs use at most this many CUs (multiple of 8; leaves the rest
                                         of the chip to kernels of other streams); <= 0 or -1 = all */
-#define VQF_OPT_COUNT 11
+#define VQF_OPT_GEMM_F32_EDGE 11      /* 0 = the large-tile fp32 GEMM treats a short last column tile like a full one (A/B) */
+#define VQF_OPT_COUNT 12
 int vqf_set_option(int option, int value, int* previous);
 int vqf_get_option(int option, int* value);
+
+/* Launch counters since the library was loaded (which GEMM kernel family a call was routed to: tests and tools use them
+ * to prove that a shape reached the kernel they mean to check; the fp32 families give bit-identical results, so the
+ * output cannot tell).  VQF_OK or VQF_E_BADARG. */
+#define VQF_STAT_GEMM_F32_TILE128 0  /* csrc/gemm_f32.hip, 128x128 tiles (incl. the batched form)  */
+#define VQF_STAT_GEMM_F32_BIG 1      /* csrc/gemm_f32_big.hip, 256x256 tiles, LDS-DMA              */
+#define VQF_STAT_GEMM_F32_WAVE 2     /* csrc/gemm_f32_wave.hip, one tile per wave (small M)        */
+#define VQF_STAT_GEMM_BF16_TILE128 3 /* csrc/gemm_bf16.hip                                         */
+#define VQF_STAT_GEMM_BF16_BIG 4     /* csrc/gemm_bf16_big.hip                                     */
+#define VQF_STAT_COUNT 5
+int vqf_stat_get(int stat, long long* value);
 
 /* --------------------------------------------------------------------------
  * Dense projections on the fp32 MFMA pipe (v_mfma_f32_32x32x2_f32).

@@ -339,7 +339,9 @@ def test_config3_every_node_of_the_bf16_step_at_batch_512(bf16_mode, monkeypatch
                 assert torch.equal(g, p.grad), (k, "model-level gradient is not this node's gradient, bit for bit")
                 seen_params.add(k)
             elif g is not None:
-                into.setdefault(id(a), []).append(g)
+                # a consumer may take a VIEW of a producer's output (AttHeadFn gets hs and hs.view(N*T, H)): credit the base
+                base = a._base if (a._base is not None and id(a._base) in produced) else a
+                into.setdefault(id(base), []).append(g.reshape(base.shape))
         name = rec["cls"].__name__
         if name == "LinearFn":
             _check_linear(rec, out2, grads, rep)

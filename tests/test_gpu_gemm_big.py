@@ -155,3 +155,75 @@ def test_headline_fp32_weight_gradient_launch_vs_fp64(ops):
     P = ops.gemm(X, W, bias=b)
     refP = _ref64(X, W, 0, 0, b)
     assert _rel(P, refP) <= 2e-6 * max(1.0, np.sqrt(2048) / 8), _rel(P, refP)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# fp32 large-tile kernel (gemm_f32_big.hip): every layout, both launch forms, the short-edge-tile path of round 3
+def _big_launches(ops):
+    return ops.stat("gemm_f32_big")
+
+
+@pytest.mark.parametrize("persist", [1, 0])
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_f32_big_all_layouts_both_launch_forms_vs_fp64(ops, ta, tb, persist):
+    """>= 1024 tiles, K >= 1536, ragged M and N tails, bias + ReLU.  persist = 0 is the one-workgroup-per-tile launch
+    that data-parallel runs use (host/parallel.py): same results as the persistent form, bit for bit."""
+    M, N, K = 8200, 8104, 1536              # 33 x 32 tiles; the last column tile has 168 live columns, the last row tile 8 rows
+    A = _u((K, M) if ta else (M, K), 201)
+    B = _u((K, N) if tb else (N, K), 202, 0.5)
+    bias = _u((N,), 203)
+    ref = _ref64(A, B, ta, tb, bias)
+    tol = 2e-6 * max(1.0, np.sqrt(K) / 8)
+    n0 = _big_launches(ops)
+    with ops.options(gemm_f32_persist=persist):
+        out = ops.gemm(A, B, ta=bool(ta), tb=bool(tb), bias=bias)
+        out_r = ops.gemm(A, B, ta=bool(ta), tb=bool(tb), bias=bias, relu=True)
+    assert _big_launches(ops) == n0 + 2, "shape did not reach gemm_f32_big.hip"
+    assert _rel(out, ref) <= tol, (_rel(out, ref), tol)
+    assert _rel(out_r, torch.relu(ref)) <= tol
+    with ops.options(gemm_f32_big=0):        # the 128x128 kernel accumulates in the same k order: the same bits
+        assert torch.equal(out, ops.gemm(A, B, ta=bool(ta), tb=bool(tb), bias=bias)) and _big_launches(ops) == n0 + 2
+    with ops.options(gemm_f32_persist=1 - persist):
+        assert torch.equal(out, ops.gemm(A, B, ta=bool(ta), tb=bool(tb), bias=bias)), "launch forms differ"
+
+
+@pytest.mark.parametrize("rem", [8, 24, 40, 64, 100, 128, 136, 170, 192, 200])
+def test_gemm_f32_big_short_last_column_tile(ops, rem):
+    """Round 3: a short last column tile of the (0,0) layout is staged in identity order and its waves multiply only the
+    column tiles that hold live columns (1, 2 or 4 per strip, none in an empty strip).  rem = live columns of the last tile
+    (8 = one MFMA tile of strip 0; 136 = the image projection's N = 5000; 200 = no special path); M has a ragged tail too.
+    Checked against fp64, against the same launch with the edge path off, with bias + ReLU, and into a row-strided view."""
+    M, N, K = 16500, 15 * 256 + rem, 1536      # 65 x 16 = 1040 tiles
+    A = torch.relu(_u((M, K), 211, 2.0))
+    B = _u((N, K), 212, 0.05)
+    bias = _u((N,), 213)
+    ref = _ref64(A, B, 0, 0, bias)
+    tol = 2e-6 * max(1.0, np.sqrt(K) / 8)
+    for persist in (1, 0):
+        with ops.options(gemm_f32_persist=persist):
+            n0 = _big_launches(ops)
+            out = ops.gemm(A, B, bias=bias)
+            assert _big_launches(ops) == n0 + 1, "shape did not reach gemm_f32_big.hip"
+            assert _rel(out, ref) <= tol, (rem, persist, _rel(out, ref))
+            with ops.options(gemm_f32_edge=0):
+                assert torch.equal(out, ops.gemm(A, B, bias=bias)), "edge path changed a value (same k order expected)"
+            assert _rel(ops.gemm(A, B, bias=bias, relu=True), torch.relu(ref)) <= tol
+    wide = torch.full((M, N + 7), 3.0, device="cuda")
+    ops.gemm(A, B, bias=bias, out=wide[:, 3:N + 3])
+    assert _rel(wide[:, 3:N + 3], ref) <= tol and bool((wide[:, :3] == 3.0).all()) and bool((wide[:, N + 3:] == 3.0).all())
+
+
+def test_headline_fp32_forward_launch_edge_tiles_bitwise(ops):
+    """The roofline launch itself (M = 100352, N = 5000, K = 2048): with and without the short-edge path, persistent and
+    one workgroup per tile -- four launches, one bit pattern; fp64 on sampled rows."""
+    g = torch.Generator(device="cpu").manual_seed(5)
+    X = torch.relu(torch.randn((512 * 196, 2048), generator=g)).cuda()
+    W = _u((5000, 2048), 223, 0.03)
+    b = _u((5000,), 224)
+    P = ops.gemm(X, W, bias=b)
+    for persist, edge in ((1, 0), (0, 1), (0, 0)):
+        with ops.options(gemm_f32_persist=persist, gemm_f32_edge=edge):
+            assert torch.equal(P, ops.gemm(X, W, bias=b)), (persist, edge)
+    rows = torch.arange(0, 512 * 196, 97, device="cuda")
+    ref = X[rows].double() @ W.double().t() + b.double()
+    assert _rel(P[rows], ref) <= 2e-6 * max(1.0, np.sqrt(2048) / 8)

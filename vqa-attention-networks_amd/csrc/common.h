@@ -50,6 +50,9 @@ extern int g_vqf_prof_on;
 // vqf_set_option.  The launchers read them as plain loads.
 extern int g_vqf_opt[VQF_OPT_COUNT];
 static inline int vqf_opt(int id, int dflt) { const int v = g_vqf_opt[id]; return v < 0 ? dflt : v; }
+// launch counters per GEMM kernel family (VQF_STAT_*, read by vqf_stat_get)
+extern long long g_vqf_stat[VQF_STAT_COUNT];
+static inline void vqf_stat_bump(int id) { __atomic_fetch_add(&g_vqf_stat[id], 1LL, __ATOMIC_RELAXED); }
 void vqf_prof_begin(int id, hipStream_t s);
 void vqf_prof_end(int id, hipStream_t s);
 void vqf_prof_dims(int d0, int d1, int d2);   // shape tag attached to the next launches of this thread

@@ -159,12 +159,23 @@ __device__ __forceinline__ void keep_scale20(const uint8_t* __restrict__ keep, u
     // (e0 % 4 == 0: the window starts at halfword 0 or 4, i.e. at word 0 or 2 of the 12-word stream)
     const uint64_t g0 = (uint64_t)(e0 >> 3);
     const uint4 r0 = philox4x32_10(g0, seed), r1 = philox4x32_10(g0 + 1, seed), r2 = philox4x32_10(g0 + 2, seed);
-    const uint32_t w[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
     const bool hi = (e0 & 4) != 0;
     const uint32_t t16 = thr >> 16;
+    // The 12 words are NAMED VALUES picked by a switch that folds after unrolling, never an array: `hi ? w[k+2] : w[k]` on
+    // an array became a dynamically indexed private array in the LDS-transposed kernels -- 48 bytes of scratch stores and
+    // 40 of loads per thread and row, 1.2 GB of extra HBM writes per backward launch at the headline shape (rocprofv3
+    // WRITE_SIZE 3.30 GB against 2.09 GB of dP + partials; profiles/r03_pmc_fuse.txt).
+    auto word = [&](int i) -> uint32_t {
+      switch (i) {
+        case 0: return r0.x; case 1: return r0.y; case 2: return r0.z; case 3: return r0.w;
+        case 4: return r1.x; case 5: return r1.y; case 6: return r1.z; case 7: return r1.w;
+        case 8: return r2.x; case 9: return r2.y; case 10: return r2.z; default: return r2.w;
+      }
+    };
 #pragma unroll
     for (int k = 0; k < 10; ++k) {
-      const uint32_t x = hi ? w[k + 2] : w[k];
+      const uint32_t lo_w = word(k), hi_w = word(k + 2);
+      const uint32_t x = hi ? hi_w : lo_w;
       sc[2 * k] = (x & 0xFFFFu) >= t16 ? inv_keep : 0.f;
       sc[2 * k + 1] = (x >> 16) >= t16 ? inv_keep : 0.f;
     }
@@ -330,12 +341,14 @@ mfb_fuse_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ dzdr
   }
 }
 
-// Coalesced (LDS-transposed) P / dP access: measured at the headline shape it pays for the fp32 backward only (1.10 ->
-// 0.985 ms: the strided dP stores go away); the forward is unchanged (0.486 vs 0.483 ms without dropout) and the bf16
-// kernels lose occupancy to the extra registers (0.44 -> 0.51 ms).  VQF_FUSE_COAL=0 / 1 forces it off / on everywhere.
-bool fuse_coalesced(bool fp32_backward) {
+// Coalesced (LDS-transposed) P / dP access.  Measured at the headline shape (tools/fuse_bench.py, profiles/r03_fuse_ab.log,
+// dropout 0.1): fp32 forward 0.64 -> 0.50 ms, fp32 backward 1.16 -> 0.89 ms, bf16-P forward 0.43 -> 0.38 ms, bf16 backward
+// 0.576 -> 0.594 ms (direct stays the default there).  Round 2 had measured the forward as a tie and the bf16 kernels as
+// slower: those variants were spilling the Philox words to scratch (see keep_scale20).  Option fuse_coal = 0 / 1 forces it
+// off / on everywhere.
+bool fuse_coalesced(bool dflt) {
   const int v = g_vqf_opt[VQF_OPT_FUSE_COAL];
-  return v < 0 ? fp32_backward : v != 0;
+  return v < 0 ? dflt : v != 0;
 }
 
 int pick_ls_fwd(int N, int L) {
@@ -425,7 +438,7 @@ static int fuse_fwd_impl(const void* P, int p_bf16, const float* pbias, const fl
   const uint32_t thr = (keep || p_drop == 0.f) ? 0u : drop_threshold_host(p_drop);
   const float inv_keep = (keep || p_drop > 0.f) ? 1.0f / (1.0f - p_drop) : 1.0f;
   const int LS = pick_ls_fwd(N, L);
-  const bool coal = fuse_coalesced(false) && ((KP * O) % (p_bf16 ? 8 : 4) == 0);
+  const bool coal = fuse_coalesced(true) && ((KP * O) % (p_bf16 ? 8 : 4) == 0);
 #define VQF_FWD(PT_, CO_)                                                                                             \
   VQF_LAUNCH(KID_MFB_FUSE_FWD, (mfb_fuse_fwd_kernel<PT_, CO_>), dim3(N, LS), dim3(256), 0, (hipStream_t)stream,         \
              (const PT_*)P, pbias, q, cascade, keep, seed, thr, inv_keep, L, O, LS, R, rowssq, zdrop)

@@ -322,6 +322,7 @@ int vqf_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A, int lda, c
   splits = (K + g.kchunk - 1) / g.kchunk;
   if (splits > 1) g.slab = (float*)ws;
   if (g_vqf_prof_on) vqf_prof_dims(M, N, K);
+  vqf_stat_bump(VQF_STAT_GEMM_BF16_TILE128);
   dim3 grid((unsigned)tiles, (unsigned)splits);
   int rc;
   if (!ta && !tb) rc = launch<false, false>(g, grid, s);

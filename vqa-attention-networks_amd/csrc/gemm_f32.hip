@@ -549,6 +549,7 @@ extern "C" int vqf_gemm_f32(int ta, int tb, int M, int N, int K, const float* A,
   dim3 grid((unsigned)tiles, (unsigned)splits);
   const int kid = KID_GEMM_A0B0 + 2 * (ta ? 1 : 0) + (tb ? 1 : 0);
   if (g_vqf_prof_on) vqf_prof_dims(M, N, K);
+  vqf_stat_bump(VQF_STAT_GEMM_F32_TILE128);
   int rc;
   if (!ta && !tb) rc = launch_gemm<false, false>(g, grid, s, kid);
   else if (!ta && tb) rc = launch_gemm<false, true>(g, grid, s, kid);
@@ -580,6 +581,7 @@ extern "C" int vqf_gemm_f32_batched(int ta, int tb, int batch, int M, int N, int
   dim3 grid((unsigned)(g.tiles_m * g.tiles_n), 1, (unsigned)batch);
   hipStream_t s = (hipStream_t)stream;
   const int kid = KID_GEMM_A0B0 + 2 * (ta ? 1 : 0) + (tb ? 1 : 0);
+  vqf_stat_bump(VQF_STAT_GEMM_F32_TILE128);
   if (!ta && !tb) return launch_gemm<false, false>(g, grid, s, kid);
   if (!ta && tb) return launch_gemm<false, true>(g, grid, s, kid);
   if (ta && !tb) return launch_gemm<true, false>(g, grid, s, kid);

@@ -29,6 +29,7 @@
 // Preconditions (else the caller uses gemm_f32.hip): K % 16 == 0, M >= 256, N >= 128, >= 1024 workgroups (tiles x
 // splits), no accumulate flag, 16-byte aligned bases, lda/ldb % 4 == 0, a K-major operand's row extent % 4 == 0.
 #include "common.h"
+#include <algorithm>
 #include <stdlib.h>
 
 namespace {
@@ -53,7 +54,10 @@ constexpr int NG = OP_BYTES / (NT * 16);               // 2 LDS-DMA instructions
 #endif
 constexpr int GROUP_M = VQF_F32BIG_GROUP_M;
 #ifndef VQF_F32BIG_DEFAULT_MODE
-#define VQF_F32BIG_DEFAULT_MODE 2     // loop form when VQF_GEMM_F32_PP is unset (see gemm_f32_big_kernel)
+#define VQF_F32BIG_DEFAULT_MODE 2     // loop form when the option gemm_f32_loop is unset (see k_loop)
+#endif
+#ifndef VQF_F32BIG_ALTMAP
+#define VQF_F32BIG_ALTMAP 1           // wave -> strip map with SIMD partners in different column strips (see gemm_f32_big_kernel)
 #endif
 
 struct BigArgs {
@@ -64,6 +68,10 @@ struct BigArgs {
   int M, N, K, lda, ldb, ldc, flags;
   int tiles_m, tiles_n, kchunk, splits;
   int group_m;           // row tiles per group of the tile order (pick_group_m)
+  // two-phase work order (see gemm_f32_big_kernel): phase 1 walks the column tiles 0 .. tiles_n_full-1 (all of them, or all
+  // but a SHORT last one), phase 2 deals the short edge tiles e = 0 .. tiles_m-1 (column tile tiles_n-1) to the workgroups
+  // (edge_w0 + e % edge_wn) % gridDim.x
+  int tiles_n_full, edge_w0, edge_wn;
 #ifdef VQF_F32BIG_CLOCK
   unsigned long long* dbg;   // diagnostic build only (tools/f32_clock.py): per workgroup and wave half, s_memtime / s_memrealtime stamps
 #endif
@@ -80,16 +88,20 @@ __device__ __forceinline__ int swz(int r) { return CH == 4 ? ((r >> 2) & 3) : ((
 // A K-contiguous B is stored with its columns PERMUTED inside each wave strip of 128 (PERM): LDS row 32 j + c of a strip
 // holds column 4 c + j, so that column tile j of a wave is the set of columns = j (mod 4) and a lane's four column tiles
 // are 16 contiguous output bytes (a K-major B has this property without a permutation: see FragB).
+// `blocked` (bit s = wave strip s of 128 LDS rows): that strip of a PERM operand keeps the IDENTITY order (LDS row 32 j + c =
+// column 32 j + c) -- the short edge strips of the last column tile, whose waves then multiply only the column tiles that hold
+// live columns (see the kernel).
 template <bool T, bool PERM>
 __device__ __forceinline__ void init_src(gfloat* (&q)[NG], const float* base, int ld, int r0, int R, int k0,
-                                         int wave, int lane) {
+                                         int wave, int lane, int blocked = 0) {
 #pragma unroll
   for (int i = 0; i < NG; ++i) {
     if (!T) {
       constexpr int RPW = 1024 / ROW_B;                        // rows per wave copy (1 KB)
       const int rho = i * (8 * RPW) + wave * RPW + lane / CH;  // LDS row
       const int chunk = (lane % CH) ^ swz(rho);                // source chunk that lands on LDS slot lane % CH
-      const int row = PERM ? (rho & ~127) + 4 * (rho & 31) + ((rho >> 5) & 3) : rho;
+      const bool perm = PERM && !((blocked >> (rho >> 7)) & 1);
+      const int row = perm ? (rho & ~127) + 4 * (rho & 31) + ((rho >> 5) & 3) : rho;
       q[i] = (gfloat*)(base + (long long)min(r0 + row, R - 1) * ld + k0 + chunk * 4);
     } else {
       const int k = i * 8 + wave;
@@ -121,7 +133,9 @@ template <bool T>
 struct FragA {                                           // v(i, e): value of row-tile i for step e of this k-step
   f32x4 fc[2];                                           // K-contiguous: [tile] (e in the vector)
   f32x2 ft[4];                                           // K-major: [e] (tile in the vector)
+  template <int NJ = 4>
   __device__ __forceinline__ void load(const char* s, int strip0, int ks, int lane) {
+    if (NJ == 0) return;                                 // a wave without live columns multiplies nothing
     const int r = lane & 31, h = lane >> 5;
     if (T) {
 #pragma unroll
@@ -138,12 +152,15 @@ struct FragA {                                           // v(i, e): value of ro
 template <bool T>
 struct FragB {
   f32x4 f[4];                                            // K-contiguous: [tile] (e in the vector); K-major: [e] (tile in the vector)
+  template <int NJ = 4>                                  // K-contiguous: only the first NJ column tiles are read
   __device__ __forceinline__ void load(const char* s, int strip0, int ks, int lane) {
+    if (NJ == 0) return;
     const int r = lane & 31, h = lane >> 5;
 #pragma unroll
     for (int x = 0; x < 4; ++x)
-      f[x] = T ? *reinterpret_cast<const f32x4*>(s + (8 * ks + 4 * h + x) * 1024 + (strip0 + 4 * r) * 4)
-               : *reinterpret_cast<const f32x4*>(s + (strip0 + 32 * x + r) * ROW_B + (((2 * ks + h) ^ swz(r)) << 4));
+      if (T || x < NJ)
+        f[x] = T ? *reinterpret_cast<const f32x4*>(s + (8 * ks + 4 * h + x) * 1024 + (strip0 + 4 * r) * 4)
+                 : *reinterpret_cast<const f32x4*>(s + (strip0 + 32 * x + r) * ROW_B + (((2 * ks + h) ^ swz(r)) << 4));
   }
   __device__ __forceinline__ float v(int j, int e) const { return T ? f[e][j] : f[j][e]; }
 };
@@ -188,6 +205,39 @@ __device__ __forceinline__ void store_tile(const BigArgs& g, float* C, const f32
   }
 }
 
+// blocked edge strips: accumulator tile (i, j) of a wave whose strip keeps the identity column order holds output column
+// strip column 32 j + cm; only the first nj column tiles were multiplied.  Dword stores: these are the few short edge tiles.
+template <bool TA>
+__device__ __forceinline__ void store_tile_blocked(const BigArgs& g, float* C, const f32x16 (&acc)[2][4], int row0, int col0,
+                                                   int lane, bool relu, bool use_bias, int nj) {
+  const int cm = lane & 31, h = lane >> 5;
+  float bv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int col = col0 + 32 * j + cm;
+    bv[j] = (use_bias && j < nj && col < g.N) ? g.bias[col] : 0.f;
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0) for the biases, as a builtin (see store_tile)
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int rm = (e & 3) + 8 * (e >> 2) + 4 * h;
+      const int row = row0 + (TA ? 2 * rm + i : 32 * i + rm);
+      if (row >= g.M) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = col0 + 32 * j + cm;
+        if (j < nj && col < g.N) {
+          float v = acc[i][j][e] + bv[j];
+          if (relu) v = fmaxf(v, 0.f);
+          C[(long long)row * g.ldc + col] = v;
+        }
+      }
+    }
+  }
+}
+
 __device__ __forceinline__ void wait_copies(int later) {     // all but the 4 * later youngest LDS-DMA copies of this wave have landed
   static_assert(2 * NG == 4 || NSLOT == 2, "the vmcnt immediates below assume 4 copies per thread per slab");
   if (later >= 3)      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
@@ -196,10 +246,24 @@ __device__ __forceinline__ void wait_copies(int later) {     // all but the 4 * 
   else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// the 8 k of one k-step for the wave's 2 x NJ MFMA tiles
+template <bool TA, bool TB, int NJ>
+__device__ __forceinline__ void mma_kstep(const FragA<TA>& fa, const FragB<TB>& fb, f32x16 (&acc)[2][4]) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.v(i, e), fb.v(j, e), acc[i][j], 0, 0, 0);
+}
+
+// K loop of one work item (S slabs), NJ = column tiles this wave multiplies (4; 1 or 2 in a short blocked edge strip; 0 in
+// a strip without live columns: such a wave still copies, waits and synchronises with the others).
 // MODE 0: lockstep loop (one barrier per slab, fragment reads one k-step ahead of the MFMAs; both waves of a SIMD
 //         interleave their MFMAs on the matrix pipe).
-// MODE 1: ping-pong loop of gemm_bf16_big.hip (for A/Bs, VQF_GEMM_F32_PP=1: with 64-cycle MFMAs it is 5 % slower here).
-// MODE 2: the lockstep loop with waves 4-7 HALF A SLAB behind waves 0-3 (VQF_GEMM_F32_PP=2): both halves still share the
+// MODE 1: ping-pong loop of gemm_bf16_big.hip (for A/Bs, gemm_f32_loop = 1: with 64-cycle MFMAs it is 5 % slower here).
+// MODE 2: the lockstep loop with waves 4-7 HALF A SLAB behind waves 0-3 (the default): both halves still share the
 //         matrix pipe of their SIMD, but while one half sits in its per-slab barrier / first fragment reads the other is
 //         in the middle of its MFMAs and takes the whole pipe.  One barrier per slab as before: waves 0-3 execute it at
 //         the START of slab s (after their vmcnt for slab s), waves 4-7 in the MIDDLE of slab s-1 (after lgkmcnt(0) for
@@ -207,73 +271,11 @@ __device__ __forceinline__ void wait_copies(int later) {     // all but the 4 * 
 //         in front of that barrier and every read of slab s comes after it; the slot of slab s-1 is refilled (slab s+4) by
 //         waves 0-3 right behind that barrier and by waves 4-7 at their own slab-s start, in both cases after every read
 //         of slab s-1 (waves 0-3: consumed by MFMAs issued before the barrier; waves 4-7: the lgkmcnt(0) above).
-template <bool TA, bool TB, int MODE>
-__global__ void __launch_bounds__(NT, 2) gemm_f32_big_kernel(const BigArgs g) {
+template <bool TA, bool TB, int MODE, int NJ>
+__device__ __forceinline__ void k_loop(const BigArgs& g, char* smem, int& slot, const int S, gfloat* (&qa)[NG],
+                                       gfloat* (&qb)[NG], f32x16 (&acc)[2][4], const int wave, const int lane,
+                                       const int wr, const int wc, const int late) {
   constexpr bool PP = MODE == 1;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;             // strip rows wr*64 .. +63, strip columns wc*128 .. +127
-  const int late = wave >> 2;                          // waves 4-7: the half that runs behind in the staggered / ping-pong loops
-
-  // ---- PERSISTENT workgroups (one per CU: a tile needs the CU's whole LDS): workgroup b runs work items b, b + gridDim.x,
-  // ... of the order below -- the items the hardware dispatcher would have handed the same XCD (gridDim.x % 8 == 0, or a
-  // single round).  The slab ring runs on across tiles: once a tile's K loop has ended every wave's LDS reads have
-  // returned (they precede the loop's last barrier in every loop form), so each wave issues the NEXT tile's first
-  // NSLOT-1 slabs right behind its own output stores, and the next K loop starts on landed data instead of paying a
-  // workgroup turn-around (7.8 us per 467-us tile of the image projection: tools/f32_clock.py) plus a cold prologue.
-  // ---- work-item order: split index slowest; bijective XCD remap, then groups of GROUP_M row tiles, m fastest
-  const int ntiles = g.tiles_m * g.tiles_n;
-  const int total = ntiles * g.splits;
-  int w = blockIdx.x;
-  int z, m0, n0, kbeg, S;                              // current work item (uniform over the workgroup)
-  gfloat* qa[NG];
-  gfloat* qb[NG];
-  int slot = 0;                                        // ring slot of the current tile's slab 0, then of slab s
-  auto begin_tile = [&]() {                            // locate work item w, issue its first NSLOT-1 slabs
-    z = w / ntiles;
-    int id = w % ntiles;
-    {
-      const int q8 = ntiles / 8, r8 = ntiles % 8, xcd = id % 8, k = id / 8;
-      id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
-    }
-    const int per_group = g.group_m * g.tiles_n;
-    const int grp = id / per_group, in = id % per_group;
-    const int gm0 = grp * g.group_m;
-    const int gsz = min(g.group_m, g.tiles_m - gm0);
-    const int tm = gm0 + in % gsz, tn = in / gsz;
-    m0 = tm * TM; n0 = tn * TN;
-    kbeg = z * g.kchunk;
-    S = (min(g.K, kbeg + g.kchunk) - kbeg) / TK;       // slabs of this split
-    init_src<TA, false>(qa, g.A, g.lda, m0, g.M, kbeg, wave, lane);
-    init_src<TB, true>(qb, g.B, g.ldb, n0, g.N, kbeg, wave, lane);
-    int sl = slot;
-#pragma unroll
-    for (int p = 0; p < NSLOT - 1; ++p) {
-      if (p < S) {
-        stage_operand<TA>(qa, g.lda, smem + sl * SLOT_BYTES, wave);
-        stage_operand<TB>(qb, g.ldb, smem + sl * SLOT_BYTES + OP_BYTES, wave);
-      }
-      sl = (sl + 1 == NSLOT) ? 0 : sl + 1;
-    }
-  };
-  begin_tile();
-  for (;;) {
-#ifdef VQF_F32BIG_CLOCK
-  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
-#endif
-
-  f32x16 acc[2][4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-#ifdef VQF_F32BIG_CLOCK
-  const unsigned long long c1 = __builtin_amdgcn_s_memtime();
-#endif
   if (MODE == 0 || (MODE == 2 && late == 0)) {
     for (int s = 0; s < S; ++s) {
       wait_copies(min(NSLOT - 2, S - 1 - s));          // my copies of slab s; later slabs stay in flight
@@ -282,8 +284,8 @@ __global__ void __launch_bounds__(NT, 2) gemm_f32_big_kernel(const BigArgs g) {
       const char* sB = sA + OP_BYTES;
       FragA<TA> fa[2];                                 // fragment double buffer: reads run one k-step ahead
       FragB<TB> fb[2];
-      fa[0].load(sA, wr * 64, 0, lane);
-      fb[0].load(sB, wc * 128, 0, lane);
+      fa[0].template load<NJ>(sA, wr * 64, 0, lane);
+      fb[0].template load<NJ>(sB, wc * 128, 0, lane);
       if (s + NSLOT - 1 < S) {                         // refill the slot of slab s-1 (its address math hides LDS latency)
         const int sl = (slot == 0) ? NSLOT - 1 : slot - 1;
         stage_operand<TA>(qa, g.lda, smem + sl * SLOT_BYTES, wave);
@@ -292,16 +294,10 @@ __global__ void __launch_bounds__(NT, 2) gemm_f32_big_kernel(const BigArgs g) {
 #pragma unroll
       for (int ks = 0; ks < TK / 8; ++ks) {
         if (ks + 1 < TK / 8) {
-          fa[(ks + 1) & 1].load(sA, wr * 64, ks + 1, lane);
-          fb[(ks + 1) & 1].load(sB, wc * 128, ks + 1, lane);
+          fa[(ks + 1) & 1].template load<NJ>(sA, wr * 64, ks + 1, lane);
+          fb[(ks + 1) & 1].template load<NJ>(sB, wc * 128, ks + 1, lane);
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ks & 1].v(i, e), fb[ks & 1].v(j, e), acc[i][j], 0, 0, 0);
+        mma_kstep<TA, TB, NJ>(fa[ks & 1], fb[ks & 1], acc);
       }
       slot = (slot + 1 == NSLOT) ? 0 : slot + 1;
     }
@@ -315,34 +311,22 @@ __global__ void __launch_bounds__(NT, 2) gemm_f32_big_kernel(const BigArgs g) {
       const char* sB = sA + OP_BYTES;
       FragA<TA> fa[2];
       FragB<TB> fb[2];
-      fa[0].load(sA, wr * 64, 0, lane);
-      fb[0].load(sB, wc * 128, 0, lane);
+      fa[0].template load<NJ>(sA, wr * 64, 0, lane);
+      fb[0].template load<NJ>(sB, wc * 128, 0, lane);
       if (s + NSLOT - 1 < S) {                         // slab s+4 into the slot of slab s-1
         const int sl = (slot == 0) ? NSLOT - 1 : slot - 1;
         stage_operand<TA>(qa, g.lda, smem + sl * SLOT_BYTES, wave);
         stage_operand<TB>(qb, g.ldb, smem + sl * SLOT_BYTES + OP_BYTES, wave);
       }
-      fa[1].load(sA, wr * 64, 1, lane);
-      fb[1].load(sB, wc * 128, 1, lane);
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0].v(i, e), fb[0].v(j, e), acc[i][j], 0, 0, 0);
+      fa[1].template load<NJ>(sA, wr * 64, 1, lane);
+      fb[1].template load<NJ>(sB, wc * 128, 1, lane);
+      mma_kstep<TA, TB, NJ>(fa[0], fb[0], acc);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0): every read of slab s by this wave has returned
       wait_copies(min(s + NSLOT - 1, S - 1) - (s + 1));   // my copies of slab s+1; later slabs stay in flight
       __builtin_amdgcn_s_barrier();                    // pairs with the slab-(s+1) barrier of waves 0-3 (their final one for s = S-1)
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1].v(i, e), fb[1].v(j, e), acc[i][j], 0, 0, 0);
+      mma_kstep<TA, TB, NJ>(fa[1], fb[1], acc);
       slot = (slot + 1 == NSLOT) ? 0 : slot + 1;
     }
   } else {
@@ -359,8 +343,8 @@ __global__ void __launch_bounds__(NT, 2) gemm_f32_big_kernel(const BigArgs g) {
       FragB<TB> fb[2];
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        fb[ks].load(sB, wc * 128, ks, lane);
-        fa[ks].load(sA, wr * 64, ks, lane);
+        fb[ks].template load<NJ>(sB, wc * 128, ks, lane);
+        fa[ks].template load<NJ>(sA, wr * 64, ks, lane);
       }
       if (s + NSLOT - 1 < S) {                         // slab s+4 into the slot of slab s-1
         const int sl = (slot == 0) ? NSLOT - 1 : slot - 1;
@@ -374,15 +358,8 @@ __global__ void __launch_bounds__(NT, 2) gemm_f32_big_kernel(const BigArgs g) {
       // ---------------- M(s) ----------------
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ks].v(i, e), fb[ks].v(j, e), acc[i][j], 0, 0, 0);
+      mma_kstep<TA, TB, NJ>(fa[0], fb[0], acc);
+      mma_kstep<TA, TB, NJ>(fa[1], fb[1], acc);
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
@@ -390,6 +367,123 @@ __global__ void __launch_bounds__(NT, 2) gemm_f32_big_kernel(const BigArgs g) {
     }
     if (!late) __builtin_amdgcn_s_barrier();           // waves 0-3 absorb the barrier waves 4-7 spent on the stagger
   }
+}
+
+// Wave -> strip map: waves 0-3 own the row strips 0-3 of column strip 0, waves 4-7 those of column strip 1, so the two
+// waves that share a SIMD (w and w + 4) sit in DIFFERENT column strips: in a short last column tile (N = 5000: 136 live
+// columns = 128 + 8) every SIMD then hosts one wave with 4 live column tiles and one with 1, instead of two SIMDs doing
+// all of the tile's work while the other two multiply clamped duplicates.
+template <bool TA, bool TB, int MODE>
+__global__ void __launch_bounds__(NT, 2) gemm_f32_big_kernel(const BigArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#if VQF_F32BIG_ALTMAP
+  const int wr = wave & 3, wc = wave >> 2;             // strip rows wr*64 .. +63, strip columns wc*128 .. +127
+#else
+  const int wr = wave >> 1, wc = wave & 1;
+#endif
+  const int late = wave >> 2;                          // waves 4-7: the half that runs behind in the staggered / ping-pong loops
+
+  // ---- PERSISTENT workgroups (one per CU: a tile needs the CU's whole LDS): workgroup b runs work items b, b + gridDim.x,
+  // ... of the order below -- the items the hardware dispatcher would have handed the same XCD (gridDim.x % 8 == 0, or a
+  // single round).  The slab ring runs on across tiles: once a tile's K loop has ended every wave's LDS reads have
+  // returned (they precede the loop's last barrier in every loop form), so each wave issues the NEXT tile's first
+  // NSLOT-1 slabs right behind its own output stores, and the next K loop starts on landed data instead of paying a
+  // workgroup turn-around (7.8 us per 467-us tile of the image projection: tools/f32_clock.py) plus a cold prologue.
+  // ---- work-item order, PHASE 1 (column tiles 0 .. tiles_n_full-1): split index slowest; bijective XCD remap, then groups
+  // of GROUP_M row tiles, m fastest.  PHASE 2 (only when the last column tile is short and the host split it off): its
+  // tiles_m edge tiles cost a fraction of a full tile (see the wave map above), so they are dealt at the end, starting at
+  // the workgroups that drew one full tile fewer in phase 1 (edge_w0, edge_wn: the host picks the deal that minimises
+  // the longest workgroup).
+  const int G = gridDim.x;
+  const int ntiles1 = g.tiles_m * g.tiles_n_full;
+  const int F = ntiles1 * g.splits;                    // phase-1 items
+  const int E = g.tiles_m * (g.tiles_n - g.tiles_n_full);   // phase-2 items
+  int cur_w = blockIdx.x, cur_e;
+  {
+    int r = (int)blockIdx.x - g.edge_w0;
+    if (r < 0) r += G;
+    cur_e = r < g.edge_wn ? r : E;
+  }
+  int z = 0, m0 = 0, n0 = 0, kbeg = 0, S = 0, nj = 4;  // current work item (uniform over the workgroup); nj: this wave's live column tiles
+#ifdef VQF_F32BIG_CLOCK
+  int w_dbg = 0;
+#endif
+  gfloat* qa[NG];
+  gfloat* qb[NG];
+  int slot = 0;                                        // ring slot of the current tile's slab 0, then of slab s
+  auto next_item = [&]() -> bool {                     // locate the next work item, issue its first NSLOT-1 slabs
+    int tm, tn;
+    if (cur_w < F) {
+#ifdef VQF_F32BIG_CLOCK
+      w_dbg = cur_w;
+#endif
+      z = cur_w / ntiles1;
+      int id = cur_w % ntiles1;
+      cur_w += G;
+      {
+        const int q8 = ntiles1 / 8, r8 = ntiles1 % 8, xcd = id % 8, k = id / 8;
+        id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
+      }
+      const int per_group = g.group_m * g.tiles_n_full;
+      const int grp = id / per_group, in = id % per_group;
+      const int gm0 = grp * g.group_m;
+      const int gsz = min(g.group_m, g.tiles_m - gm0);
+      tm = gm0 + in % gsz; tn = in / gsz;
+    } else if (cur_e < E) {
+#ifdef VQF_F32BIG_CLOCK
+      w_dbg = F + cur_e;
+#endif
+      z = 0; tm = cur_e; tn = g.tiles_n - 1;
+      cur_e += g.edge_wn;
+    } else {
+      return false;
+    }
+    m0 = tm * TM; n0 = tn * TN;
+    kbeg = z * g.kchunk;
+    S = (min(g.K, kbeg + g.kchunk) - kbeg) / TK;       // slabs of this split
+    // live columns of the two column strips: a K-contiguous B strip with <= 64 of them is staged in identity order and its
+    // waves multiply 1 or 2 column tiles; a strip without any multiplies nothing
+    const int live0 = g.N - n0, live1 = g.N - n0 - 128;
+    const int blocked = TB ? 0 : ((live0 <= 64 ? 1 : 0) | (live1 <= 64 ? 2 : 0));
+    const int live = wc ? live1 : live0;
+    nj = live <= 0 ? 0 : (TB || live > 64) ? 4 : (live > 32 ? 2 : 1);
+    init_src<TA, false>(qa, g.A, g.lda, m0, g.M, kbeg, wave, lane);
+    init_src<TB, true>(qb, g.B, g.ldb, n0, g.N, kbeg, wave, lane, blocked);
+    int sl = slot;
+#pragma unroll
+    for (int p = 0; p < NSLOT - 1; ++p) {
+      if (p < S) {
+        stage_operand<TA>(qa, g.lda, smem + sl * SLOT_BYTES, wave);
+        stage_operand<TB>(qb, g.ldb, smem + sl * SLOT_BYTES + OP_BYTES, wave);
+      }
+      sl = (sl + 1 == NSLOT) ? 0 : sl + 1;
+    }
+    return true;
+  };
+  if (!next_item()) return;
+  for (;;) {
+#ifdef VQF_F32BIG_CLOCK
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+#ifdef VQF_F32BIG_CLOCK
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+#endif
+  // (wave-uniform branches; a K-major B cannot be re-ordered per strip, so it only knows full and empty strips)
+  if (nj == 4)                k_loop<TA, TB, MODE, 4>(g, smem, slot, S, qa, qb, acc, wave, lane, wr, wc, late);
+  else if (!TB && nj == 2)    k_loop<TA, TB, MODE, 2>(g, smem, slot, S, qa, qb, acc, wave, lane, wr, wc, late);
+  else if (!TB && nj == 1)    k_loop<TA, TB, MODE, 1>(g, smem, slot, S, qa, qb, acc, wave, lane, wr, wc, late);
+  else                        k_loop<TA, TB, MODE, 0>(g, smem, slot, S, qa, qb, acc, wave, lane, wr, wc, late);
 
 #ifdef VQF_F32BIG_CLOCK
   const unsigned long long c2 = __builtin_amdgcn_s_memtime(), r2 = __builtin_amdgcn_s_memrealtime();
@@ -401,24 +495,26 @@ __global__ void __launch_bounds__(NT, 2) gemm_f32_big_kernel(const BigArgs g) {
   const bool vec = (g.N % 4 == 0) && (g.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
                    (!split || (((size_t)g.M * g.N) % 4 == 0));
   const int row0 = m0 + wr * 64, col0 = n0 + wc * 128;
-  if (vec) {
-    if (m0 + TM <= g.M) store_tile<TA, false, true>(g, C, acc, row0, col0, lane, relu, use_bias);
-    else                store_tile<TA, true, true>(g, C, acc, row0, col0, lane, relu, use_bias);
-  } else {
-    store_tile<TA, true, false>(g, C, acc, row0, col0, lane, relu, use_bias);
+  if (nj == 4) {
+    if (vec) {
+      if (m0 + TM <= g.M) store_tile<TA, false, true>(g, C, acc, row0, col0, lane, relu, use_bias);
+      else                store_tile<TA, true, true>(g, C, acc, row0, col0, lane, relu, use_bias);
+    } else {
+      store_tile<TA, true, false>(g, C, acc, row0, col0, lane, relu, use_bias);
+    }
+  } else if (nj > 0) {
+    store_tile_blocked<TA>(g, C, acc, row0, col0, lane, relu, use_bias, nj);
   }
 #ifdef VQF_F32BIG_CLOCK
   if (g.dbg && lane == 0 && (wave & 3) == 0) {         // one record per wave half: [entry, loop start, loop end, stores issued] cycles,
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // [entry, loop end] 100 MHz ticks, slabs; stores landed at the last stamp
     const unsigned long long c3 = __builtin_amdgcn_s_memtime();
-    unsigned long long* d = g.dbg + ((size_t)w * 2 + late) * 8;
+    unsigned long long* d = g.dbg + ((size_t)w_dbg * 2 + late) * 8;
     d[0] = c1 - c0; d[1] = c2 - c1; d[2] = c3 - c2; d[3] = r2 - r0; d[4] = c2 - c0; d[5] = (unsigned long long)S;
     d[6] = r0; d[7] = c0;
   }
 #endif
-  w += gridDim.x;
-  if (w >= total) break;
-  begin_tile();
+  if (!next_item()) break;
   }
 }
 
@@ -457,8 +553,30 @@ int pick_group_m(int tiles_m, int tiles_n, int splits) {
   return best;
 }
 
+// Phase 2 of the work order: which workgroups take the short edge tiles (kernel header).  Costs in eighths of a full tile:
+// a full tile keeps every SIMD busy for 8 units, an edge tile for nj0 + nj1 (one wave of each column strip per SIMD).
+// After phase 1 the first h = F % G workgroups hold one full tile more than the others ("light").  Two deals are priced
+// and the one with the shorter longest workgroup is taken: the light workgroups only, or everybody starting at the first
+// light one.  One workgroup per item (gridDim = F + E): workgroup F + e simply takes edge e.
+void deal_edge_tiles(BigArgs& g, int G) {
+  const int F = g.tiles_m * g.tiles_n_full * g.splits, E = g.tiles_m * (g.tiles_n - g.tiles_n_full);
+  g.edge_w0 = 0; g.edge_wn = G > 0 ? G : 1;
+  if (E == 0) return;
+  if (G >= F + E) { g.edge_w0 = F; g.edge_wn = E; return; }
+  const int rem = g.N - (g.tiles_n - 1) * TN;          // live columns of the edge tile (1 .. 192 here)
+  auto njf = [](int live) { return live <= 0 ? 0 : live > 64 ? 4 : live > 32 ? 2 : 1; };
+  const long long c8 = njf(rem) + njf(rem - 128);
+  const int h = F % G, light = G - h;
+  const long long a = F / G;
+  const long long maxA = std::max(h > 0 ? (a + 1) * 8 : 0LL, a * 8 + ((E + light - 1) / light) * c8);
+  auto cnt = [&](int r) { return E > r ? (long long)((E - r - 1) / G + 1) : 0LL; };
+  const long long maxB = std::max(a * 8 + cnt(0) * c8, h > 0 ? (a + 1) * 8 + cnt(light) * c8 : 0LL);
+  g.edge_w0 = h;
+  g.edge_wn = (maxA <= maxB) ? light : G;
+}
+
 template <bool TA, bool TB>
-int launch(const BigArgs& g, hipStream_t s) {
+int launch(const BigArgs& g_in, hipStream_t s) {
   // > 64 KB of dynamic LDS needs the attribute, once per device and instantiation (common.h)
   static VqfDynLdsFlags attr = {}, attr_pp = {};
   const int lo = vqf_opt(VQF_OPT_GEMM_F32_LOOP, VQF_F32BIG_DEFAULT_MODE);   // A/B switch: 0 lockstep, 1 ping-pong, 2 staggered lockstep
@@ -466,7 +584,7 @@ int launch(const BigArgs& g, hipStream_t s) {
   const int kid = KID_GEMM_A0B0 + 2 * (TA ? 1 : 0) + (TB ? 1 : 0);
   // persistent workgroups: one per CU, each walking its share of the work items (VQF_OPT_GEMM_F32_PERSIST = 0: one
   // workgroup per item, as in round 1); VQF_OPT_GEMM_CU_LIMIT leaves part of the chip to other streams
-  const int total = g.tiles_m * g.tiles_n * g.splits;
+  const int total = g_in.tiles_m * g_in.tiles_n * g_in.splits;
   int nwg = total;
   if (vqf_opt(VQF_OPT_GEMM_F32_PERSIST, 1) != 0) {
     int cus = vqf_cu_count() & ~7;                     // a multiple of 8 keeps every workgroup's items on its own XCD
@@ -475,6 +593,8 @@ int launch(const BigArgs& g, hipStream_t s) {
     if (cus >= 8 && total > cus) nwg = cus;
   }
   const dim3 grid(nwg);
+  BigArgs g = g_in;
+  deal_edge_tiles(g, nwg);
   if (mode == 1) {
     if (int e = vqf_set_dyn_lds(reinterpret_cast<const void*>(&gemm_f32_big_kernel<TA, TB, 1>), SMEM_BIG, attr_pp)) return e;
     VQF_LAUNCH(kid, (gemm_f32_big_kernel<TA, TB, 1>), grid, dim3(NT), SMEM_BIG, s, g);
@@ -540,11 +660,18 @@ int vqf_gemm_f32_big_try(int ta, int tb, int M, int N, int K, const float* A, in
   splits = (K + g.kchunk - 1) / g.kchunk;
   g.splits = splits;
   if (splits > 1) { g.C = (float*)ws; g.ldc = N; }
-  g.group_m = pick_group_m(g.tiles_m, g.tiles_n, splits);
+  // a SHORT last column tile of a K-contiguous B (N = 5000: 136 of 256 columns) is split off into phase 2 of the work order:
+  // its waves multiply only the column tiles that hold live columns (kernel header)
+  const int rem = N % TN;
+  const bool edge_opt = !tb && splits == 1 && g.tiles_n > 1 && rem > 0 && rem <= 192 && vqf_opt(VQF_OPT_GEMM_F32_EDGE, 1) != 0;
+  g.tiles_n_full = edge_opt ? g.tiles_n - 1 : g.tiles_n;
+  g.edge_w0 = 0; g.edge_wn = 1;
+  g.group_m = pick_group_m(g.tiles_m, g.tiles_n_full, splits);
 #ifdef VQF_F32BIG_CLOCK
   g.dbg = (splits == 1 && ws && ws_bytes >= (size_t)tiles * 2 * 8 * 8) ? (unsigned long long*)ws : nullptr;
 #endif
   vqf_prof_dims(M, N, K);
+  vqf_stat_bump(VQF_STAT_GEMM_F32_BIG);
   if (ta) *rc = tb ? launch<true, true>(g, s) : launch<true, false>(g, s);
   else    *rc = tb ? launch<false, true>(g, s) : launch<false, false>(g, s);
   if (*rc == VQF_OK && splits > 1) *rc = vqf_splitk_reduce((const float*)ws, splits, M, N, C, ldc, bias, flags, s);

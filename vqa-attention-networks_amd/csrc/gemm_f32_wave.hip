@@ -265,6 +265,7 @@ int vqf_gemm_f32_wave_try(int ta, int tb, int M, int N, int K, const float* A, i
   if (!wk) return 0;
   g.kpart = (wk == 1) ? K : K / 4;
   vqf_prof_dims(M, N, K);
+  vqf_stat_bump(VQF_STAT_GEMM_F32_WAVE);
   if (wk == 1) *rc = tb ? launch<true, 1>(g, nwg1, s) : launch<false, 1>(g, nwg1, s);
   else         *rc = tb ? launch<true, 4>(g, nwg4, s) : launch<false, 4>(g, nwg4, s);
   return 1;

@@ -6,11 +6,13 @@
 
 int g_vqf_prof_on = 0;
 int g_vqf_opt[VQF_OPT_COUNT];
+long long g_vqf_stat[VQF_STAT_COUNT] = {};
 
 namespace {
 const char* const kOptEnv[VQF_OPT_COUNT] = {
     "VQF_GEMM_F32_PERSIST", "VQF_GEMM_BF16_PERSIST", "VQF_GEMM_F32_PP", "VQF_GEMM_BF16_PP", "VQF_GEMM_F32_BIG",
-    "VQF_GEMM_BF16_BIG", "VQF_GEMM_F32_WAVE", "VQF_FUSE_COAL", "VQF_FUSE_LS", "VQF_FUSE_LS_BWD", "VQF_GEMM_CU_LIMIT"};
+    "VQF_GEMM_BF16_BIG", "VQF_GEMM_F32_WAVE", "VQF_FUSE_COAL", "VQF_FUSE_LS", "VQF_FUSE_LS_BWD", "VQF_GEMM_CU_LIMIT",
+    "VQF_GEMM_F32_EDGE"};
 // the environment is read ONCE, when the library is loaded (command-line A/Bs); never on a launch path
 struct OptInit {
   OptInit() {
@@ -68,6 +70,11 @@ int vqf_set_option(int option, int value, int* previous) {
   if (option < 0 || option >= VQF_OPT_COUNT) return VQF_E_BADARG;
   if (previous) *previous = g_vqf_opt[option];
   g_vqf_opt[option] = value < 0 ? -1 : value;
+  return VQF_OK;
+}
+int vqf_stat_get(int stat, long long* value) {
+  if (stat < 0 || stat >= VQF_STAT_COUNT || !value) return VQF_E_BADARG;
+  *value = __atomic_load_n(&g_vqf_stat[stat], __ATOMIC_RELAXED);
   return VQF_OK;
 }
 int vqf_get_option(int option, int* value) {

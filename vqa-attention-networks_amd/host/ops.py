@@ -67,7 +67,8 @@ def workspace(device, nbytes):
 # ---------------------------------------------------------------------------
 # library options (include/vqa_fusion.h VQF_OPT_*): process-wide launch policy, cached in the library
 OPTIONS = {"gemm_f32_persist": 0, "gemm_bf16_persist": 1, "gemm_f32_loop": 2, "gemm_bf16_loop": 3, "gemm_f32_big": 4,
-           "gemm_bf16_big": 5, "gemm_f32_wave": 6, "fuse_coal": 7, "fuse_ls": 8, "fuse_ls_bwd": 9, "gemm_cu_limit": 10}
+           "gemm_bf16_big": 5, "gemm_f32_wave": 6, "fuse_coal": 7, "fuse_ls": 8, "fuse_ls_bwd": 9, "gemm_cu_limit": 10,
+           "gemm_f32_edge": 11}
 
 
 def set_option(name, value):
@@ -81,6 +82,16 @@ def set_option(name, value):
 def get_option(name):
     v = ctypes.c_int(0)
     _l.check(_lib().vqf_get_option(OPTIONS[name], ctypes.byref(v)), "vqf_get_option(%s)" % name)
+    return v.value
+
+
+STATS = {"gemm_f32_tile128": 0, "gemm_f32_big": 1, "gemm_f32_wave": 2, "gemm_bf16_tile128": 3, "gemm_bf16_big": 4}
+
+
+def stat(name):
+    """Launches routed to a GEMM kernel family since the library was loaded (include/vqa_fusion.h VQF_STAT_*)."""
+    v = ctypes.c_longlong(0)
+    _l.check(_lib().vqf_stat_get(STATS[name], ctypes.byref(v)), "vqf_stat_get(%s)" % name)
     return v.value
 
 
