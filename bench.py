@@ -46,6 +46,9 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 matrix peak 
 HBM_PEAK_GBS = 8000.0
 # algorithmic GEMM FLOPs of one train step per QA pair (SURVEY 8d / BASELINE.md section 4), forward + backward
 STEP_MFLOP_PER_QA = {"mfb": 10034.0, "mhb_coAtt": 9578.0, "hieCoAtten": 1515.0}
+CENSUS_STEPS = 4
+KERNELS_NOTE = ("per-kernel times from %d further UNTIMED steps with every library kernel bracketed by hipEvents; the timed "
+                "region brackets only the dominant GEMM launches (a bracket costs the stream ~6-10 us)" % CENSUS_STEPS)
 
 
 def full_cfg(model_name="mfb"):
@@ -286,13 +289,23 @@ class Workload:
         torch.cuda.empty_cache()
 
 
+def dominant_mnk(model_name, B):
+    """M * N * K of the dominant GEMM of a configuration (image projection; img_emb for HieCoAtten)."""
+    return B * 196 * (512 if model_name == "hieCoAtten" else 5000) * 2048
+
+
 def timed_steps(wl, ops, warmup, steps, fence):
+    """W untimed warm-ups, then EXACTLY `steps` timed steps between fences.  Inside the timed region only the dominant GEMM
+    launches (M * N * K >= half of the image projection's) carry hipEvent brackets: a bracket costs the stream ~6-10 us
+    between two kernels (rocprofv3 kernel trace of r03: 10.4 us gaps between bracketed launches, none between unbracketed
+    ones; ~135 launches per MFB step), so bracketing every kernel would tax the step it measures by ~2 % (13 % for
+    HieCoAtten).  The per-kernel table comes from census_steps() afterwards."""
     for _ in range(warmup):
         wl.step()
     if wl.reducer is not None:
         wl.reducer.timing = True
     ops.prof_reset()
-    ops.prof_enable(True)
+    ops.prof_enable(True, min_mnk=dominant_mnk(wl.name, wl.B) // 2)
     fence()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -301,6 +314,21 @@ def timed_steps(wl, ops, warmup, steps, fence):
     elapsed = time.perf_counter() - t0
     ops.prof_enable(False)
     return elapsed, loss
+
+
+def census_steps(wl, ops, steps, fence):
+    """`steps` further UNTIMED steps with every library kernel bracketed -> {kernel: (launches, total_ms)}."""
+    if wl.reducer is not None:
+        wl.reducer.timing = False
+    ops.prof_reset()
+    ops.prof_enable(True)
+    for _ in range(steps):
+        wl.step()
+    fence()
+    ops.prof_enable(False)
+    rep = ops.prof_report()
+    ops.prof_reset()
+    return rep
 
 
 def kernel_table(rep, steps):
@@ -334,7 +362,6 @@ def secondary_config(vqa_amd, which, dev, steps, warmup):
         torch.cuda.synchronize()
     elapsed, loss = timed_steps(wl, ops, warmup, steps, fence)
     ms = 1e3 * elapsed / steps
-    rep = ops.prof_report()
     if which == "config3":
         M, N, K = B * 196, 5000, 2048
         roof = gemm_roofline(ops, "gemm_bf16", "bf16", M, N, K,
@@ -361,11 +388,12 @@ def secondary_config(vqa_amd, which, dev, steps, warmup):
                 roof["wgrad"] = {k: w[k] for k in ("kernel", "achieved", "frac", "avg_launch_ms", "launches", "traffic", "traffic_source")}
         workload = ("HieCoAtten train step (fwd+CE+bwd+Adam), batch 256, img_size 2048, embed 512, 14 tokens, fp32, "
                     "functional dropout always on (reference behaviour)")
+    rep = census_steps(wl, ops, CENSUS_STEPS, fence)
     out = {"metric": "QA-pairs/sec fwd+bwd, %s batch %d" % (name, B), "value": round(B * steps / elapsed, 2),
            "unit": "QA-pairs/s", "ms_per_step": round(ms, 3), "steps": steps, "warmup": warmup,
            "dtype": "bf16" if dtype != "f32" else "f32", "config": {"workload": workload, "global_batch": B},
            "loss": round(float(loss.item()), 5), "roofline": roof, "step_roofline": step_roofline(name, B, ms, dtype),
-           "kernels_ms_per_step": kernel_table(rep, steps)}
+           "kernels_ms_per_step": kernel_table(rep, CENSUS_STEPS), "kernels_note": KERNELS_NOTE}
     wl.free()
     return out
 
@@ -465,8 +493,8 @@ def main():
                                  "operands": ("in-step launch; in faithful MFB dP is EXACTLY ZERO (singleton-axis "
                                               "softmax): see wgrad_live for random operands")
                                  if (args.model == "mfb" and not args.pruned) else "in-step launch, live operands"}
-    rep = ops.prof_report()
     exposed = reducer.exposed_ms()
+    rep = census_steps(wl, ops, CENSUS_STEPS, fence)
     gemm_wg = reducer.gemm_workgroups()
     if roofline is not None and world == 1 and args.dtype == "f32" and args.model == "mfb" and not args.forward_only:
         n_l, ms_l, red_l = live_wgrad_probe(ops, B, dev)
@@ -480,7 +508,7 @@ def main():
             tr, _, src = pmc_lookup("f32", N, K, M)       # beyond-L2 bytes of this launch from the committed --pmc passes
             if tr is not None:
                 roofline["wgrad_live"].update(traffic=tr, traffic_source=src)
-    kernels = kernel_table(rep, args.steps)
+    kernels = kernel_table(rep, CENSUS_STEPS)
     # secondary roofline: the HBM-bound kernels of the step.  algorithmic bytes per step: fusion fwd reads P (+q) and
     # writes R for the L=196 stage and the final block; bwd reads P, dY, Y and writes dP; the glimpse passes
     # read the image tensor once; att_logits_bwd reads + writes the co-attention hidden layer.  `traffic` = HBM bytes per
@@ -500,7 +528,7 @@ def main():
     if args.model != "hieCoAtten":
         for name, nbytes in alg.items():
             if name in rep and rep[name][1] > 0:
-                ms_step = rep[name][1] / args.steps
+                ms_step = rep[name][1] / CENSUS_STEPS
                 gbs = nbytes / (ms_step * 1e-3) / 1e9
                 pm, src = pmc_kernel_lookup(name) if (args.model == "mfb" and args.dtype == "f32" and B == 512) else (None, None)
                 roofline_hbm[name] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -538,7 +566,7 @@ def main():
             "roofline": roofline,
             "step_roofline": step_roofline(args.model, B, ms_per_step, args.dtype) if not (args.forward_only or args.pruned) else None,
             "roofline_hbm_kernels": roofline_hbm,
-            "kernels_ms_per_step": kernels,
+            "kernels_ms_per_step": kernels, "kernels_note": KERNELS_NOTE,
         }
     headline_default = (args.model == "mfb" and args.dtype == "f32" and B == 512 and not args.pruned
                         and not args.forward_only and not args.miopen_lstm)

@@ -116,6 +116,15 @@ int vqf_gemm_f32(int ta, int tb, int M, int N, int K,
                  float* C, int ldc, const float* bias, int flags,
                  void* ws, size_t ws_bytes, void* stream);
 
+/* The same product with a per-row-group scale in the epilogue:
+ *   C[m,n] = relu?( rowscale[m / rows_per_scale] * sum_k Aop[m,k] Bop[n,k] + bias[n] )
+ * -- the co-attention conv applied to the UN-NORMALISED fusion output R of a sample (mfb.py:105-109: F.normalize, then
+ * co_att_conv1): rowscale = 1 / max(||R_n||, eps), rows_per_scale = L, so the normalised tensor is never written.
+ * Always the 128x128-tile kernel, no split-K, no VQF_GEMM_ACCUM. */
+int vqf_gemm_f32_rowscale(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                          float* C, int ldc, const float* bias, int flags, const float* rowscale, int rows_per_scale,
+                          void* stream);
+
 /* Batched form: for b < batch, C_b = Aop_b * Bop_b^T with A_b = A + b*strideA etc.
  * (element strides).  No bias, no split-K.  Per-sample products of
  * hieCoAtten.py:32,38,41,45,48 and modules.py:65,91,94. */
@@ -168,6 +177,12 @@ int vqf_relu_bwd_f32(const float* dX, const float* Y, int M, int C, float* dXpre
 int vqf_att_logits_fwd(const float* hid, const float* w2, const float* b2,
                        int M, int Hh, int G, float* logits, void* stream);
 
+/* vqf_att_logits_fwd for a hidden layer hid = relu(pre + b1) whose `pre` is LINEAR in the layer's input: additionally
+ * lin[m,g] = sum_{j: hid[m,j] > 0} w2[g,j] * (hid[m,j] - b1[j]), the part of the logit linear in that input.  With it
+ * sum(Y * dY) of F.normalize's backward is sum_g dlogits[m,g] * lin[m,g] (vqf_l2_norm_bwd_coef_lin): no pass over Y, dY. */
+int vqf_att_logits_fwd_lin(const float* hid, const float* w2, const float* b2, const float* b1, int M, int Hh, int G,
+                           float* logits, float* lin, void* stream);
+
 /* Backward of the G-logit head; relu_mask != 0: THROUGH the ReLU that produced hid:
  *   dhid_pre[m,j] = (sum_g dl[m,g] w2[g,j]) * (hid[m,j] > 0  or 1)
  *   dw2[g,j] = sum_m dl[m,g] hid[m,j];  db2[g] = sum_m dl[m,g]
@@ -177,6 +192,11 @@ size_t vqf_att_logits_bwd_ws_bytes(int M, int Hh);
 int vqf_att_logits_bwd(const float* dlogits, const float* hid, const float* w2,
                        int M, int Hh, int G, int relu_mask, float* dhid_pre, float* dw2,
                        float* db2, float* dbias1, void* ws, size_t ws_bytes, void* stream);
+/* Same, with the STORED dhid_pre rows multiplied by rowscale[m / rows_per_scale] (NULL: 1); dbias1 sums the unscaled
+ * values.  For a layer fed by vqf_gemm_f32_rowscale: dW1 = dhid_pre^T R and dR = dhid_pre W1 then need no scaling. */
+int vqf_att_logits_bwd_rowscale(const float* dlogits, const float* hid, const float* w2, const float* rowscale,
+                                int rows_per_scale, int M, int Hh, int G, int relu_mask, float* dhid_pre, float* dw2,
+                                float* db2, float* dbias1, void* ws, size_t ws_bytes, void* stream);
 
 /* wts[n,g,:] = softmax_s(logits[n,:,g])   (unit_softmax != 0: wts == 1, the
  * mfb.py:84,118 singleton-axis softmax);  pooled[n, g*C + c] = sum_s wts[n,g,s] feat[n,s,c].
@@ -239,6 +259,11 @@ int vqf_rowdot(const float* Y, const float* dY, int M, int W, float* rowdot, voi
  *   coefA = inv, coefB = inv * sum_l rowdot   (coefB = 0 when norm <= eps: clamped branch) */
 int vqf_l2_norm_bwd_coef(const float* rowdot, const float* norm, const float* inv,
                          int N, int L, float* coefA, float* coefB, void* stream);
+/* The un-normalised formulation (R handed on without vqf_scale_rows; the consumer scales in its GEMM epilogue and returns
+ * dYs = dY / norm):  dR = dYs - coefB R,  coefB[n] = inv[n]^2 * sum_{l,g} dlogits lin  (0 in the clamped branch),
+ * coefA[n] = unit[n] = 1: call vqf_mfb_fuse_bwd with dY := dYs, Y := R, inv := unit. */
+int vqf_l2_norm_bwd_coef_lin(const float* dlogits, const float* lin, int G, const float* norm, const float* inv, int N,
+                             int L, float* coefA, float* coefB, float* unit, void* stream);
 
 /* Backward of vqf_mfb_fuse_fwd given dY (N*L,O) w.r.t. the NORMALISED output Y
  * and, optionally, dzdrop (N*L,5*O) w.r.t. the zdrop output (NULL: none):
@@ -392,9 +417,13 @@ int vqf_adam_step(const VqfAdamTensor* tensors, int count, double lr, double bet
 
 /* --------------------------------------------------------------------------
  * Opt-in profiler: hipEvent pairs around every kernel launch, on the stream
- * the kernel is launched on.  Off by default (zero overhead).
+ * the kernel is launched on.  Off by default (zero overhead).  An event pair costs the stream
+ * ~6-10 us between two kernels (rocprofv3 kernel trace of bench.py: 10.4 us gaps between bracketed
+ * launches, none between unbracketed ones), so a timed region should bracket only what it reports:
+ * vqf_prof_filter(min_mnk) > 0 restricts the brackets to GEMM launches with M * N * K >= min_mnk.
  */
 void vqf_prof_enable(int on);
+void vqf_prof_filter(long long min_mnk);
 void vqf_prof_reset(void);
 int vqf_prof_num_kernels(void);
 const char* vqf_prof_kernel_name(int id);

@@ -186,8 +186,8 @@ def _check_logsoftmax(rec, out, grads, rep):
 
 
 def _check_att_head(rec, out, grads, rep):
-    x, feat, w1, b1, wm, bm, w2, b2, unit, bf16 = rec["args"]
-    assert wm is None and not unit
+    x, feat, w1, b1, wm, bm, w2, b2, unit, bf16 = rec["args"][:10]
+    assert wm is None and not unit and (len(rec["args"]) < 11 or rec["args"][10] is None)    # no NormLink in the bf16 head
     bf16 = bool(bf16)
     dt = torch.float64
     leaves = {0: _dbl(x, dt), 2: _dbl(w1.reshape(w1.shape[0], -1), dt), 3: _dbl(b1, dt),
@@ -215,8 +215,8 @@ def _check_att_head(rec, out, grads, rep):
 
 
 def _check_img_fuse(rec, out, grads, rep, saved):
-    img, wi, bi, q, keep, seed, p_drop, bf16 = rec["args"]
-    assert bool(bf16) and keep is None and p_drop == 0.0
+    img, wi, bi, q, keep, seed, p_drop, bf16 = rec["args"][:8]
+    assert bool(bf16) and keep is None and p_drop == 0.0 and (len(rec["args"]) < 9 or rec["args"][8] is None)
     N, L, D = img.shape
     img_b, P_k = saved[0], saved[3]                               # saved: (img2d bf16, wi, q, P, Y, norm, inv, keep)
     assert img_b.dtype == torch.bfloat16 and P_k.dtype == torch.bfloat16, "config 3 stores the image grid and P in bf16"

@@ -178,6 +178,48 @@ def test_mfb_unit_softmax_switch_gives_live_attention():
     assert float(model.co_att_conv1.weight.grad.abs().max()) > 0.0
 
 
+@pytest.mark.parametrize("mhb", [False, True])
+def test_fold_norm_equals_materialised_normalisation(mhb):
+    """F.normalize folded into co_att_conv1's GEMM epilogue (functions.NormLink, the default) against the round-2 form that
+    writes fusion_normed and runs the scale / rowdot passes (`fold_norm = False`): same outputs to rounding, and BOTH forms'
+    gradients inside the oracle's conditioning-aware bound.  MFB runs with live softmaxes here so that the co-attention
+    branch carries a gradient (under the reference's singleton softmax it is exactly zero in both forms)."""
+    vqa = _vqa()
+    case = dict((MHBCOATT_CASES if mhb else MFB_CASES)[2])
+    cfg, img, q, glove, hard, soft = mfb_inputs(case, "cuda")
+    model = _no_dropout_train(_load((vqa.MHBCoAtt if mhb else vqa.MFB)(cfg), case["salt"]))
+    if not mhb:
+        model.unit_softmax = False
+    outs = {}
+    for fold in (True, False):
+        model.fold_norm = fold
+        model.zero_grad(set_to_none=True)
+        n_scale = vqa.ops.stat("gemm_f32_tile128")
+        vqa.ops.prof_reset(); vqa.ops.prof_enable(True)
+        out = model.forward(img, q, glove_matrix=glove) if mhb else model.forward(img, q)
+        (torch.nn.KLDivLoss()(out, soft) if mhb else torch.nn.CrossEntropyLoss()(out, hard)).backward()
+        torch.cuda.synchronize()
+        rep = vqa.ops.prof_report(); vqa.ops.prof_enable(False)
+        # the folded form launches scale_rows / rowdot only for the final (N, 1000) blocks, never for the (N*L, 1000) tensor
+        n_final = 2 if mhb else 1
+        assert rep["scale_rows"][0] == (n_final if fold else n_final + 1), rep["scale_rows"]
+        assert rep["rowdot"][0] == (n_final if fold else n_final + 1), rep["rowdot"]
+        outs[fold] = (out.detach().clone(), {k: g.clone() for k, g in _named_grads(model).items()})
+    assert rel_err(outs[True][0].cpu().numpy(), outs[False][0].cpu().numpy()) <= 2e-6
+    if mhb:
+        _, g32, g64 = _oracle_pair(case, True, img, q, glove, soft)
+    else:
+        res = []
+        for dt in (torch.float32, torch.float64):
+            sd = {k: v.to(dt).requires_grad_(True) for k, v in recipe_sd(O.mfb_shapes(cfg), case["salt"]).items()}
+            o = O.mfb_forward(sd, cfg, img.cpu().to(dt), q.cpu(), live_softmax=True)
+            O.ce_loss(o, hard.cpu()).backward()
+            res.append({k: v.grad for k, v in sd.items()})
+        g32, g64 = res
+    for fold in (True, False):
+        grad_parity(outs[fold][1], g32, g64, label="fold_norm=%s %s" % (fold, "mhb_coAtt" if mhb else "mfb live softmax"))
+
+
 def test_full_size_batch_512_by_sample_independence():
     """BASELINE config 2 shapes (B=512, 196x2048, H=1024, T=14): MFB samples are independent, so
     rows of the B=512 GPU result must equal the oracle run on those samples alone; every sample's

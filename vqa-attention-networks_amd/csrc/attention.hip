@@ -24,35 +24,53 @@ namespace {
 constexpr int MAXS = 1024;
 
 // ---- logits[m,g] = hid[m,:] . w[g,:] + b[g]; one wave per row ------------------------------
-template <int G>
+// LIN: hid = relu(pre + b1) with pre LINEAR in the layer's input (the co-attention conv of the un-normalised fusion output,
+// scaled per sample in the GEMM epilogue).  lin[m,g] = sum_j w[g,j] * (hid[m,j] - b1[j]) over the columns with hid > 0 is
+// then the part of the logit that is linear in that input: the backward of F.normalize needs sum(Y * dY) per sample, which
+// equals sum_g dlogits[m,g] * lin[m,g] and so costs no pass over the (N*L, 1000) tensors (vqf_l2_norm_bwd_coef_lin).
+template <int G, bool LIN>
 __global__ void att_logits_fwd_kernel(const float* __restrict__ hid, const float* __restrict__ w2,
-                                      const float* __restrict__ b2, int M, int Hh,
-                                      float* __restrict__ logits) {
+                                      const float* __restrict__ b2, const float* __restrict__ b1, int M, int Hh,
+                                      float* __restrict__ logits, float* __restrict__ lin) {
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= M) return;
   const int lane = threadIdx.x & 63;
   const float* h = hid + (long long)row * Hh;
-  float a[G];
+  float a[G], al[G];
 #pragma unroll
-  for (int g = 0; g < G; ++g) a[g] = 0.f;
-  if ((Hh & 3) == 0 && aligned16_dev(h) && aligned16_dev(w2)) {
+  for (int g = 0; g < G; ++g) { a[g] = 0.f; al[g] = 0.f; }
+  if ((Hh & 3) == 0 && aligned16_dev(h) && aligned16_dev(w2) && (!LIN || aligned16_dev(b1))) {
     for (int c = lane * 4; c < Hh; c += 256) {
       const f32x4 x = *reinterpret_cast<const f32x4*>(h + c);
+      f32x4 xl = x;
+      if (LIN) {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(b1 + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xl[j] = x[j] > 0.f ? x[j] - bb[j] : 0.f;
+      }
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         const f32x4 u = *reinterpret_cast<const f32x4*>(w2 + g * Hh + c);
         a[g] += x[0] * u[0] + x[1] * u[1] + x[2] * u[2] + x[3] * u[3];
+        if (LIN) al[g] += xl[0] * u[0] + xl[1] * u[1] + xl[2] * u[2] + xl[3] * u[3];
       }
     }
   } else {
     for (int c = lane; c < Hh; c += 64)
 #pragma unroll
-      for (int g = 0; g < G; ++g) a[g] += h[c] * w2[g * Hh + c];
+      for (int g = 0; g < G; ++g) {
+        a[g] += h[c] * w2[g * Hh + c];
+        if (LIN) al[g] += (h[c] > 0.f ? h[c] - b1[c] : 0.f) * w2[g * Hh + c];
+      }
   }
 #pragma unroll
   for (int g = 0; g < G; ++g) {
     a[g] = wave_sum(a[g]);
-    if (lane == 0) logits[(long long)G * row + g] = a[g] + b2[g];
+    if (LIN) al[g] = wave_sum(al[g]);
+    if (lane == 0) {
+      logits[(long long)G * row + g] = a[g] + b2[g];
+      if (LIN) lin[(long long)G * row + g] = al[g];
+    }
   }
 }
 
@@ -64,10 +82,13 @@ __global__ void att_logits_fwd_kernel(const float* __restrict__ hid, const float
 //   part[b][(G+1)*Hh + g]  sum_m dl[m,g]
 constexpr int LB_ROWS = 128;
 
+// rowscale != nullptr: the STORED dhid_pre rows are multiplied by rowscale[row / rps] (the per-sample 1/norm of the layer's
+// un-normalised input: its weight gradient and dgrad GEMMs then need no scaling); the bias partial sums stay unscaled.
 template <int G, bool RELU>
 __global__ void att_logits_bwd_kernel(const float* __restrict__ dl, const float* __restrict__ hid,
                                       const float* __restrict__ w2, int M, int Hh,
-                                      float* __restrict__ dhid_pre, float* __restrict__ part) {
+                                      float* __restrict__ dhid_pre, float* __restrict__ part,
+                                      const float* __restrict__ rowscale, int rps) {
   const int r0 = blockIdx.x * LB_ROWS, r1 = min(M, r0 + LB_ROWS);
   const int pw = (G + 1) * Hh + 4;
   float* prow = part + (long long)blockIdx.x * pw;
@@ -82,34 +103,47 @@ __global__ void att_logits_bwd_kernel(const float* __restrict__ dl, const float*
         u[g][j] = j < nc ? w2[g * Hh + c + j] : 0.f;
         s[g][j] = 0.f;
       }
-    for (int r = r0; r < r1; ++r) {
-      float d[G];
+    // RB rows per trip: their loads are issued together (one 16-byte load per row and thread is all a row needs, so a
+    // thread that walks row by row keeps 1 KB per wave in flight: 3.4 TB/s; four rows at a time: see DESIGN)
+    constexpr int RB = 4;
+    for (int rb = r0; rb < r1; rb += RB) {
+      float d[RB][G], x[RB][4], rs[RB];
 #pragma unroll
-      for (int g = 0; g < G; ++g) d[g] = dl[(long long)G * r + g];
-      float x[4] = {0, 0, 0, 0}, gp[4];
-      const float* hp = hid + (long long)r * Hh + c;
-      if (vec) {
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(hp);
-        x[0] = xv[0]; x[1] = xv[1]; x[2] = xv[2]; x[3] = xv[3];
-      } else {
+      for (int q = 0; q < RB; ++q) {
+        const int r = min(rb + q, r1 - 1);               // the tail trip re-reads the last row (its results are not used)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) if (j < nc) x[j] = hp[j];
+        for (int g = 0; g < G; ++g) d[q][g] = dl[(long long)G * r + g];
+        rs[q] = rowscale ? rowscale[r / rps] : 1.0f;
+        const float* hp = hid + (long long)r * Hh + c;
+        if (vec) {
+          const f32x4 xv = *reinterpret_cast<const f32x4*>(hp);
+          x[q][0] = xv[0]; x[q][1] = xv[1]; x[q][2] = xv[2]; x[q][3] = xv[3];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) x[q][j] = j < nc ? hp[j] : 0.f;
+        }
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float t = 0.f;
+      for (int q = 0; q < RB; ++q) {
+        const int r = rb + q;
+        if (r >= r1) break;
+        float gp[4];
 #pragma unroll
-        for (int g = 0; g < G; ++g) { t += d[g] * u[g][j]; s[g][j] += d[g] * x[j]; }
-        gp[j] = (!RELU || x[j] > 0.f) ? t : 0.f;
-        sb[j] += gp[j];
-      }
-      float* o = dhid_pre + (long long)r * Hh + c;
-      if (vec) {
-        f32x4 gv = {gp[0], gp[1], gp[2], gp[3]};
-        *reinterpret_cast<f32x4*>(o) = gv;
-      } else {
+        for (int j = 0; j < 4; ++j) {
+          float t = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) if (j < nc) o[j] = gp[j];
+          for (int g = 0; g < G; ++g) { t += d[q][g] * u[g][j]; s[g][j] += d[q][g] * x[q][j]; }
+          gp[j] = (!RELU || x[q][j] > 0.f) ? t : 0.f;
+          sb[j] += gp[j];
+        }
+        float* o = dhid_pre + (long long)r * Hh + c;
+        if (vec) {
+          f32x4 gv = {gp[0] * rs[q], gp[1] * rs[q], gp[2] * rs[q], gp[3] * rs[q]};
+          *reinterpret_cast<f32x4*>(o) = gv;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) if (j < nc) o[j] = gp[j] * rs[q];
+        }
       }
     }
 #pragma unroll
@@ -290,12 +324,28 @@ int vqf_att_logits_fwd(const float* hid, const float* w2, const float* b2, int M
   if (!hid || !w2 || !b2 || !logits || M <= 0 || Hh <= 0) return VQF_E_BADARG;
   if (G != 1 && G != 2) return VQF_E_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
+  const float* nob1 = nullptr;
+  float* nolin = nullptr;
   if (G == 2)
-    VQF_LAUNCH(KID_ATT_LOGITS_FWD, att_logits_fwd_kernel<2>, dim3((M + 3) / 4), dim3(256), 0, s, hid,
-               w2, b2, M, Hh, logits);
+    VQF_LAUNCH(KID_ATT_LOGITS_FWD, (att_logits_fwd_kernel<2, false>), dim3((M + 3) / 4), dim3(256), 0, s, hid,
+               w2, b2, nob1, M, Hh, logits, nolin);
   else
-    VQF_LAUNCH(KID_ATT_LOGITS_FWD, att_logits_fwd_kernel<1>, dim3((M + 3) / 4), dim3(256), 0, s, hid,
-               w2, b2, M, Hh, logits);
+    VQF_LAUNCH(KID_ATT_LOGITS_FWD, (att_logits_fwd_kernel<1, false>), dim3((M + 3) / 4), dim3(256), 0, s, hid,
+               w2, b2, nob1, M, Hh, logits, nolin);
+  return vqf_last_error();
+}
+
+int vqf_att_logits_fwd_lin(const float* hid, const float* w2, const float* b2, const float* b1, int M, int Hh, int G,
+                           float* logits, float* lin, void* stream) {
+  if (!hid || !w2 || !b2 || !b1 || !logits || !lin || M <= 0 || Hh <= 0) return VQF_E_BADARG;
+  if (G != 1 && G != 2) return VQF_E_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  if (G == 2)
+    VQF_LAUNCH(KID_ATT_LOGITS_FWD, (att_logits_fwd_kernel<2, true>), dim3((M + 3) / 4), dim3(256), 0, s, hid,
+               w2, b2, b1, M, Hh, logits, lin);
+  else
+    VQF_LAUNCH(KID_ATT_LOGITS_FWD, (att_logits_fwd_kernel<1, true>), dim3((M + 3) / 4), dim3(256), 0, s, hid,
+               w2, b2, b1, M, Hh, logits, lin);
   return vqf_last_error();
 }
 
@@ -307,7 +357,14 @@ size_t vqf_att_logits_bwd_ws_bytes(int M, int Hh) {
 int vqf_att_logits_bwd(const float* dlogits, const float* hid, const float* w2, int M, int Hh, int G,
                        int relu_mask, float* dhid_pre, float* dw2, float* db2, float* dbias1,
                        void* ws, size_t ws_bytes, void* stream) {
-  if (!dlogits || !hid || !w2 || !dhid_pre || !dw2 || !db2 || M <= 0 || Hh <= 0)
+  return vqf_att_logits_bwd_rowscale(dlogits, hid, w2, nullptr, 1, M, Hh, G, relu_mask, dhid_pre, dw2, db2, dbias1, ws,
+                                     ws_bytes, stream);
+}
+
+int vqf_att_logits_bwd_rowscale(const float* dlogits, const float* hid, const float* w2, const float* rowscale,
+                                int rows_per_scale, int M, int Hh, int G, int relu_mask, float* dhid_pre, float* dw2,
+                                float* db2, float* dbias1, void* ws, size_t ws_bytes, void* stream) {
+  if (!dlogits || !hid || !w2 || !dhid_pre || !dw2 || !db2 || M <= 0 || Hh <= 0 || rows_per_scale <= 0)
     return VQF_E_BADARG;
   if (G != 1 && G != 2) return VQF_E_UNSUPPORTED;
   if (!ws || ws_bytes < vqf_att_logits_bwd_ws_bytes(M, Hh)) return VQF_E_WORKSPACE;
@@ -318,7 +375,7 @@ int vqf_att_logits_bwd(const float* dlogits, const float* hid, const float* w2, 
   float* red = part + (size_t)nb * pw;     // reduced row [pw]
 #define VQF_LB(G_, R_)                                                                           \
   VQF_LAUNCH(KID_ATT_LOGITS_BWD, (att_logits_bwd_kernel<G_, R_>), dim3(nb), dim3(256), 0, s,     \
-             dlogits, hid, w2, M, Hh, dhid_pre, part)
+             dlogits, hid, w2, M, Hh, dhid_pre, part, rowscale, rows_per_scale)
   if (G == 2) { if (relu_mask) VQF_LB(2, true); else VQF_LB(2, false); }
   else        { if (relu_mask) VQF_LB(1, true); else VQF_LB(1, false); }
 #undef VQF_LB

@@ -53,7 +53,7 @@ static inline int vqf_opt(int id, int dflt) { const int v = g_vqf_opt[id]; retur
 // launch counters per GEMM kernel family (VQF_STAT_*, read by vqf_stat_get)
 extern long long g_vqf_stat[VQF_STAT_COUNT];
 static inline void vqf_stat_bump(int id) { __atomic_fetch_add(&g_vqf_stat[id], 1LL, __ATOMIC_RELAXED); }
-void vqf_prof_begin(int id, hipStream_t s);
+bool vqf_prof_begin(int id, hipStream_t s);   // false: this launch is filtered out (vqf_prof_filter), no events recorded
 void vqf_prof_end(int id, hipStream_t s);
 void vqf_prof_dims(int d0, int d1, int d2);   // shape tag attached to the next launches of this thread
 
@@ -61,9 +61,9 @@ void vqf_prof_dims(int d0, int d1, int d2);   // shape tag attached to the next 
 #define VQF_LAUNCH(id, kern, grid, block, shmem, stream, ...)                      \
   do {                                                                             \
     (void)hipGetLastError(); /* drop stale errors of unrelated earlier calls */    \
-    if (g_vqf_prof_on) vqf_prof_begin((id), (stream));                             \
+    const bool vqf_bracket_ = g_vqf_prof_on && vqf_prof_begin((id), (stream));     \
     hipLaunchKernelGGL(kern, grid, block, shmem, stream, __VA_ARGS__);             \
-    if (g_vqf_prof_on) vqf_prof_end((id), (stream));                               \
+    if (vqf_bracket_) vqf_prof_end((id), (stream));                                \
   } while (0)
 
 // two-stage column reduction (reduce.hip); scratch holds VQF_REDUCE_SPLITS x W floats

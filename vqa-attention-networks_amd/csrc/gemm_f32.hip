@@ -70,6 +70,8 @@ struct GemmArgs {
   int tiles_m, tiles_n;
   int vecA, vecB;          // 16-B vector loads allowed
   long long sA, sB, sC;    // batch strides (grid.z), 0 when not batched
+  const float* rowscale;   // epilogue: C = rowscale[row / rps] * acc + bias (vqf_gemm_f32_rowscale), or nullptr
+  int rps;
 };
 
 // Thread -> (row, k) of its i-th float4 in the K-contiguous ("RK") tile image.  A ds_write_b128
@@ -435,7 +437,7 @@ __global__ void __launch_bounds__(NTHREADS, VQF_GEMM_WAVES_PER_SIMD) gemm_f32_ke
         const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (row < g.M) {
           float* pc = out + (long long)row * ldo + col;
-          float v = acc[i][j][r] + bv;
+          float v = (g.rowscale ? acc[i][j][r] * g.rowscale[row / g.rps] : acc[i][j][r]) + bv;
           if (!to_slab) {
             if (g.flags & VQF_GEMM_ACCUM) v += *pc;
             if (g.flags & VQF_GEMM_RELU) v = fmaxf(v, 0.f);
@@ -500,6 +502,10 @@ extern "C" size_t vqf_gemm_f32_ws_bytes(int ta, int tb, int M, int N, int K) {
   return vqf_gemm_f32_big_ws_bytes(ta, tb, M, N, K);
 }
 
+static int gemm_tile128(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
+                        int ldc, const float* bias, int flags, const float* rowscale, int rps, void* ws, size_t ws_bytes,
+                        hipStream_t s);
+
 extern "C" int vqf_gemm_f32(int ta, int tb, int M, int N, int K, const float* A, int lda,
                             const float* B, int ldb, float* C, int ldc, const float* bias,
                             int flags, void* ws, size_t ws_bytes, void* stream) {
@@ -512,10 +518,28 @@ extern "C" int vqf_gemm_f32(int ta, int tb, int M, int N, int K, const float* A,
     // small-M products (the LSTM's recurrent GEMMs): one tile per wave, no split-K slabs / reduce launch (gemm_f32_wave.hip)
     if (vqf_gemm_f32_wave_try(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, s, &rc)) return rc;
   }
+  return gemm_tile128(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, nullptr, 1, ws, ws_bytes, s);
+}
+
+extern "C" int vqf_gemm_f32_rowscale(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B,
+                                     int ldb, float* C, int ldc, const float* bias, int flags, const float* rowscale,
+                                     int rows_per_scale, void* stream) {
+  if (!A || !B || !C || !rowscale || rows_per_scale <= 0 || M <= 0 || N <= 0 || K <= 0 || lda <= 0 || ldb <= 0 || ldc < N)
+    return VQF_E_BADARG;
+  if (flags & VQF_GEMM_ACCUM) return VQF_E_UNSUPPORTED;
+  return gemm_tile128(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, rowscale, rows_per_scale, nullptr, 0,
+                      (hipStream_t)stream);
+}
+
+// the 128x128-tile kernel of this file (ws == nullptr: no split-K)
+static int gemm_tile128(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
+                        int ldc, const float* bias, int flags, const float* rowscale, int rps, void* ws, size_t ws_bytes,
+                        hipStream_t s) {
   GemmArgs g;
   g.A = A; g.B = B; g.C = C; g.bias = bias; g.slab = nullptr;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.flags = flags;
   g.sA = g.sB = g.sC = 0;
+  g.rowscale = rowscale; g.rps = rps;
   g.tiles_m = (M + BM - 1) / BM;
   g.tiles_n = (N + BN - 1) / BN;
   g.vecA = aligned16(A) && (lda % 4 == 0);
@@ -573,6 +597,7 @@ extern "C" int vqf_gemm_f32_batched(int ta, int tb, int batch, int M, int N, int
   g.A = A; g.B = B; g.C = C; g.bias = nullptr; g.slab = nullptr;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.flags = flags;
   g.sA = strideA; g.sB = strideB; g.sC = strideC;
+  g.rowscale = nullptr; g.rps = 1;
   g.tiles_m = (M + BM - 1) / BM;
   g.tiles_n = (N + BN - 1) / BN;
   g.vecA = aligned16(A) && (lda % 4 == 0) && (strideA % 4 == 0);

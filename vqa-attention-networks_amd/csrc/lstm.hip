@@ -426,7 +426,7 @@ int run_fwd_bf16(const float* xw, const float* w_hh, int S, int B, float* hs, fl
   const long long bh = (long long)B * H;
   dim3 grid(H / UPB);
   (void)hipGetLastError();
-  if (g_vqf_prof_on) { vqf_prof_dims(S, B, H); vqf_prof_begin(KID_LSTM_FWD, s); }
+  const bool bracket = g_vqf_prof_on && (vqf_prof_dims(S, B, H), vqf_prof_begin(KID_LSTM_FWD, s));
   const long long n16 = (long long)(H / UPB) * (H / 32) * 64;
   hipLaunchKernelGGL(pack_w_fwd_bf16_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s, w_hh, H, wf);
   for (int t = 0; t < S; ++t) {
@@ -435,7 +435,7 @@ int run_fwd_bf16(const float* xw, const float* w_hh, int S, int B, float* hs, fl
     hipLaunchKernelGGL(lstm_step_fwd_bf16_kernel<KI>, grid, dim3(64 * FWD_WAVES), 0, s, xw + t * 4 * bh,
                        (const __bf16*)wf, hp, cp, B, hs + t * bh, cs + t * bh, gates + t * 4 * bh, hf[t & 1]);
   }
-  if (g_vqf_prof_on) vqf_prof_end(KID_LSTM_FWD, s);
+  if (bracket) vqf_prof_end(KID_LSTM_FWD, s);
   return vqf_last_error();
 }
 
@@ -452,7 +452,7 @@ int run_bwd_bf16(const float* dhs, const float* gates, const float* cs, const fl
   const long long bh = (long long)B * H;
   dim3 grid(H / UPB);
   (void)hipGetLastError();
-  if (g_vqf_prof_on) { vqf_prof_dims(S, B, H); vqf_prof_begin(KID_LSTM_BWD, s); }
+  const bool bracket = g_vqf_prof_on && (vqf_prof_dims(S, B, H), vqf_prof_begin(KID_LSTM_BWD, s));
   const long long n16 = (long long)(H / UPB) * (4 * H / 32) * 16;
   hipLaunchKernelGGL(pack_w_bwd_bf16_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s, w_hh, H, wb);
   for (int t = S - 1; t >= 0; --t) {
@@ -462,7 +462,7 @@ int run_bwd_bf16(const float* dhs, const float* gates, const float* cs, const fl
                        (const __bf16*)wb, gates + t * 4 * bh, cs + t * bh, cp, dc_carry, B, dgates + t * 4 * bh,
                        gf[t & 1]);
   }
-  if (g_vqf_prof_on) vqf_prof_end(KID_LSTM_BWD, s);
+  if (bracket) vqf_prof_end(KID_LSTM_BWD, s);
   return vqf_last_error();
 }
 
@@ -477,7 +477,7 @@ int run_fwd(const float* xw, const float* w_hh, int S, int B, float* hs, float* 
   const long long bh = (long long)B * H;
   dim3 grid(H / UPB);
   (void)hipGetLastError();
-  if (g_vqf_prof_on) { vqf_prof_dims(S, B, H); vqf_prof_begin(KID_LSTM_FWD, s); }   // one bracket per sequence
+  const bool bracket = g_vqf_prof_on && (vqf_prof_dims(S, B, H), vqf_prof_begin(KID_LSTM_FWD, s));   // one bracket per sequence
   const long long n4 = (long long)(H / UPB) * (H / 16) * 64;
   hipLaunchKernelGGL(pack_w_fwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, w_hh, H, wf);
   for (int t = 0; t < S; ++t) {
@@ -486,7 +486,7 @@ int run_fwd(const float* xw, const float* w_hh, int S, int B, float* hs, float* 
     hipLaunchKernelGGL(lstm_step_fwd_kernel<KI>, grid, dim3(64 * FWD_WAVES), 0, s, xw + t * 4 * bh,
                        (const float*)wf, hp, cp, B, hs + t * bh, cs + t * bh, gates + t * 4 * bh, hf[t & 1]);
   }
-  if (g_vqf_prof_on) vqf_prof_end(KID_LSTM_FWD, s);
+  if (bracket) vqf_prof_end(KID_LSTM_FWD, s);
   return vqf_last_error();
 }
 
@@ -501,7 +501,7 @@ int run_bwd(const float* dhs, const float* gates, const float* cs, const float* 
   const long long bh = (long long)B * H;
   dim3 grid(H / UPB);
   (void)hipGetLastError();
-  if (g_vqf_prof_on) { vqf_prof_dims(S, B, H); vqf_prof_begin(KID_LSTM_BWD, s); }
+  const bool bracket = g_vqf_prof_on && (vqf_prof_dims(S, B, H), vqf_prof_begin(KID_LSTM_BWD, s));
   const long long n4 = (long long)(H / UPB) * (4 * H / 16) * 16;
   hipLaunchKernelGGL(pack_w_bwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, w_hh, H, wb);
   for (int t = S - 1; t >= 0; --t) {
@@ -511,7 +511,7 @@ int run_bwd(const float* dhs, const float* gates, const float* cs, const float* 
                        (const float*)wb, gates + t * 4 * bh, cs + t * bh, cp, dc_carry, B, dgates + t * 4 * bh,
                        gf[t & 1]);
   }
-  if (g_vqf_prof_on) vqf_prof_end(KID_LSTM_BWD, s);
+  if (bracket) vqf_prof_end(KID_LSTM_BWD, s);
   return vqf_last_error();
 }
 

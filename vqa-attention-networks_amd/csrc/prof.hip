@@ -31,6 +31,7 @@ std::vector<Pair> g_pairs;
 std::vector<hipEvent_t> g_free;
 thread_local hipEvent_t t_start = nullptr;
 thread_local int t_dims[3] = {0, 0, 0};
+long long g_min_mnk = 0;     // vqf_prof_filter: bracket only GEMM launches whose M * N * K reaches this (0 = every kernel)
 
 const char* const kNames[KID_COUNT] = {
     "gemm_f32_a0b0(fwd)", "gemm_f32_a0b1(dgrad)", "gemm_f32_a1b0", "gemm_f32_a1b1(wgrad)",
@@ -52,9 +53,14 @@ hipEvent_t get_event() {
 }
 }  // namespace
 
-void vqf_prof_begin(int, hipStream_t s) {
+bool vqf_prof_begin(int id, hipStream_t s) {
+  if (g_min_mnk > 0) {       // an event pair costs the stream ~6-10 us: a timed region brackets its dominant launches only
+    const bool gemm = (id >= KID_GEMM_A0B0 && id <= KID_GEMM_A1B1) || id == KID_GEMM_BF16;   // these tag M, N, K right before the launch
+    if (!gemm || (long long)t_dims[0] * t_dims[1] * t_dims[2] < g_min_mnk) return false;
+  }
   t_start = get_event();
   (void)hipEventRecord(t_start, s);
+  return true;
 }
 void vqf_prof_end(int id, hipStream_t s) {
   hipEvent_t b = get_event();
@@ -88,6 +94,7 @@ const char* vqf_build_info(void) {
          "256x256x32(lds-dma, ping-pong) wave64 philox4x32-10";
 }
 void vqf_prof_enable(int on) { g_vqf_prof_on = on ? 1 : 0; }
+void vqf_prof_filter(long long min_mnk) { g_min_mnk = min_mnk > 0 ? min_mnk : 0; }
 void vqf_prof_reset(void) {
   std::lock_guard<std::mutex> lk(g_mu);
   for (auto& p : g_pairs) { g_free.push_back(p.a); g_free.push_back(p.b); }

@@ -120,6 +120,24 @@ __global__ void l2_group_norm_kernel(const float* __restrict__ rowssq, int N, in
   }
 }
 
+__global__ void l2_norm_bwd_coef_lin_kernel(const float* __restrict__ dl, const float* __restrict__ lin, int G,
+                                            const float* __restrict__ norm, const float* __restrict__ inv, int N, int L,
+                                            float* __restrict__ coefA, float* __restrict__ coefB,
+                                            float* __restrict__ unit) {
+  const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const int lane = threadIdx.x & 63;
+  float a = 0.f;
+  const long long base = (long long)n * L * G;
+  for (int i = lane; i < L * G; i += 64) a += dl[base + i] * lin[base + i];
+  a = wave_sum(a);
+  if (lane == 0) {
+    coefA[n] = 1.0f;
+    unit[n] = 1.0f;
+    coefB[n] = norm[n] > 1e-12f ? inv[n] * inv[n] * a : 0.f;   // clamp_min branch has no projection term
+  }
+}
+
 __global__ void l2_norm_bwd_coef_kernel(const float* __restrict__ rowdot,
                                         const float* __restrict__ norm,
                                         const float* __restrict__ inv, int N, int L,
@@ -224,6 +242,18 @@ int vqf_l2_norm_bwd_coef(const float* rowdot, const float* norm, const float* in
   if (!rowdot || !norm || !inv || !coefA || !coefB || N <= 0 || L <= 0) return VQF_E_BADARG;
   VQF_LAUNCH(KID_L2_BWD_COEF, l2_norm_bwd_coef_kernel, dim3((N + 3) / 4), dim3(256), 0,
              (hipStream_t)stream, rowdot, norm, inv, N, L, coefA, coefB);
+  return vqf_last_error();
+}
+
+// The same coefficients for the UN-NORMALISED formulation (the fusion output R is handed on without the scale pass; the
+// consumer folds 1/norm into its GEMM epilogue and returns dYs = dY / norm):  dR = dYs - coefB * R with
+// coefB = inv^2 * sum(R * dYs), and sum(R * dYs) over a sample = sum_{l,g} dlogits * lin (attention.hip, LIN).
+// coefA = 1 and unit = 1 (the "inv" the fusion backward multiplies its 0.5 / |Y| by).
+int vqf_l2_norm_bwd_coef_lin(const float* dlogits, const float* lin, int G, const float* norm, const float* inv, int N,
+                             int L, float* coefA, float* coefB, float* unit, void* stream) {
+  if (!dlogits || !lin || !norm || !inv || !coefA || !coefB || !unit || N <= 0 || L <= 0 || G <= 0) return VQF_E_BADARG;
+  VQF_LAUNCH(KID_L2_BWD_COEF, l2_norm_bwd_coef_lin_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, dlogits,
+             lin, G, norm, inv, N, L, coefA, coefB, unit);
   return vqf_last_error();
 }
 

@@ -27,6 +27,21 @@ def _bf16_ok(*dims):
     return all(d % 8 == 0 for d in dims)
 
 
+class NormLink:
+    """F.normalize folded into its consumer (mfb.py:105-109: fusion_normed is consumed by co_att_conv1 alone).
+
+    The producer (ImgFuseFn / MfbFuseFn) hands on R, the signed square roots WITHOUT the per-sample 1/norm, and leaves
+    inv = 1 / max(||R_n||, eps) and L here; the consumer (the co-attention AttHeadFn) applies inv in the epilogue of its
+    conv GEMM (vqf_gemm_f32_rowscale), scales its stored hidden-layer gradient by it so that dW1 and the gradient it
+    returns (dYs = dY / norm) need no further pass, and leaves (dlogits, lin) here, from which the producer's backward gets
+    sum(Y * dY) per sample.  Saves the scale_rows pass (forward) and the rowdot pass (backward) over the (N*L, 1000)
+    tensors.  One link per forward call; only valid while the producer's output has exactly this one consumer."""
+    __slots__ = ("inv", "L", "lin")
+
+    def __init__(self):
+        self.inv, self.L, self.lin = None, 0, None
+
+
 class LinearFn(torch.autograd.Function):
     """y = x @ W^T + b  (optionally relu).  x (M,K), W (N,K).
     bf16 (gemm_dtype "bf16-all"): bf16 operands / fp32 accumulate in the forward, the dgrad and the weight gradient
@@ -85,10 +100,22 @@ class AttHeadFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, feat, w1, b1, wm, bm, w2, b2, unit_softmax, bf16=False):
+    def forward(ctx, x, feat, w1, b1, wm, bm, w2, b2, unit_softmax, bf16=False, link=None):
         x = _c(x)
         feat = _c(feat)
         ctx.bf16 = bool(bf16)
+        ctx.link = link if (link is not None and link.inv is not None) else None
+        if ctx.link is not None:
+            # x is the UN-NORMALISED fusion output: 1/norm of the sample goes into the conv GEMM's epilogue, and the logit
+            # kernel also returns the part of each logit that is linear in x (NormLink)
+            if ctx.bf16 or wm is not None or b1 is None:
+                raise ops._l.VqfError("AttHeadFn: a NormLink needs the fp32, single-hidden-layer head with a bias")
+            hid1 = ops.gemm_rowscale(x, _w2d(w1), link.inv, link.L, bias=b1, relu=True)
+            logits, lin = ops.att_logits_fwd_lin(hid1, _w2d(w2), b2, b1)
+            wts, pooled = ops.glimpse_pool_fwd(feat, logits, unit_softmax)
+            ctx.save_for_backward(x, feat, w1, None, w2, hid1, None, wts, lin)
+            ctx.unit = bool(unit_softmax)
+            return pooled
         if ctx.bf16:
             # bf16 operands, fp32 accumulate (BASELINE config 3); K padded to a multiple of 32
             xb, w1b = ops.cast_bf16(x, 32), ops.cast_bf16(_w2d(w1), 32)
@@ -100,16 +127,24 @@ class AttHeadFn(torch.autograd.Function):
         last = hid2 if hid2 is not None else hid1
         logits = ops.att_logits_fwd(last, _w2d(w2), b2)
         wts, pooled = ops.glimpse_pool_fwd(feat, logits, unit_softmax)
-        ctx.save_for_backward(x, feat, w1, wm, w2, hid1, hid2, wts)
+        ctx.save_for_backward(x, feat, w1, wm, w2, hid1, hid2, wts, None)
         ctx.unit = bool(unit_softmax)
         return pooled
 
     @staticmethod
     def backward(ctx, dpooled):
-        x, feat, w1, wm, w2, hid1, hid2, wts = ctx.saved_tensors
+        x, feat, w1, wm, w2, hid1, hid2, wts, lin = ctx.saved_tensors
         dpooled = _c(dpooled)
         need_dfeat = ctx.needs_input_grad[1]
         dlogits, dfeat = ops.glimpse_pool_bwd(dpooled, feat, wts, ctx.unit, need_dfeat)
+        if ctx.link is not None:
+            link = ctx.link
+            d1s, dw2, db2, db1 = ops.att_logits_bwd(dlogits, hid1, _w2d(w2), relu_mask=True, rowscale=link.inv,
+                                                    rows_per_scale=link.L)          # stored rows already times 1/norm
+            link.lin = (dlogits, lin)                                               # -> sum(Y * dY) in the producer's backward
+            dw1 = ops.gemm(d1s, x, ta=True, tb=True).view_as(w1)                    # = dpre^T Y
+            dx = ops.gemm(d1s, _w2d(w1), tb=True) if ctx.needs_input_grad[0] else None   # dYs = dY / norm
+            return dx, dfeat, dw1, db1, None, None, dw2.view_as(w2), db2, None, None, None
         last = hid2 if hid2 is not None else hid1
         dlast_pre, dw2, db2, dblast = ops.att_logits_bwd(dlogits, last, _w2d(w2), relu_mask=True)
         dwm = dbm = None
@@ -131,7 +166,25 @@ class AttHeadFn(torch.autograd.Function):
         else:
             dw1 = ops.gemm(d1_pre, x, ta=True, tb=True).view_as(w1)
             dx = ops.gemm(d1_pre, _w2d(w1), tb=True) if ctx.needs_input_grad[0] else None
-        return dx, dfeat, dw1, db1, dwm, dbm, dw2.view_as(w2), db2, None, None
+        return dx, dfeat, dw1, db1, dwm, dbm, dw2.view_as(w2), db2, None, None, None
+
+
+def _arm_link(link, inv, L):
+    """producer side of a NormLink: publish 1/norm and the row-group size for the consumer's GEMM epilogue"""
+    if link is not None:
+        link.inv, link.L, link.lin = inv, L, None
+    return link
+
+
+def _take_lin(link):
+    """producer's backward: the consumer's (dlogits, lin), exactly once"""
+    if link is None:
+        return None
+    if link.lin is None:
+        raise ops._l.VqfError("NormLink: the fusion output's consumer has not run its backward (the un-normalised output "
+                              "of ImgFuseFn / MfbFuseFn may only feed the co-attention AttHeadFn it was linked to)")
+    lin, link.lin = link.lin, None
+    return lin
 
 
 class ImgFuseFn(torch.autograd.Function):
@@ -145,7 +198,7 @@ class ImgFuseFn(torch.autograd.Function):
     BF16_P = True      # bf16 mode: store P in bf16 when the large-tile GEMM applies (A/B switch)
 
     @staticmethod
-    def forward(ctx, img, wi, bi, q, keep, seed, p_drop, bf16=False):
+    def forward(ctx, img, wi, bi, q, keep, seed, p_drop, bf16=False, link=None):
         img = _c(img)
         q = _c(q)
         N, L, D = img.shape
@@ -163,7 +216,8 @@ class ImgFuseFn(torch.autograd.Function):
                 P = ops.gemm_bf16(img, wb, bias=bi)
         else:
             P = ops.gemm(img.view(N * L, D), wi2, bias=bi)
-        Y, norm, inv, _ = ops.mfb_fuse_fwd(P, q, N, L, O, keep=keep, seed=seed, p_drop=p_drop)
+        Y, norm, inv, _ = ops.mfb_fuse_fwd(P, q, N, L, O, keep=keep, seed=seed, p_drop=p_drop, normalise=link is None)
+        ctx.link = _arm_link(link, inv, L)
         ctx.save_for_backward(img, wi, q, P, Y, norm, inv, keep)
         ctx.seed, ctx.p_drop, ctx.dims = seed, p_drop, (N, L, D, O)
         return Y
@@ -173,12 +227,12 @@ class ImgFuseFn(torch.autograd.Function):
         img, wi, q, P, Y, norm, inv, keep = ctx.saved_tensors
         N, L, D, O = ctx.dims
         dP, dq, _, dbi = ops.mfb_fuse_bwd(_c(dY), Y, norm, inv, P, q, N, L, O, keep=keep, seed=ctx.seed,
-                                          p_drop=ctx.p_drop, want_dbias=True, dp_bf16=ctx.bf16)
+                                          p_drop=ctx.p_drop, want_dbias=True, dp_bf16=ctx.bf16, lin=_take_lin(ctx.link))
         if ctx.bf16:                  # dP already is the bf16 A operand of the weight-gradient GEMM
             dwi = ops.gemm_bf16(dP, img, ta=True, tb=True).view_as(wi)
         else:
             dwi = ops.gemm(dP, img.view(N * L, D), ta=True, tb=True).view_as(wi)   # wgrad, K = N*L
-        return None, dwi, dbi, dq, None, None, None, None
+        return None, dwi, dbi, dq, None, None, None, None, None
 
 
 class ImgProjFn(torch.autograd.Function):
@@ -218,10 +272,12 @@ class MfbFuseFn(torch.autograd.Function):
     """a6: Y = L2norm_n(ssqrt(pool5(dropout((P0 + bias) * q[n])))) for the L regions of each sample."""
 
     @staticmethod
-    def forward(ctx, P0, bi, q, keep, seed, p_drop, N, L):
+    def forward(ctx, P0, bi, q, keep, seed, p_drop, N, L, link=None):
         P0, q = _c(P0), _c(q)
         O = P0.shape[1] // ops.POOL_K
-        Y, norm, inv, _ = ops.mfb_fuse_fwd(P0, q, N, L, O, keep=keep, seed=seed, p_drop=p_drop, pbias=bi)
+        Y, norm, inv, _ = ops.mfb_fuse_fwd(P0, q, N, L, O, keep=keep, seed=seed, p_drop=p_drop, pbias=bi,
+                                           normalise=link is None)
+        ctx.link = _arm_link(link, inv, L)
         ctx.save_for_backward(P0, bi, q, Y, norm, inv, keep)
         ctx.seed, ctx.p_drop, ctx.dims = seed, p_drop, (N, L, O)
         return Y
@@ -231,8 +287,8 @@ class MfbFuseFn(torch.autograd.Function):
         P0, bi, q, Y, norm, inv, keep = ctx.saved_tensors
         N, L, O = ctx.dims
         dP, dq, _, dbi = ops.mfb_fuse_bwd(_c(dY), Y, norm, inv, P0, q, N, L, O, keep=keep, seed=ctx.seed,
-                                          p_drop=ctx.p_drop, want_dbias=True, pbias=bi)
-        return dP, dbi, dq, None, None, None, None, None
+                                          p_drop=ctx.p_drop, want_dbias=True, pbias=bi, lin=_take_lin(ctx.link))
+        return dP, dbi, dq, None, None, None, None, None, None
 
 
 class FinalMfbFn(torch.autograd.Function):

@@ -38,6 +38,7 @@ SIGNATURES = {
     "vqf_stat_get": (c_i, [c_i, ctypes.POINTER(ctypes.c_longlong)]),
     "vqf_gemm_f32_ws_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i]),
     "vqf_gemm_f32": (c_i, [c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_i, c_f, c_i, c_f, c_i, c_p, c_sz, c_p]),
+    "vqf_gemm_f32_rowscale": (c_i, [c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_i, c_f, c_i, c_f, c_i, c_f, c_i, c_p]),
     "vqf_gemm_f32_batched": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, ctypes.c_longlong,
                                    c_f, c_i, ctypes.c_longlong, c_f, c_i, ctypes.c_longlong, c_i, c_p]),
     "vqf_gemm_bf16_ws_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i]),
@@ -48,7 +49,9 @@ SIGNATURES = {
     "vqf_group_reduce_f32": (c_i, [c_f, c_i, c_i, c_i, c_f, c_p]),
     "vqf_relu_bwd_f32": (c_i, [c_f, c_f, c_i, c_i, c_f, c_f, c_p, c_sz, c_p]),
     "vqf_att_logits_fwd": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_p]),
+    "vqf_att_logits_fwd_lin": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_p]),
     "vqf_att_logits_bwd_ws_bytes": (c_sz, [c_i, c_i]),
+    "vqf_att_logits_bwd_rowscale": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_p, c_sz, c_p]),
     "vqf_att_logits_bwd": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_p, c_sz, c_p]),
     "vqf_glimpse_pool_fwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_p]),
     "vqf_glimpse_pool_bwd": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_p]),
@@ -66,6 +69,7 @@ SIGNATURES = {
     "vqf_scale_rows": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f, c_p]),
     "vqf_rowdot": (c_i, [c_f, c_f, c_i, c_i, c_f, c_p]),
     "vqf_l2_norm_bwd_coef": (c_i, [c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_p]),
+    "vqf_l2_norm_bwd_coef_lin": (c_i, [c_f, c_f, c_i, c_f, c_f, c_i, c_i, c_f, c_f, c_f, c_p]),
     "vqf_mfb_fuse_bwd_ws_bytes": (c_sz, [c_i, c_i, c_i]),
     "vqf_mfb_fuse_bwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_u64, ctypes.c_float,
                                c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_p, c_sz, c_p]),
@@ -92,6 +96,7 @@ SIGNATURES = {
     "vqf_adam_step": (c_i, [c_p, c_i, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                             ctypes.c_double, ctypes.c_longlong, c_p]),
     "vqf_prof_enable": (None, [c_i]),
+    "vqf_prof_filter": (None, [ctypes.c_longlong]),
     "vqf_prof_reset": (None, []),
     "vqf_prof_num_kernels": (c_i, []),
     "vqf_prof_kernel_name": (ctypes.c_char_p, [c_i]),

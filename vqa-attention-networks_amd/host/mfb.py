@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from .functions import (LinearFn, AttHeadFn, ImgFuseFn, ImgProjFn, MfbFuseFn, FinalMfbFn, LstmBatchFn, UnitPoolFn,
-                        DeadParamsFn)
+                        DeadParamsFn, NormLink)
 
 
 def _image_is_data(img, gemm_dtype="fp32"):
@@ -169,6 +169,10 @@ class MFB(nn.Module):
         # bf16 mode: one autograd node for projection + fusion, whose backward writes dP in bf16 for the
         # weight-gradient GEMM (no 2 GB fp32 round trip, no cast pass); takes precedence over the overlap
         self.fuse_bf16_dp = True
+        # F.normalize (mfb.py:105) folded into co_att_conv1's GEMM epilogue: fusion_normed is never written and neither the
+        # scale pass nor the sum(Y * dY) pass of its backward runs (functions.NormLink).  fp32 co-attention, single hidden
+        # layer only; False materialises fusion_normed as round 2 did
+        self.fold_norm = True
         self._side = _SideStream()
         self._seeds = _DropSeeds()
 
@@ -230,17 +234,19 @@ class MFB(nn.Module):
         pm = self.dropout_m.p
         seed, p = self._seeds.next(self.training, pm)
         k1 = keep.get('m1')
+        coatt_bf16 = self.gemm_dtype in ("bf16", "bf16-att", "bf16-all")
+        link = NormLink() if (self.fold_norm and not self.multilayer and not coatt_bf16) else None
         if proj is not None:
             P0 = self._side.join(*proj)
-            Y = MfbFuseFn.apply(P0, self.img_conv1d.bias, qp, k1, seed, pm if k1 is not None else p, N, L)
+            Y = MfbFuseFn.apply(P0, self.img_conv1d.bias, qp, k1, seed, pm if k1 is not None else p, N, L, link)
         else:
             Y = ImgFuseFn.apply(img_features, self.img_conv1d.weight, self.img_conv1d.bias, qp,
-                                k1, seed, pm if k1 is not None else p, bf16_img)
+                                k1, seed, pm if k1 is not None else p, bf16_img, link)
         # a7+a8: co-attention over the regions                               mfb.py:109-123
+        # (with a link Y is the un-normalised R and 1/norm rides in co_att_conv1's GEMM epilogue)
         wm, bm = self._mc('co_att_multiconv')
         va = AttHeadFn.apply(Y, img_features, self.co_att_conv1.weight, self.co_att_conv1.bias, wm, bm,
-                             self.co_att_conv2.weight, self.co_att_conv2.bias, self.unit_softmax,
-                             self.gemm_dtype in ("bf16", "bf16-att", "bf16-all"))
+                             self.co_att_conv2.weight, self.co_att_conv2.bias, self.unit_softmax, coatt_bf16, link)
         # a9: final MFB block                                                mfb.py:126-135
         seed, p = self._seeds.next(self.training, pm)
         k2 = keep.get('m2')

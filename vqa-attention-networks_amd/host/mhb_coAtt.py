@@ -8,7 +8,8 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .functions import LinearFn, AttHeadFn, ImgFuseFn, MfbFuseFn, FinalMfbFn, LstmSeqFn, LstmBatchFn, LogSoftmaxRowsFn
+from .functions import (LinearFn, AttHeadFn, ImgFuseFn, MfbFuseFn, FinalMfbFn, LstmSeqFn, LstmBatchFn, LogSoftmaxRowsFn,
+                        NormLink)
 from .mfb import _DropSeeds, _image_is_data, _SideStream, _lstm_bf16, batch_first_lstm, warn_once
 
 
@@ -40,6 +41,7 @@ class MHBCoAtt(nn.Module):
         self.use_hip_lstm = True
         self.overlap_streams = True       # img_conv1d on a side stream, see MFB.overlap_streams
         self.fuse_bf16_dp = True          # see MFB.fuse_bf16_dp
+        self.fold_norm = True             # see MFB.fold_norm
         self._side = _SideStream()
         self._seeds = _DropSeeds()
 
@@ -90,15 +92,16 @@ class MHBCoAtt(nn.Module):
         pm = self.dropout_m.p
         seed, p = self._seeds.next(self.training, pm)
         k1 = keep.get('m1')
+        coatt_bf16 = self.gemm_dtype in ("bf16", "bf16-att", "bf16-all")
+        link = NormLink() if (self.fold_norm and not coatt_bf16) else None
         if proj is not None:
             P0 = self._side.join(*proj)
-            Y = MfbFuseFn.apply(P0, self.img_conv1d.bias, qp, k1, seed, pm if k1 is not None else p, N, L)
+            Y = MfbFuseFn.apply(P0, self.img_conv1d.bias, qp, k1, seed, pm if k1 is not None else p, N, L, link)
         else:
             Y = ImgFuseFn.apply(img_features, self.img_conv1d.weight, self.img_conv1d.bias, qp,
-                                k1, seed, pm if k1 is not None else p, bf16_img)
+                                k1, seed, pm if k1 is not None else p, bf16_img, link)
         va = AttHeadFn.apply(Y, img_features, self.co_att_conv1.weight, self.co_att_conv1.bias, None, None,
-                             self.co_att_conv2.weight, self.co_att_conv2.bias, False,
-                             self.gemm_dtype in ("bf16", "bf16-att", "bf16-all"))
+                             self.co_att_conv2.weight, self.co_att_conv2.bias, False, coatt_bf16, link)
         ys = []
         for tag, qpj, ipj in (('m2', self.ques_proj2, self.img_proj2), ('m3', self.ques_proj3, self.img_proj3)):
             seed, p = self._seeds.next(self.training, pm)

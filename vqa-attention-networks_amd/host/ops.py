@@ -148,6 +148,21 @@ def gemm(a, b, ta=False, tb=False, bias=None, relu=False, out=None, accumulate=F
     return out
 
 
+def gemm_rowscale(a, b, rowscale, rows_per_scale, bias=None, relu=False):
+    """C = relu?(rowscale[m // rows_per_scale] * (a @ b^T) + bias): a (M,K), b (N,K) fp32; the 128x128-tile kernel with the
+    per-sample scale in its epilogue (the co-attention conv on the un-normalised fusion output)."""
+    _chk(a, b, rowscale, bias)
+    M, K = a.shape
+    N = b.shape[0]
+    if b.shape[1] != K or rowscale.numel() * rows_per_scale < M:
+        raise _l.VqfError("gemm_rowscale: shape mismatch")
+    out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    _l.check(_lib().vqf_gemm_f32_rowscale(0, 0, M, N, K, _ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(out), N,
+                                          _ptr(bias), GEMM_RELU if relu else 0, _ptr(rowscale), int(rows_per_scale),
+                                          _stream()), "vqf_gemm_f32_rowscale")
+    return out
+
+
 def _chk_bf16(*ts):
     for t in ts:
         if not t.is_cuda or t.dtype != torch.bfloat16 or t.stride(-1) != 1:
@@ -247,8 +262,22 @@ def att_logits_fwd(hid, w2, b2):
     return out
 
 
-def att_logits_bwd(dlogits, hid, w2, relu_mask=True):
-    _chk(dlogits, hid, w2)
+def att_logits_fwd_lin(hid, w2, b2, b1):
+    """-> (logits (M,G), lin (M,G)): lin = the part of the logit that is linear in the input of the ReLU layer in front
+    (include/vqa_fusion.h vqf_att_logits_fwd_lin)."""
+    _chk(hid, w2, b2, b1)
+    M, Hh = hid.shape
+    G = w2.shape[0]
+    out = torch.empty((M, G), dtype=torch.float32, device=hid.device)
+    lin = torch.empty((M, G), dtype=torch.float32, device=hid.device)
+    _l.check(_lib().vqf_att_logits_fwd_lin(_ptr(hid), _ptr(w2), _ptr(b2), _ptr(b1), M, Hh, G, _ptr(out), _ptr(lin),
+                                           _stream()), "vqf_att_logits_fwd_lin")
+    return out, lin
+
+
+def att_logits_bwd(dlogits, hid, w2, relu_mask=True, rowscale=None, rows_per_scale=1):
+    """rowscale (per row group of rows_per_scale rows): the stored dhid_pre is scaled by it, the bias sums are not."""
+    _chk(dlogits, hid, w2, rowscale)
     M, Hh = hid.shape
     G = w2.shape[0]
     dpre = torch.empty_like(hid)
@@ -256,9 +285,9 @@ def att_logits_bwd(dlogits, hid, w2, relu_mask=True):
     db2 = torch.empty(G, dtype=torch.float32, device=hid.device)
     db1 = torch.empty(Hh, dtype=torch.float32, device=hid.device)
     ws = workspace(hid.device, _lib().vqf_att_logits_bwd_ws_bytes(M, Hh))
-    _l.check(_lib().vqf_att_logits_bwd(_ptr(dlogits), _ptr(hid), _ptr(w2), M, Hh, G, int(bool(relu_mask)),
-                                       _ptr(dpre), _ptr(dw2), _ptr(db2), _ptr(db1), _ptr(ws), ws.numel(),
-                                       _stream()), "vqf_att_logits_bwd")
+    _l.check(_lib().vqf_att_logits_bwd_rowscale(_ptr(dlogits), _ptr(hid), _ptr(w2), _ptr(rowscale), int(rows_per_scale),
+                                                M, Hh, G, int(bool(relu_mask)), _ptr(dpre), _ptr(dw2), _ptr(db2), _ptr(db1),
+                                                _ptr(ws), ws.numel(), _stream()), "vqf_att_logits_bwd")
     return dpre, dw2, db2, db1
 
 
@@ -364,9 +393,11 @@ def _keep_ptr(keep):
     return ctypes.c_void_p(keep.data_ptr())
 
 
-def mfb_fuse_fwd(P, q, N, L, O, keep=None, seed=0, p_drop=0.0, cascade=None, want_zdrop=False, pbias=None):
+def mfb_fuse_fwd(P, q, N, L, O, keep=None, seed=0, p_drop=0.0, cascade=None, want_zdrop=False, pbias=None,
+                 normalise=True):
     """-> (Y normalised (N*L,O), norm (N), inv (N), zdrop or None).  pbias: projection bias added on load.
-    P may be bf16 (written by gemm_bf16(out_bf16=True))."""
+    P may be bf16 (written by gemm_bf16(out_bf16=True)).  normalise=False: the first output is R, the signed square roots
+    WITHOUT the per-sample 1/norm (no vqf_scale_rows pass: the consumer applies inv in its GEMM epilogue)."""
     (_chk_bf16 if P.dtype == torch.bfloat16 else _chk)(P)
     _chk(q, cascade, pbias)
     dev = P.device
@@ -386,24 +417,36 @@ def mfb_fuse_fwd(P, q, N, L, O, keep=None, seed=0, p_drop=0.0, cascade=None, wan
     inv = torch.empty(N, dtype=torch.float32, device=dev)
     _l.check(_lib().vqf_l2_group_norm(_ptr(rowssq), N, L, _ptr(norm), _ptr(inv), _stream()),
              "vqf_l2_group_norm")
-    _l.check(_lib().vqf_scale_rows(_ptr(R), _ptr(inv), N * L, L, O, _ptr(R), _stream()), "vqf_scale_rows")
+    if normalise:
+        _l.check(_lib().vqf_scale_rows(_ptr(R), _ptr(inv), N * L, L, O, _ptr(R), _stream()), "vqf_scale_rows")
     return R, norm, inv, zdrop
 
 
 def mfb_fuse_bwd(dY, Y, norm, inv, P, q, N, L, O, keep=None, seed=0, p_drop=0.0, cascade=None,
-                 want_dbias=False, dzdrop=None, pbias=None, dp_bf16=False):
-    """-> (dP (N*L,5O) fp32 | bf16, dq (N,5O), dcascade or None, dbiasP or None)."""
+                 want_dbias=False, dzdrop=None, pbias=None, dp_bf16=False, lin=None):
+    """-> (dP (N*L,5O) fp32 | bf16, dq (N,5O), dcascade or None, dbiasP or None).
+    lin = (dlogits, lin) of the consumer's attention head: the UN-NORMALISED formulation -- Y is R (mfb_fuse_fwd(normalise=
+    False)), dY is dYs = dY / norm, and sum(R * dYs) per sample comes from the head's (N*L, G) tensors instead of a
+    rowdot pass over the (N*L, O) ones (vqf_l2_norm_bwd_coef_lin)."""
     (_chk_bf16 if P.dtype == torch.bfloat16 else _chk)(P)
     _chk(dY, Y, norm, inv, q, cascade, dzdrop, pbias)
     if P.dtype == torch.bfloat16 and not dp_bf16:
         raise _l.VqfError("mfb_fuse_bwd: a bf16 P comes with a bf16 dP")
     dev = P.device
-    rowdot = torch.empty(N * L, dtype=torch.float32, device=dev)
-    _l.check(_lib().vqf_rowdot(_ptr(Y), _ptr(dY), N * L, O, _ptr(rowdot), _stream()), "vqf_rowdot")
     cA = torch.empty(N, dtype=torch.float32, device=dev)
     cB = torch.empty(N, dtype=torch.float32, device=dev)
-    _l.check(_lib().vqf_l2_norm_bwd_coef(_ptr(rowdot), _ptr(norm), _ptr(inv), N, L, _ptr(cA), _ptr(cB),
-                                         _stream()), "vqf_l2_norm_bwd_coef")
+    if lin is not None:
+        dl, ln = lin
+        _chk(dl, ln)
+        unit = torch.empty(N, dtype=torch.float32, device=dev)
+        _l.check(_lib().vqf_l2_norm_bwd_coef_lin(_ptr(dl), _ptr(ln), dl.shape[1], _ptr(norm), _ptr(inv), N, L, _ptr(cA),
+                                                 _ptr(cB), _ptr(unit), _stream()), "vqf_l2_norm_bwd_coef_lin")
+        inv = unit
+    else:
+        rowdot = torch.empty(N * L, dtype=torch.float32, device=dev)
+        _l.check(_lib().vqf_rowdot(_ptr(Y), _ptr(dY), N * L, O, _ptr(rowdot), _stream()), "vqf_rowdot")
+        _l.check(_lib().vqf_l2_norm_bwd_coef(_ptr(rowdot), _ptr(norm), _ptr(inv), N, L, _ptr(cA), _ptr(cB),
+                                             _stream()), "vqf_l2_norm_bwd_coef")
     dq = torch.empty((N, POOL_K * O), dtype=torch.float32, device=dev)
     db = torch.empty(POOL_K * O, dtype=torch.float32, device=dev) if want_dbias else None
     ws = workspace(dev, _lib().vqf_mfb_fuse_bwd_ws_bytes(N, L, O))
@@ -609,7 +652,10 @@ def adam_step(params, grads, exp_avgs, exp_avg_sqs, step, lr, beta1=0.9, beta2=0
 
 
 # ---------------------------------------------------------------------------
-def prof_enable(on=True):
+def prof_enable(on=True, min_mnk=0):
+    """hipEvent brackets around the library's launches.  min_mnk > 0: only GEMM launches with M * N * K >= min_mnk (an
+    event pair costs the stream ~6-10 us between two kernels, so a timed region brackets its dominant launches only)."""
+    _lib().vqf_prof_filter(int(min_mnk))
     _lib().vqf_prof_enable(int(on))
 
 
