@@ -47,6 +47,7 @@ HBM_PEAK_GBS = 8000.0
 # algorithmic GEMM FLOPs of one train step per QA pair (SURVEY 8d / BASELINE.md section 4), forward + backward
 STEP_MFLOP_PER_QA = {"mfb": 10034.0, "mhb_coAtt": 9578.0, "hieCoAtten": 1515.0}
 CENSUS_STEPS = 4
+C3_SIDE_CUS = 128
 KERNELS_NOTE = ("per-kernel times from %d further UNTIMED steps with every library kernel bracketed by hipEvents; the timed "
                 "region brackets only the dominant GEMM launches (a bracket costs the stream ~6-10 us)" % CENSUS_STEPS)
 
@@ -251,6 +252,12 @@ class Workload:
             "one compute stream (projection its own node, weight gradient last)")
         if hasattr(model, "overlap_streams"):              # the SAME configuration at every N
             model.overlap_streams = False if no_overlap else (True if overlap else "same-stream")
+            if args is not None and overlap:
+                model.side_bf16 = bool(args.side_bf16)
+                model.side_cu_limit = int(args.side_cu_limit)
+                if args.side_bf16 or args.side_cu_limit:
+                    self.stream_mode += " (bf16 projection on the side stream: %s; its GEMMs on <= %s CUs)" % (
+                        bool(args.side_bf16), args.side_cu_limit or "all")
         self.model = model
         # solver.py:25-29: criterion + Adam, both on the HIP path (host/train_step.py)
         self.opt = vqa_amd.Adam(model.parameters(), lr=7e-4)
@@ -354,15 +361,24 @@ def secondary_config(vqa_amd, which, dev, steps, warmup):
     ops = vqa_amd.ops
     if which == "config3":
         name, dtype, B = "mhb_coAtt", "bf16", 512
+    elif which == "config3_all":
+        name, dtype, B = "mhb_coAtt", "bf16-all", 512
     else:
         name, dtype, B = "hieCoAtten", "f32", 256
     wl = Workload(vqa_amd, name, dtype, B, 0, dev)
+    if name == "mhb_coAtt":
+        # The 512-step batch-axis LSTM recursion (4.7 ms of latency-bound 4-us kernels) leaves the chip idle: the image
+        # projection and its weight gradient run beside it on a second stream, their persistent GEMMs confined to 128
+        # CUs so that the recursion's workgroups find free CUs (tools/c3_side_sweep*.sh: 15.8 -> 14.0 ms; 144 / 112 CUs 14.7 / 14.2)
+        wl.model.overlap_streams, wl.model.side_bf16, wl.model.side_cu_limit = True, True, C3_SIDE_CUS
+        wl.stream_mode = ("two streams: image projection + its weight gradient beside the LSTM recursion, persistent GEMMs on "
+                          "<= %d CUs" % C3_SIDE_CUS)
 
     def fence():
         torch.cuda.synchronize()
     elapsed, loss = timed_steps(wl, ops, warmup, steps, fence)
     ms = 1e3 * elapsed / steps
-    if which == "config3":
+    if name == "mhb_coAtt":
         M, N, K = B * 196, 5000, 2048
         roof = gemm_roofline(ops, "gemm_bf16", "bf16", M, N, K,
                              "img_conv1d forward GEMM, bf16 operands / fp32 accumulate / bf16 output (M=%d,N=%d,K=%d; "
@@ -373,9 +389,13 @@ def secondary_config(vqa_amd, which, dev, steps, warmup):
                               "operands, split-K)" % (N, K, M), BF16_MFMA_PEAK_TFLOPS)
             if w is not None:
                 roof["wgrad"] = {k: w[k] for k in ("kernel", "achieved", "frac", "avg_launch_ms", "launches", "traffic", "traffic_source")}
+        if roof is not None:
+            roof["note"] = ("this launch shares the chip with the LSTM recursion (second stream, <= %d of 256 CUs): its duration is "
+                            "the price of the overlap, not the kernel's stand-alone rate (1.68 ms = 0.49 of peak on all CUs)" % C3_SIDE_CUS)
         workload = ("MHBCoAtt train step (fwd+KLDiv+bwd+Adam), batch 512, 196x2048 image grid stored in bf16, 14 tokens, "
-                    "bf16 operands / fp32 accumulate in the img_conv1d and co_att_conv1 GEMM families, everything else fp32; "
-                    "reference LSTM orientation (512-step batch-axis recursion)")
+                    "bf16 operands / fp32 accumulate in %s, everything else fp32; reference LSTM orientation (512-step batch-axis "
+                    "recursion)" % ("the img_conv1d and co_att_conv1 GEMM families" if dtype == "bf16" else
+                                    "every projection GEMM (img_conv1d, co_att_conv1, ques_proj*, img_proj*, question attention, LSTM input projection)"))
     else:
         M, N, K = B * 196, 512, 2048
         roof = gemm_roofline(ops, "gemm_f32_a0b0(fwd)", "f32", M, N, K,
@@ -391,7 +411,8 @@ def secondary_config(vqa_amd, which, dev, steps, warmup):
     rep = census_steps(wl, ops, CENSUS_STEPS, fence)
     out = {"metric": "QA-pairs/sec fwd+bwd, %s batch %d" % (name, B), "value": round(B * steps / elapsed, 2),
            "unit": "QA-pairs/s", "ms_per_step": round(ms, 3), "steps": steps, "warmup": warmup,
-           "dtype": "bf16" if dtype != "f32" else "f32", "config": {"workload": workload, "global_batch": B},
+           "dtype": "bf16" if dtype != "f32" else "f32",
+           "config": {"workload": workload, "global_batch": B, "streams": wl.stream_mode},
            "loss": round(float(loss.item()), 5), "roofline": roof, "step_roofline": step_roofline(name, B, ms, dtype),
            "kernels_ms_per_step": kernel_table(rep, CENSUS_STEPS), "kernels_note": KERNELS_NOTE}
     wl.free()
@@ -415,6 +436,8 @@ def main():
                     help="A/B: image projection on a side HIP stream.  Default at EVERY N: one compute stream with "
                          "the projection as its own autograd node ('same-stream'): its weight-gradient GEMM runs "
                          "last in the backward and the other buckets' all-reduce (RCCL's stream) hides behind it")
+    ap.add_argument("--side-bf16", action="store_true", help="with --overlap: the bf16 projection goes to the side stream too (MFB.side_bf16)")
+    ap.add_argument("--side-cu-limit", type=int, default=0, help="with --overlap: the side stream's persistent GEMMs use at most this many CUs")
     ap.add_argument("--miopen-lstm", action="store_true", help="A/B: question-encoder LSTM on nn.LSTM (MIOpen)")
     ap.add_argument("--pruned", action="store_true",
                     help="MFB.pruned: skip the work that is provably dead under the reference's singleton-axis softmaxes "
@@ -574,7 +597,7 @@ def main():
         wl.free()
         del reducer
         out["secondary"] = {}
-        for which in ("config3", "config4"):
+        for which in ("config3", "config4", "config3_all"):
             try:
                 out["secondary"][which] = secondary_config(vqa_amd, which, dev, args.secondary_steps, args.secondary_warmup)
             except Exception as e:          # the headline line must survive a secondary failure; say what happened

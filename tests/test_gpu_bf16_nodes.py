@@ -247,6 +247,44 @@ def _check_img_fuse(rec, out, grads, rep, saved):
     rep.append("ImgFuseFn[bf16] N=%d: Y %.1e, P bit-equal %.4f, grads err/bound %.2f" % (N, y_err, eq, worst))
 
 
+def _check_img_proj_late(rec, out, grads, rep):
+    """side-stream form: P0 = RNE(bf16 img x bf16 W^T) computed early without a node; the late node only owns the weight
+    gradient dW = dP^T X with the bf16 dP it is handed."""
+    P0, img2, wi, _ = rec["args"]
+    assert P0.dtype == torch.bfloat16 and img2.dtype == torch.bfloat16 and rec["dout"].dtype == torch.bfloat16
+    wb = bf(wi.detach().reshape(wi.shape[0], -1))
+    rows = torch.arange(0, img2.shape[0], 7, device=img2.device)
+    P64 = img2[rows].double() @ wb.double().t()
+    assert float(((P0[rows].double() - P64).abs() - (2.0 ** -8) * P64.abs()).max()) <= 1e-6, "stored P0 is not a bf16 rounding of the product"
+    eq = float((P0[rows] == P64.to(torch.float32).to(torch.bfloat16)).float().mean())
+    assert eq >= 0.98, eq
+    ref = (rec["dout"].double().t() @ img2.double()).view_as(wi)
+    e = _nrel(grads[2], ref)
+    assert e <= BENIGN_TOL_BF16, ("ImgProjLateFn dW", e)
+    rep.append("ImgProjLateFn[bf16]: P0 bit-equal %.4f, dW %.1e" % (eq, e))
+
+
+def _check_mfb_fuse(rec, out, grads, rep):
+    """side-stream form of the image fusion: bf16 P0 (+ bias inside the kernel) in, bf16 dP out."""
+    P0, bi, q, keep, seed, p_drop, N, L = rec["args"][:8]
+    assert P0.dtype == torch.bfloat16 and keep is None and p_drop == 0.0
+    res = {}
+    for dt in (torch.float64, torch.float32):
+        Pl = P0.detach().to(dt).requires_grad_(True)
+        bl, ql = bi.detach().to(dt).requires_grad_(True), q.detach().to(dt).requires_grad_(True)
+        Y = ref_fuse(Pl + bl, ql, N, L)
+        dP, db, dq = torch.autograd.grad(Y, [Pl, bl, ql], rec["dout"].to(dt))
+        res[dt] = (Y.detach(), dP, db, dq)
+        del Pl, Y
+    y_err = _nrel(out, res[torch.float64][0])
+    assert y_err <= 1e-5, ("MfbFuseFn Y", y_err)
+    assert grads[0].dtype == torch.bfloat16
+    worst = _cond_check("MfbFuseFn dP (bf16)", grads[0].float(), res[torch.float64][1], res[torch.float32][1], floor=5e-3)
+    worst = max(worst, _cond_check("MfbFuseFn dbias", grads[1], res[torch.float64][2], res[torch.float32][2]))
+    worst = max(worst, _cond_check("MfbFuseFn dq", grads[2], res[torch.float64][3], res[torch.float32][3]))
+    rep.append("MfbFuseFn[bf16 P/dP] N=%d: Y %.1e, grads err/bound %.2f" % (N, y_err, worst))
+
+
 def _check_final_mfb(rec, out, grads, rep, saved):
     qa, va, wq, bq, wv, bv, keep, seed, p_drop, cascade, want_zdrop, bf16 = (list(rec["args"]) + [None, False, False])[:12]
     assert keep is None and p_drop == 0.0 and cascade is None and not want_zdrop
@@ -293,8 +331,10 @@ def _check_lstm_seq(rec, out, grads, rep):
     rep.append("LstmSeqFn[bf16=%r] S=%d: %.1e" % (bf16, x.shape[0], worst))
 
 
-@pytest.mark.parametrize("bf16_mode", ["bf16", "bf16-all"])
+@pytest.mark.parametrize("bf16_mode", ["bf16", "bf16-all", "bf16-side"])
 def test_config3_every_node_of_the_bf16_step_at_batch_512(bf16_mode, monkeypatch):
+    """bf16-side = gemm_dtype "bf16" in the form bench.py times as BASELINE config 3 since round 3: the image projection and
+    its weight gradient on a second stream beside the 512-step LSTM recursion, confined to 128 CUs (MFB.side_bf16)."""
     import vqa_amd
     vqa_amd.lib.load()
     fns = vqa_amd.functions
@@ -308,20 +348,25 @@ def test_config3_every_node_of_the_bf16_step_at_batch_512(bf16_mode, monkeypatch
     for m in model.modules():
         if isinstance(m, torch.nn.Dropout):
             m.p = 0.0
-    model.gemm_dtype = bf16_mode
+    side = bf16_mode == "bf16-side"
+    model.gemm_dtype = "bf16" if side else bf16_mode
+    if side:
+        model.overlap_streams, model.side_bf16, model.side_cu_limit = True, True, 128
     img = torch.relu(torch.randn((512, 196, 2048), generator=torch.Generator().manual_seed(1234))).cuda()
     q = torch.randint(1, 1000, (512, 14), generator=torch.Generator().manual_seed(1235)).cuda()
     soft = torch.softmax(torch.randn((512, 1000), generator=torch.Generator().manual_seed(1236)), 1).cuda()
     img_b = vqa_amd.ops.cast_bf16(img.view(-1, 2048)).view(img.shape)            # config 3: bf16 feature storage
     del img
 
-    recd = _Recorder(monkeypatch, fns, ["LstmSeqFn", "AttHeadFn", "LinearFn", "ImgFuseFn", "FinalMfbFn", "LogSoftmaxRowsFn"])
+    recd = _Recorder(monkeypatch, fns, ["LstmSeqFn", "AttHeadFn", "LinearFn", "ImgFuseFn", "FinalMfbFn", "LogSoftmaxRowsFn",
+                                        "ImgProjLateFn", "MfbFuseFn"])
     out = model.forward(img_b, q)
     vqa_amd.KLDivLoss()(out, soft).backward()
     torch.cuda.synchronize()
     kinds = [r["cls"].__name__ for r in recd.records]
-    assert kinds == ["LstmSeqFn", "AttHeadFn", "LinearFn", "ImgFuseFn", "AttHeadFn", "FinalMfbFn", "FinalMfbFn", "LinearFn",
-                     "LogSoftmaxRowsFn"], kinds
+    fuse = ["ImgProjLateFn", "MfbFuseFn"] if side else ["ImgFuseFn"]
+    assert kinds == ["LstmSeqFn", "AttHeadFn", "LinearFn"] + fuse + ["AttHeadFn", "FinalMfbFn", "FinalMfbFn", "LinearFn",
+                                                                    "LogSoftmaxRowsFn"], kinds
     assert all(r["dout"] is not None for r in recd.records)
 
     params = {id(p): (k, p) for k, p in model.named_parameters()}
@@ -351,6 +396,10 @@ def test_config3_every_node_of_the_bf16_step_at_batch_512(bf16_mode, monkeypatch
             _check_att_head(rec, out2, grads, rep)
         elif name == "ImgFuseFn":
             _check_img_fuse(rec, out2, grads, rep, saved)
+        elif name == "ImgProjLateFn":
+            _check_img_proj_late(rec, out2, grads, rep)
+        elif name == "MfbFuseFn":
+            _check_mfb_fuse(rec, out2, grads, rep)
         elif name == "FinalMfbFn":
             _check_final_mfb(rec, out2, grads, rep, saved)
         elif name == "LstmSeqFn":

@@ -279,6 +279,9 @@ def test_gemm_small_m_wave_kernel(ops, tb, M, N, K, what):
     with ops.options(gemm_f32_wave=0):                         # the 128x128 split-K path on the same operands
         old = ops.gemm(Ad, Bd, tb=bool(tb))
     assert _rel(old, ref) <= tol and not torch.equal(old, out), "the wave kernel did not take this shape"
+    n0 = ops.stat("gemm_f32_wave")
+    with ops.options(gemm_f32_wave=1):                         # round 2's form (every wave its own B slab): the same k order, the same bits
+        assert torch.equal(out, ops.gemm(Ad, Bd, tb=bool(tb))) and ops.stat("gemm_f32_wave") == n0 + 1
     assert torch.equal(out, ops.gemm(Ad, Bd, tb=bool(tb)))      # fixed-order in-workgroup K reduction
     # bias + relu, and accumulate into a row-strided output view (LstmBatchFn adds into xw[t])
     out2 = ops.gemm(Ad, Bd, tb=bool(tb), bias=bias.float().cuda(), relu=True)

@@ -145,7 +145,7 @@ def test_same_stream_mode_runs_the_projection_weight_gradient_last():
         return real(a_, b_, ta=ta, tb=tb, **kw)
 
     grads = {}
-    for mode in ("same-stream", False):
+    for mode in ("same-stream", False, True):
         model.overlap_streams = mode
         model.zero_grad(set_to_none=True)
         out = model.forward(img, q)
@@ -164,5 +164,14 @@ def test_same_stream_mode_runs_the_projection_weight_gradient_last():
             assert last[0] and last[1] and last[2] == (NL, 5000) and last[3] == (NL, img.shape[2]), calls[-3:]
             wg = [i for i, c in enumerate(calls) if c[0] and c[1] and c[2] == (NL, 5000)]
             assert wg == [len(calls) - 1]
+        if mode is True:
+            # a real second stream: the product is computed first, its autograd node is created LATE (ImgProjLateFn), so the
+            # weight gradient is issued right behind the fusion's backward, before the question side's (LSTM) backward
+            NL = img.shape[0] * img.shape[1]
+            wg = [i for i, c in enumerate(calls) if c[0] and c[1] and c[2] == (NL, 5000)]
+            H = model.lstm.hidden_size
+            lstm = [i for i, c in enumerate(calls) if (not c[0]) and c[1] and c[3] == (4 * H, H)]     # dh = dG W_hh
+            assert len(wg) == 1 and lstm and wg[0] < lstm[0], (wg, lstm[:2])
     for k in grads[False]:
         assert torch.equal(grads["same-stream"][k], grads[False][k]), k
+        assert torch.equal(grads[True][k], grads[False][k]), k

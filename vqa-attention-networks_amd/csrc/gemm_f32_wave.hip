@@ -231,6 +231,161 @@ __global__ void __launch_bounds__(NT, 1) gemm_f32_wave_kernel(const WaveArgs g) 
   }
 }
 
+// ---- WK = 1 with the B panel staged ONCE per workgroup (round 3) ---------------------------------------------------------
+// The four waves of a WK = 1 workgroup own four row tiles of the SAME 64 columns, and each used to stream its own copy of
+// that B slab: 6 KB per wave and slab, 384 MB through L2 per 512 x 4096 x 1024 product for 27 MB of operands, i.e. the
+// kernel ran at the rate a CU can pull from L2 / Infinity Cache (58 us, 0.47 of the MFMA peak).  Here a slab's B image is
+// ONE 4 KB region per workgroup, filled a quarter per wave (copy index = wave), so a workgroup moves 12 KB per slab
+// instead of 24.  The price is one s_barrier per slab: it sits in the MIDDLE of the previous slab's MFMA stream (behind
+// the wave's own counted vmcnt for the next slab), so the matrix pipe keeps draining while the waves meet.
+//   RAW: a wave reads slab s+1's B only behind that barrier, which every wave enters after its own copies of slab s+1.
+//   WAR: the slot of slab s-1 is refilled (slab s+5) during slab s, i.e. behind the barrier of slab s-1, which every wave
+//        enters after lgkmcnt(0) for its reads of slab s-1 (issued and drained during slab s-2).
+// NSL slots per operand ring (NSL - 1 slabs in flight): 12 KB of LDS per slot and workgroup (4 x 2 KB private A + 4 KB shared B)
+constexpr int NGS = NGA + 1;                            // copies per lane and slab: 2 (own A rows) + 1 (a quarter of B)
+
+__device__ __forceinline__ void wait_copies3(int later) {   // all but the 3 * later youngest copies of this wave have landed
+  switch (later < 0 ? 0 : later) {                     // (vmcnt is a 6-bit immediate: 3 * 10 = 30 copies fit)
+    case 0:  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1:  asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 2:  asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 3:  asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 4:  asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 5:  asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+    case 6:  asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+    case 7:  asm volatile("s_waitcnt vmcnt(21)" ::: "memory"); break;
+    case 8:  asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+    case 9:  asm volatile("s_waitcnt vmcnt(27)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(30)" ::: "memory"); break;
+  }
+}
+
+template <bool TB>
+struct FragS {                                         // Frag with A and B in different LDS regions
+  f32x4 a;
+  f32x4 bc[2];
+  f32x2 bt[4];
+  __device__ __forceinline__ void load(const char* sa, const char* sb, int ks, int lane) {
+    const int r = lane & 31, h = lane >> 5;
+    a = *reinterpret_cast<const f32x4*>(sa + r * 64 + (((2 * ks + h) ^ swz(r)) << 4));
+    if (!TB) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        bc[j] = *reinterpret_cast<const f32x4*>(sb + (32 * j + r) * 64 + (((2 * ks + h) ^ swz(r)) << 4));
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bt[e] = *reinterpret_cast<const f32x2*>(sb + (8 * ks + 4 * h + e) * 256 + r * 8);
+    }
+  }
+  __device__ __forceinline__ float b(int j, int e) const { return TB ? bt[e][j] : bc[j][e]; }
+};
+
+template <bool TB, int NSL>
+__global__ void __launch_bounds__(NT, 1) gemm_f32_wave_shb_kernel(const WaveArgs g) {
+  constexpr int SHB_A = NSL * A_BYTES;
+  static_assert(NSL >= 3 && NSL <= 12, "at most 10 later slabs in the vmcnt ladder");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) char lds_char;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int t = 4 * wg + wave;                         // tiles_m % 4 == 0 (host): the 4 waves share the column tile
+  const int tm = t % g.tiles_m, tn = t / g.tiles_m;
+  const int m0 = tm * WTM, n0 = tn * WTN;
+  const int S = g.kpart / TK;
+  char* myA = smem + wave * SHB_A;
+  char* shB = smem + 4 * SHB_A;
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+  gfloat* q[NGS];                                      // [0..1] my A rows, [2] my quarter of the workgroup's B slab
+#pragma unroll
+  for (int i = 0; i < NGA; ++i) {
+    const int row = 16 * i + (lane >> 2);
+    const int chunk = (lane & 3) ^ swz(row);
+    q[i] = (gfloat*)(g.A + (long long)min(m0 + row, g.M - 1) * g.lda + chunk * 4);
+  }
+  if (!TB) {                                           // B (N,K): LDS row rho holds column 2 (rho & 31) + (rho >> 5); my rows 16 wave ..
+    const int rho = 16 * wave + (lane >> 2);
+    const int chunk = (lane & 3) ^ swz(rho);
+    const int col = 2 * (rho & 31) + (rho >> 5);
+    q[NGA] = (gfloat*)(g.B + (long long)min(n0 + col, g.N - 1) * g.ldb + chunk * 4);
+  } else {                                             // B (K,N): my k-rows 4 wave + (l >> 4), columns 4 (l & 15) .. +3
+    const int k = 4 * wave + (lane >> 4);
+    q[NGA] = (gfloat*)(g.B + (long long)k * g.ldb + min(n0 + 4 * (lane & 15), g.N - 4));
+  }
+  auto copy = [&](int i, int sl) {                     // copy i of the slab going into slot sl
+    lds_char* dst = (i < NGA) ? (lds_char*)(myA + sl * A_BYTES + i * 1024) : (lds_char*)(shB + sl * B_BYTES + wave * 1024);
+    __builtin_amdgcn_global_load_lds(q[i], dst, 16, 0, 0);
+    q[i] += (i >= NGA && TB) ? (long long)TK * g.ldb : TK;
+  };
+#pragma unroll
+  for (int p = 0; p < NSL - 1; ++p)
+    if (p < S) {
+#pragma unroll
+      for (int i = 0; i < NGS; ++i) copy(i, p);
+    }
+  FragS<TB> fa[2], fb[2];
+  int slot = 0;
+  auto half = [&](int s, FragS<TB> (&cur)[2], FragS<TB> (&nxt)[2]) {
+    const bool more = s + 1 < S, refill = s + NSL - 1 < S;
+    const int nslot = (slot + 1 == NSL) ? 0 : slot + 1;
+    const int rslot = (slot == 0) ? NSL - 1 : slot - 1;     // slot of slab s-1 takes slab s+NSL-1
+#pragma unroll
+    for (int n = 0; n < 16; ++n) {                     // MFMA n: k-step n >> 3, step e = (n >> 1) & 3, column tile n & 1
+      const int ks = n >> 3, e = (n >> 1) & 3, j = n & 1;
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[ks].a[e], cur[ks].b(j, e), acc[j], 0, 0, 0);
+      if (n < NGS && refill) copy(n, rslot);
+      if (n == 6 && more) {                            // everybody's copies of slab s+1, then its fragment reads
+        wait_copies3(min(NSL - 2, S - 2 - s));
+        __builtin_amdgcn_s_barrier();
+      }
+      if (n == 7 && more) nxt[0].load(myA + nslot * A_BYTES, shB + nslot * B_BYTES, 0, lane);
+      if (n == 9 && more) nxt[1].load(myA + nslot * A_BYTES, shB + nslot * B_BYTES, 1, lane);
+      __builtin_amdgcn_sched_barrier(0);               // keep this interleave
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);                // lgkmcnt(0): no LDS read pending at the loop head
+    __builtin_amdgcn_sched_barrier(0);
+    slot = nslot;
+  };
+  if (S > 0) {
+    wait_copies3(min(NSL - 2, S - 1));                 // my copies of slab 0
+    __builtin_amdgcn_s_barrier();                      // ... and everybody else's
+    fa[0].load(myA, shB, 0, lane);
+    fa[1].load(myA, shB, 1, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  for (int s = 0; s < S; s += 2) {
+    half(s, fa, fb);
+    if (s + 1 < S) half(s + 1, fb, fa);
+  }
+  const int cm = lane & 31, h = lane >> 5;
+  const bool vec = ((g.ldc & 1) == 0) && ((reinterpret_cast<uintptr_t>(g.C) & 7) == 0);
+  const int col = n0 + 2 * cm;
+  const float b0 = (g.bias && col < g.N) ? g.bias[col] : 0.f;
+  const float b1 = (g.bias && col + 1 < g.N) ? g.bias[col + 1] : 0.f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e)
+    put2(g, m0 + (e & 3) + 8 * (e >> 2) + 4 * h, col, acc[0][e], acc[1][e], b0, b1, vec);
+}
+
+template <bool TB, int NSL>
+int launch_shb(const WaveArgs& g, int nwg, hipStream_t s) {
+  static VqfDynLdsFlags attr = {};
+  constexpr int SMEM_SHB = NSL * (4 * A_BYTES + B_BYTES);
+  if (int e = vqf_set_dyn_lds(reinterpret_cast<const void*>(&gemm_f32_wave_shb_kernel<TB, NSL>), SMEM_SHB, attr)) return e;
+  VQF_LAUNCH(KID_GEMM_A0B0 + (TB ? 1 : 0), (gemm_f32_wave_shb_kernel<TB, NSL>), dim3(nwg), dim3(NT), SMEM_SHB, s, g);
+  return vqf_last_error();
+}
+
 template <bool TB, int WK>
 int launch(const WaveArgs& g, int nwg, hipStream_t s) {
   static VqfDynLdsFlags attr = {};
@@ -266,7 +421,12 @@ int vqf_gemm_f32_wave_try(int ta, int tb, int M, int N, int K, const float* A, i
   g.kpart = (wk == 1) ? K : K / 4;
   vqf_prof_dims(M, N, K);
   vqf_stat_bump(VQF_STAT_GEMM_F32_WAVE);
-  if (wk == 1) *rc = tb ? launch<true, 1>(g, nwg1, s) : launch<false, 1>(g, nwg1, s);
+  // option gemm_f32_wave: 1 = every wave streams its own B slab (round 2), 2 / default = B staged once per workgroup
+  const bool shb = wk == 1 && (g.tiles_m % 4 == 0) && tiles % 4 == 0 && vqf_opt(VQF_OPT_GEMM_F32_WAVE, 2) != 1;
+  if (shb && vqf_opt(VQF_OPT_GEMM_F32_WAVE, 2) == 3)   // A/B: 12 slots, 11 slabs in flight
+    *rc = tb ? launch_shb<true, 12>(g, nwg1, s) : launch_shb<false, 12>(g, nwg1, s);
+  else if (shb)     *rc = tb ? launch_shb<true, 6>(g, nwg1, s) : launch_shb<false, 6>(g, nwg1, s);
+  else if (wk == 1) *rc = tb ? launch<true, 1>(g, nwg1, s) : launch<false, 1>(g, nwg1, s);
   else         *rc = tb ? launch<true, 4>(g, nwg4, s) : launch<false, 4>(g, nwg4, s);
   return 1;
 }

@@ -268,8 +268,55 @@ class ImgProjFn(torch.autograd.Function):
         return None, dwi, None
 
 
+def img_project(img, wi, bf16, cu_limit=0):
+    """a5 without an autograd node: P0 = img W^T (no bias), fp32 or -- bf16 operands -- STORED in bf16 when the large-tile
+    kernel applies.  Returns (P0, img2d as the GEMM consumed it).  cu_limit > 0: the persistent large-tile GEMM leaves
+    the other CUs to kernels of other streams (library option gemm_cu_limit)."""
+    img = _c(img)
+    N, L, D = img.shape
+    wi2 = _w2d(wi)
+    with ops.options(gemm_cu_limit=cu_limit if cu_limit else None):
+        if bf16:
+            img2 = img.view(N * L, D) if img.dtype == torch.bfloat16 else ops.cast_bf16(img.view(N * L, D))
+            wb = ops.cast_bf16(wi2)
+            P0 = ops.gemm_bf16(img2, wb, out_bf16=True) if ImgFuseFn.BF16_P else None
+            if P0 is None:
+                P0 = ops.gemm_bf16(img2, wb)
+        else:
+            img2 = img.view(N * L, D)
+            P0 = ops.gemm(img2, wi2)
+    return P0, img2
+
+
+class ImgProjLateFn(torch.autograd.Function):
+    """The autograd node of an image projection whose product was ALREADY computed (img_project, issued at the very start
+    of the forward on a side stream).  Created late -- right before the fusion node that consumes P0 -- so that autograd runs
+    its backward (the weight-gradient GEMM, 14 ms in fp32) right after the fusion's backward and BEFORE the question-side
+    backward is issued: on its own stream it then overlaps the LSTM backward.  (A node created first runs last.)
+    dP arrives in P0's dtype: fp32, or bf16 straight from vqf_mfb_fuse_bwd_pbf16 (no cast pass)."""
+
+    @staticmethod
+    def forward(ctx, P0, img2, wi, cu_limit=0):
+        ctx.save_for_backward(img2, wi)
+        ctx.cu_limit = cu_limit
+        return P0.view_as(P0)
+
+    @staticmethod
+    def backward(ctx, dP):
+        img2, wi = ctx.saved_tensors
+        dP = _c(dP)
+        with ops.options(gemm_cu_limit=ctx.cu_limit if ctx.cu_limit else None):
+            if img2.dtype == torch.bfloat16:
+                dPb = dP if dP.dtype == torch.bfloat16 else ops.cast_bf16(dP)
+                dwi = ops.gemm_bf16(dPb, img2, ta=True, tb=True).view_as(wi)
+            else:
+                dwi = ops.gemm(dP, img2, ta=True, tb=True).view_as(wi)            # wgrad, K = N*L
+        return None, None, dwi, None
+
+
 class MfbFuseFn(torch.autograd.Function):
-    """a6: Y = L2norm_n(ssqrt(pool5(dropout((P0 + bias) * q[n])))) for the L regions of each sample."""
+    """a6: Y = L2norm_n(ssqrt(pool5(dropout((P0 + bias) * q[n])))) for the L regions of each sample.
+    P0 fp32, or bf16 (then dP is handed back in bf16 too: the bf16 mode's projection storage)."""
 
     @staticmethod
     def forward(ctx, P0, bi, q, keep, seed, p_drop, N, L, link=None):
@@ -287,7 +334,8 @@ class MfbFuseFn(torch.autograd.Function):
         P0, bi, q, Y, norm, inv, keep = ctx.saved_tensors
         N, L, O = ctx.dims
         dP, dq, _, dbi = ops.mfb_fuse_bwd(_c(dY), Y, norm, inv, P0, q, N, L, O, keep=keep, seed=ctx.seed,
-                                          p_drop=ctx.p_drop, want_dbias=True, pbias=bi, lin=_take_lin(ctx.link))
+                                          p_drop=ctx.p_drop, want_dbias=True, pbias=bi, lin=_take_lin(ctx.link),
+                                          dp_bf16=P0.dtype == torch.bfloat16)
         return dP, dbi, dq, None, None, None, None, None, None
 
 

@@ -11,8 +11,8 @@ back on nn.LSTM / MIOpen).
 import torch
 import torch.nn as nn
 
-from .functions import (LinearFn, AttHeadFn, ImgFuseFn, ImgProjFn, MfbFuseFn, FinalMfbFn, LstmBatchFn, UnitPoolFn,
-                        DeadParamsFn, NormLink)
+from .functions import (LinearFn, AttHeadFn, ImgFuseFn, ImgProjFn, ImgProjLateFn, MfbFuseFn, FinalMfbFn, LstmBatchFn,
+                        UnitPoolFn, DeadParamsFn, NormLink, img_project)
 
 
 def _image_is_data(img, gemm_dtype="fp32"):
@@ -78,30 +78,37 @@ class _SideStream:
     def __init__(self):
         self.streams = {}
 
-    def project(self, img, conv, bf16, same_stream=False):
+    def project(self, img, conv, bf16, same_stream=False, cu_limit=0):
         dev = img.device
         if same_stream:
             # the projection stays its own autograd node but runs on the caller's stream: created first, its
             # backward (the weight-gradient GEMM) is the LAST node autograd runs, so every other gradient bucket
             # is already being all-reduced (on RCCL's stream) while that 15 ms GEMM computes
             return ImgProjFn.apply(img, conv.weight, bf16), None
+        # a second stream: the product is computed NOW, without an autograd node; join() creates the node late, so that
+        # its backward (the weight gradient) is issued early in the backward pass (functions.ImgProjLateFn) and overlaps
+        # the question-side backward the way the product overlaps the question-side forward
         side = self.streams.get(dev)
         if side is None:
             side = self.streams[dev] = torch.cuda.Stream(device=dev)
         cur = torch.cuda.current_stream(dev)
         side.wait_stream(cur)                    # inputs / weights produced on the caller's stream
-        with torch.cuda.stream(side):
-            P0 = ImgProjFn.apply(img, conv.weight, bf16)
-        return P0, side
+        with torch.cuda.stream(side), torch.no_grad():
+            P0, img2 = img_project(img, conv.weight, bf16, cu_limit)
+        return (P0, img2, conv.weight, cu_limit), side
 
     @staticmethod
     def join(P0, side):
         if side is None:
             return P0
-        cur = torch.cuda.current_stream(P0.device)
+        P0, img2, w, cu_limit = P0
+        with torch.cuda.stream(side):            # the node's stream = the stream its backward will run on
+            P = ImgProjLateFn.apply(P0, img2, w, cu_limit)
+        cur = torch.cuda.current_stream(P.device)
         cur.wait_stream(side)
         P0.record_stream(cur)                    # allocated on the side stream, consumed here
-        return P0
+        img2.record_stream(cur)
+        return P
 
 
 class _DropSeeds:
@@ -173,6 +180,13 @@ class MFB(nn.Module):
         # scale pass nor the sum(Y * dY) pass of its backward runs (functions.NormLink).  fp32 co-attention, single hidden
         # layer only; False materialises fusion_normed as round 2 did
         self.fold_norm = True
+        # overlap_streams = True only: the persistent image-projection GEMMs use at most this many CUs (a multiple of 8; 0 =
+        # all), which leaves the others to the question-side kernels of the main stream (library option gemm_cu_limit)
+        self.side_cu_limit = 0
+        # bf16 modes keep projection + fusion in ONE node on the caller's stream by default (fuse_bf16_dp); side_bf16 = True
+        # lets overlap_streams = True put the bf16 projection on the second stream as well (bf16 P in, bf16 dP out of
+        # MfbFuseFn): worth it where the question side is long and idle, i.e. MHBCoAtt's 512-step LSTM recursion
+        self.side_bf16 = False
         self._side = _SideStream()
         self._seeds = _DropSeeds()
 
@@ -210,9 +224,11 @@ class MFB(nn.Module):
         # a5 starts first, on the side stream: it only needs the image and its weights
         # bf16 mode keeps projection + fusion in one autograd node (ImgFuseFn): its backward hands dP to the
         # weight-gradient GEMM in bf16 without an fp32 round trip, which is worth more than the stream overlap
-        side = self.overlap_streams and not (bf16_img and self.fuse_bf16_dp) and not (self.pruned and self.unit_softmax)
+        # (a real second stream -- overlap_streams is True -- keeps the bf16 hand-off too: MfbFuseFn takes / returns bf16)
+        side = self.overlap_streams and not (bf16_img and self.fuse_bf16_dp and not (self.overlap_streams is True and self.side_bf16)) \
+            and not (self.pruned and self.unit_softmax)
         proj = self._side.project(img_features, self.img_conv1d, bf16_img,
-                                  self.overlap_streams == "same-stream") if side else None
+                                  self.overlap_streams == "same-stream", self.side_cu_limit) if side else None
         # a2: question encoder                                               mfb.py:68-70
         que_embedded = torch.tanh(self.word_embedding(questions))
         lstm_o = batch_first_lstm(self.lstm, que_embedded, self.use_hip_lstm, _lstm_bf16(self.gemm_dtype))

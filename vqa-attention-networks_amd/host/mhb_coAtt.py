@@ -42,6 +42,8 @@ class MHBCoAtt(nn.Module):
         self.overlap_streams = True       # img_conv1d on a side stream, see MFB.overlap_streams
         self.fuse_bf16_dp = True          # see MFB.fuse_bf16_dp
         self.fold_norm = True             # see MFB.fold_norm
+        self.side_cu_limit = 0            # see MFB.side_cu_limit
+        self.side_bf16 = False            # see MFB.side_bf16
         self._side = _SideStream()
         self._seeds = _DropSeeds()
 
@@ -56,9 +58,10 @@ class MHBCoAtt(nn.Module):
         bf16_all = self.gemm_dtype == "bf16-all"          # also ques_proj*, img_proj*, the question-attention conv
         # bf16 mode keeps projection + fusion in one autograd node (ImgFuseFn): its backward hands dP to the
         # weight-gradient GEMM in bf16 without an fp32 round trip, which is worth more than the stream overlap
-        side = self.overlap_streams and not (bf16_img and self.fuse_bf16_dp)
+        # (a real second stream -- overlap_streams is True -- keeps the bf16 hand-off too: MfbFuseFn takes / returns bf16)
+        side = self.overlap_streams and not (bf16_img and self.fuse_bf16_dp and not (self.overlap_streams is True and self.side_bf16))
         proj = self._side.project(img_features, self.img_conv1d, bf16_img,
-                                  self.overlap_streams == "same-stream") if side else None
+                                  self.overlap_streams == "same-stream", self.side_cu_limit) if side else None
         que_embedded = torch.tanh(self.word_embedding(questions))            # (N,T,E)
         if self.cfg.glove:
             assert glove_matrix is not None, 'glove should not be NoneType.'
