@@ -181,6 +181,32 @@ def live_wgrad_probe(ops, B, dev, reps=6):
     return n, ms, red
 
 
+def standalone_bf16_projection(ops, B, dev, reps=6):
+    """The bf16 image-projection launch ALONE on the chip (all CUs, nothing beside it), live operands, bf16 output: what the
+    kernel itself reaches when config 3's step does not make it share the chip with the LSTM recursion."""
+    M, N, K = B * 196, 5000, 2048
+    g = torch.Generator(device="cpu").manual_seed(4322)
+    X = torch.relu(torch.randn((M, K), generator=g)).to(dev).to(torch.bfloat16)
+    W = ((torch.rand((N, K), generator=g) - 0.5) * 0.06).to(dev).to(torch.bfloat16)
+    for _ in range(2):
+        ops.gemm_bf16(X, W, out_bf16=True)
+    torch.cuda.synchronize()
+    ops.prof_reset()
+    ops.prof_enable(True, min_mnk=M * N * K // 2)
+    for _ in range(reps):
+        ops.gemm_bf16(X, W, out_bf16=True)
+    torch.cuda.synchronize()
+    ops.prof_enable(False)
+    n, ms = ops.prof_shape("gemm_bf16", M, N, K)
+    ops.prof_reset()
+    del X, W
+    if not n:
+        return None
+    ach = 2.0 * M * N * K / (ms / n * 1e-3) / 1e12
+    return {"achieved": round(ach, 2), "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "avg_launch_ms": round(ms / n, 4), "launches": n,
+            "what": "the same launch alone on all 256 CUs, outside the step"}
+
+
 def pmc_lookup(dtype, M, N, K):
     """Beyond-L2 bytes per launch of a GEMM from the committed rocprofv3 --pmc passes (PMC passes cannot run inside
     the timed process): newest profiles/r*_pmc_*.json whose dtype / M / N / K match.  -> (bytes, note, source) or Nones."""
@@ -409,6 +435,8 @@ def secondary_config(vqa_amd, which, dev, steps, warmup):
         workload = ("HieCoAtten train step (fwd+CE+bwd+Adam), batch 256, img_size 2048, embed 512, 14 tokens, fp32, "
                     "functional dropout always on (reference behaviour)")
     rep = census_steps(wl, ops, CENSUS_STEPS, fence)
+    if name == "mhb_coAtt" and roof is not None:
+        roof["standalone"] = standalone_bf16_projection(ops, B, dev)
     out = {"metric": "QA-pairs/sec fwd+bwd, %s batch %d" % (name, B), "value": round(B * steps / elapsed, 2),
            "unit": "QA-pairs/s", "ms_per_step": round(ms, 3), "steps": steps, "warmup": warmup,
            "dtype": "bf16" if dtype != "f32" else "f32",

@@ -108,16 +108,36 @@ __device__ __forceinline__ void wait_copies(int later) {   // all but the 6 * la
   else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// one output row's two values of this lane: (+bias) (+C) (relu), 8-byte store when the row pitch allows it
-__device__ __forceinline__ void put2(const WaveArgs& g, int row, int col, float v0, float v1, float b0, float b1, bool vec) {
+// one output row's two values of this lane: (+bias) (+C) (relu), 8-byte store when the row pitch allows it.
+// VQF_GEMM_ACCUM: the old C values arrive in (c0, c1) -- fetched by c_prefetch() at kernel ENTRY.  Loading them here, between
+// the stores of the previous rows, made the epilogue a chain of 16 dependent memory round trips (the compiler cannot move a
+// load across a store it cannot disambiguate): 8 us of the LSTM's 58-us forward product.
+__device__ __forceinline__ void put2(const WaveArgs& g, int row, int col, float v0, float v1, float b0, float b1, bool vec,
+                                     float c0 = 0.f, float c1 = 0.f) {
   if (row >= g.M || col >= g.N) return;
   float* pc = g.C + (long long)row * g.ldc + col;
   const bool two = col + 1 < g.N;
   v0 += b0; v1 += b1;
-  if (g.flags & VQF_GEMM_ACCUM) { v0 += pc[0]; if (two) v1 += pc[1]; }
+  if (g.flags & VQF_GEMM_ACCUM) { v0 += c0; v1 += c1; }
   if (g.flags & VQF_GEMM_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
   if (vec && two) *reinterpret_cast<f32x2*>(pc) = f32x2{v0, v1};
   else { pc[0] = v0; if (two) pc[1] = v1; }
+}
+
+// the lane's 16 x 2 old C values of its 32 x 64 tile (rows (e & 3) + 8 (e >> 2) + 4h, columns 2 cm, 2 cm + 1): zeros unless
+// VQF_GEMM_ACCUM; issued before the K loop, consumed after it
+__device__ __forceinline__ void c_prefetch(const WaveArgs& g, int m0, int n0, int lane, bool vec, f32x2 (&cold)[16]) {
+  const int cm = lane & 31, h = lane >> 5, col = n0 + 2 * cm;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    cold[e] = f32x2{0.f, 0.f};
+    const int row = m0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+    if ((g.flags & VQF_GEMM_ACCUM) && row < g.M && col < g.N) {
+      const float* pc = g.C + (long long)row * g.ldc + col;
+      if (vec && col + 1 < g.N) cold[e] = *reinterpret_cast<const f32x2*>(pc);
+      else { cold[e][0] = pc[0]; if (col + 1 < g.N) cold[e][1] = pc[1]; }
+    }
+  }
 }
 
 template <bool TB, int WK>
@@ -150,6 +170,9 @@ __global__ void __launch_bounds__(NT, 1) gemm_f32_wave_kernel(const WaveArgs g) 
 #pragma unroll
   for (int p = 0; p < NSLOT - 1; ++p)
     if (p < S) stage<TB>(q, g, my + p * SLOT_BYTES);
+  const bool vec = ((g.ldc & 1) == 0) && ((reinterpret_cast<uintptr_t>(g.C) & 7) == 0);
+  f32x2 cold[16];                                      // WK = 1: the old C values of an accumulating product, in flight
+  if (WK == 1 && live) c_prefetch(g, m0, n0, lane, vec, cold);   // behind the first slabs' copies (vmcnt is in order)
   // Fragments are double-buffered ACROSS slabs: the 6 LDS reads of slab s+1 are issued before the 16 MFMAs of slab s
   // (two named sets, loop unrolled by two: a runtime-indexed set would live in scratch).
   Frag<TB> fa[2], fb[2];
@@ -197,7 +220,6 @@ __global__ void __launch_bounds__(NT, 1) gemm_f32_wave_kernel(const WaveArgs g) 
 
   // ---- epilogue: tile j, register e, lane (cm, h): row (e & 3) + 8 (e >> 2) + 4h, column 2 cm + j
   const int cm = lane & 31, h = lane >> 5;
-  const bool vec = ((g.ldc & 1) == 0) && ((reinterpret_cast<uintptr_t>(g.C) & 7) == 0);
   if (WK == 1) {
     if (!live) return;
     const int col = n0 + 2 * cm;
@@ -205,7 +227,7 @@ __global__ void __launch_bounds__(NT, 1) gemm_f32_wave_kernel(const WaveArgs g) 
     const float b1 = (g.bias && col + 1 < g.N) ? g.bias[col + 1] : 0.f;
 #pragma unroll
     for (int e = 0; e < 16; ++e)
-      put2(g, m0 + (e & 3) + 8 * (e >> 2) + 4 * h, col, acc[0][e], acc[1][e], b0, b1, vec);
+      put2(g, m0 + (e & 3) + 8 * (e >> 2) + 4 * h, col, acc[0][e], acc[1][e], b0, b1, vec, cold[e][0], cold[e][1]);
   } else {
     // partial tiles through LDS (each wave's own region, free once its last slab has been read): [e][lane] float2
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -226,7 +248,13 @@ __global__ void __launch_bounds__(NT, 1) gemm_f32_wave_kernel(const WaveArgs g) 
         const f32x2 p = reinterpret_cast<const f32x2*>(smem + w * WAVE_LDS)[e * 64 + lane];
         v[0] += p[0]; v[1] += p[1];
       }
-      put2(g, m0 + (e & 3) + 8 * (e >> 2) + 4 * h, col, v[0], v[1], b0, b1, vec);
+      float c0 = 0.f, c1 = 0.f;                          // (WK = 4 with accumulate: 4 rows per wave, loaded here)
+      const int row = m0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      if ((g.flags & VQF_GEMM_ACCUM) && row < g.M && col < g.N) {
+        c0 = g.C[(long long)row * g.ldc + col];
+        if (col + 1 < g.N) c1 = g.C[(long long)row * g.ldc + col + 1];
+      }
+      put2(g, row, col, v[0], v[1], b0, b1, vec, c0, c1);
     }
   }
 }
@@ -331,6 +359,9 @@ __global__ void __launch_bounds__(NT, 1) gemm_f32_wave_shb_kernel(const WaveArgs
 #pragma unroll
       for (int i = 0; i < NGS; ++i) copy(i, p);
     }
+  const bool vec = ((g.ldc & 1) == 0) && ((reinterpret_cast<uintptr_t>(g.C) & 7) == 0);
+  f32x2 cold[16];
+  c_prefetch(g, m0, n0, lane, vec, cold);
   FragS<TB> fa[2], fb[2];
   int slot = 0;
   auto half = [&](int s, FragS<TB> (&cur)[2], FragS<TB> (&nxt)[2]) {
@@ -368,13 +399,12 @@ __global__ void __launch_bounds__(NT, 1) gemm_f32_wave_shb_kernel(const WaveArgs
     if (s + 1 < S) half(s + 1, fb, fa);
   }
   const int cm = lane & 31, h = lane >> 5;
-  const bool vec = ((g.ldc & 1) == 0) && ((reinterpret_cast<uintptr_t>(g.C) & 7) == 0);
   const int col = n0 + 2 * cm;
   const float b0 = (g.bias && col < g.N) ? g.bias[col] : 0.f;
   const float b1 = (g.bias && col + 1 < g.N) ? g.bias[col + 1] : 0.f;
 #pragma unroll
   for (int e = 0; e < 16; ++e)
-    put2(g, m0 + (e & 3) + 8 * (e >> 2) + 4 * h, col, acc[0][e], acc[1][e], b0, b1, vec);
+    put2(g, m0 + (e & 3) + 8 * (e >> 2) + 4 * h, col, acc[0][e], acc[1][e], b0, b1, vec, cold[e][0], cold[e][1]);
 }
 
 template <bool TB, int NSL>
