@@ -227,3 +227,29 @@ def test_headline_fp32_forward_launch_edge_tiles_bitwise(ops):
     rows = torch.arange(0, 512 * 196, 97, device="cuda")
     ref = X[rows].double() @ W.double().t() + b.double()
     assert _rel(P[rows], ref) <= 2e-6 * max(1.0, np.sqrt(2048) / 8)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_persistent_gemms_confined_to_a_cu_subset_give_the_same_bits(ops, dtype):
+    """Library option gemm_cu_limit (the config-3 step runs the image projection beside the LSTM recursion on 128 CUs): the
+    persistent large-tile GEMMs launch at most that many workgroups and walk the same work items -> bit-identical output."""
+    M, N, K = 16896, 5000, 1536              # 66 x 20 = 1320 tiles: large-tile kernels in both dtypes
+    A, B = _u((M, K), 301), _u((N, K), 302, 0.5)
+    bias = _u((N,), 303)
+    if dtype == "bf16":
+        A, B = A.to(torch.bfloat16), B.to(torch.bfloat16)
+        fn = lambda: ops.gemm_bf16(A, B, bias=bias)
+        n0 = ops.stat("gemm_bf16_big")
+    else:
+        fn = lambda: ops.gemm(A, B, bias=bias)
+        n0 = ops.stat("gemm_f32_big")
+    full = fn()
+    outs = []
+    for lim in (128, 64, 250):                # 250 -> 248 (multiples of 8)
+        with ops.options(gemm_cu_limit=lim):
+            outs.append(fn())
+    assert ops.stat("gemm_bf16_big" if dtype == "bf16" else "gemm_f32_big") == n0 + 4
+    for o in outs:
+        assert torch.equal(o, full)
+    ref = _ref64(A, B, 0, 0, bias)
+    assert _rel(full, ref) <= (2e-5 if dtype == "bf16" else 2e-6) * max(1.0, np.sqrt(K) / 8)

@@ -116,6 +116,9 @@ class AttHeadFn(torch.autograd.Function):
             ctx.save_for_backward(x, feat, w1, None, w2, hid1, None, wts, lin)
             ctx.unit = bool(unit_softmax)
             return pooled
+        # (the bf16 GEMM entry point wants K and every K-major operand's row extent to be multiples of 8: here the hidden
+        #  width and, for the dgrad's N = C_in columns, the input width; else the head stays fp32, like LinearFn / FinalMfbFn)
+        ctx.bf16 = ctx.bf16 and _bf16_ok(_w2d(w1).shape[0], _w2d(w1).shape[1])
         if ctx.bf16:
             # bf16 operands, fp32 accumulate (BASELINE config 3); K padded to a multiple of 32
             xb, w1b = ops.cast_bf16(x, 32), ops.cast_bf16(_w2d(w1), 32)

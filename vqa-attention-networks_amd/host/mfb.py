@@ -24,7 +24,7 @@ def _image_is_data(img, gemm_dtype="fp32"):
         raise VqfError("vqa fusion modules need GPU tensors (HIP extension is the only path; no CPU fallback)")
     if img.dtype == torch.bfloat16:
         if gemm_dtype not in ("bf16", "bf16-img", "bf16-all"):
-            raise VqfError("bf16 img_features need model.gemm_dtype = 'bf16' (or 'bf16-img'); "
+            raise VqfError("bf16 img_features need model.gemm_dtype = 'bf16', 'bf16-img' or 'bf16-all'; "
                            "the fp32 path takes fp32 features")
         if img.shape[-1] % 8:
             raise VqfError("bf16 img_features: the channel count must be a multiple of 8")
@@ -162,8 +162,9 @@ class MFB(nn.Module):
         # "fp32" (default, parity 1e-4) or "bf16": bf16 operands / fp32 accumulate for the two large
         # GEMM families (img_conv1d and co_att_conv1, 96 % of the FLOPs); everything else stays fp32.
         # "bf16-all": additionally ques_proj1, the final blocks' ques_proj* / img_proj* and the question-attention
-        # conv take bf16 operands (forward, dgrad and weight gradient); the classifier, the LSTM input projection
-        # (K = 300), the fusion / attention / normalisation arithmetic and every reduction stay fp32
+        # conv take bf16 operands (forward, dgrad and weight gradient), and so do the LSTM's input projection (K = 300
+        # zero-padded to 304 by the cast) with its two gradients and the recurrent weight gradient; the classifier, the
+        # fusion / attention / normalisation arithmetic, the LSTM's gates and state and every reduction stay fp32
         self.gemm_dtype = "fp32"
         # True: run img_conv1d (and, through autograd, its weight gradient) on a side stream, concurrently
         # with the question encoder / question attention (and their backward + gradient all-reduce).
