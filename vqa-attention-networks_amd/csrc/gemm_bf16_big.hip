@@ -24,14 +24,16 @@
 //     different bank quarters.
 //   * deterministic split-K (fixed-order slab reduction, vqf_splitk_reduce) when the tile count alone
 //     cannot fill the chip (the weight gradient: 20 x 8 tiles, K = 100352).
-// Measured on the image projection (M=100352, N=5000, K=2048, random operands): 675 -> 876 TFLOP/s
-// (s_setprio(1) around the MFMA blocks: 860; the weight gradient 887 -> 780: not used.  Two wave groups one
-// phase apart -- waves 0-3 read slab s while waves 4-7 multiply slab s-1, two raw barriers per slab -- 859 / 746:
-// not used either.  LDS moves 96 KB of fragment reads + 32 KB of DMA writes per slab and CU = 1024 clk at
-// 128 B/clk, exactly the 1024 MFMA cycles a SIMD spends on a slab: the kernel sits on the LDS roofline.)
-// By ablation the 2.35 ms are 1.09 ms of MFMA work at the ~1.8 GHz the chip sustains here, +0.43 ms
-// fragment-read stalls, +0.50 ms copy issue / barriers, +0.34 ms for the exposed fp32 epilogue (one
-// workgroup per CU).
+// History of this file's loops on the image projection (M=100352, N=5000, K=2048, random operands, fp32 output):
+//   round 1, gemm_bf16_big_kernel (all 8 waves in lockstep: barrier -> 12 fragment reads -> 16 MFMAs): 675 -> 876 TFLOP/s over the
+//     128x128 kernel; the matrix pipes were 44 % busy (the two waves of a SIMD read together, then multiplied together).
+//   round 2, gemm_bf16_pp_kernel / gemm_bf16_pp16_kernel (the default): ping-pong halves -- waves 4-7 half a slab behind waves 0-3,
+//     one multiplies while its SIMD partner loads -- and v_mfma_f32_16x16x32_bf16 with one ds_read_b128 per fragment for
+//     K-contiguous operands: 1081 TFLOP/s with fp32 output, 1197-1230 with bf16 output (0.48-0.49 of the 2.5 PFLOP/s peak), weight
+//     gradient 1113-1145; PMC (profiles/r03_pmc_gemm.txt): MFMA pipe 67 % / 58 % busy at the 1.5-1.6 GHz the chip holds under
+//     this load; the loop is bound by the issue cost of the LDS-DMA copies (s_memtime stamps), not by idle pipes.
+//   round 3: nothing changed in the loops; the persistent launch takes a CU limit (library option gemm_cu_limit) so that config 3
+//     can run these GEMMs beside the LSTM recursion.
 // Preconditions (else the caller falls back to gemm_bf16.hip): K % 32 == 0, M >= 256, N >= 128, no
 // accumulate flag, a K-major operand's row extent % 8 == 0; 16-byte aligned bases, lda/ldb % 8 == 0.
 #include "common.h"
