@@ -465,6 +465,8 @@ def main():
                     help="A/B: image projection on a side HIP stream.  Default at EVERY N: one compute stream with "
                          "the projection as its own autograd node ('same-stream'): its weight-gradient GEMM runs "
                          "last in the backward and the other buckets' all-reduce (RCCL's stream) hides behind it")
+    ap.add_argument("--no-defer", action="store_true",
+                    help="A/B: one-stream form with the projection's product issued FIRST in the forward (round 2) instead of behind the question encoder")
     ap.add_argument("--side-bf16", action="store_true", help="with --overlap: the bf16 projection goes to the side stream too (MFB.side_bf16)")
     ap.add_argument("--side-cu-limit", type=int, default=0, help="with --overlap: the side stream's persistent GEMMs use at most this many CUs")
     ap.add_argument("--miopen-lstm", action="store_true", help="A/B: question-encoder LSTM on nn.LSTM (MIOpen)")
@@ -490,6 +492,8 @@ def main():
     ops = vqa_amd.ops
     vqa_amd.lib.load()
 
+    if args.no_defer:
+        import_module("vqa-attention-networks_amd.host.mfb")._SideStream.DEFER = False
     rank, world, local = parallel.init_distributed(args.backend)
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N ranks with `python -m torch.distributed.run "

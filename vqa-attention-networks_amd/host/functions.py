@@ -271,6 +271,32 @@ class ImgProjFn(torch.autograd.Function):
         return None, dwi, None
 
 
+class ImgProjDeferFn(torch.autograd.Function):
+    """fp32 image projection whose NODE exists before its PRODUCT: forward() only allocates P0 and returns it; fill() issues the
+    GEMM into that buffer later (a raw write the autograd graph does not see).  The one-stream form wants the node created
+    FIRST (a node created first runs its backward last: the 14 ms weight gradient then hides the other gradients' all-reduce)
+    but the product issued AFTER the question encoder: the projection is then not the kernel right behind the previous step's
+    weight-gradient GEMM and Adam -- two back-to-back 14 ms MFMA-bound launches made the second one run 1.4 % slower (same box:
+    14.67 vs 14.47 ms, `profiles/r03_all_configs.log`; forward-only steps reach 14.23)."""
+
+    @staticmethod
+    def forward(ctx, img, wi):
+        img = _c(img)
+        N, L, D = img.shape
+        ctx.save_for_backward(img.view(N * L, D), wi)
+        return torch.empty((N * L, wi.shape[0]), dtype=torch.float32, device=img.device)
+
+    @staticmethod
+    def fill(P0, img, wi):
+        img = _c(img)
+        ops.gemm(img.view(-1, img.shape[-1]), _w2d(wi), out=P0.detach())
+
+    @staticmethod
+    def backward(ctx, dP):
+        img2, wi = ctx.saved_tensors
+        return None, ops.gemm(_c(dP), img2, ta=True, tb=True).view_as(wi)            # wgrad, K = N*L
+
+
 def img_project(img, wi, bf16, cu_limit=0):
     """a5 without an autograd node: P0 = img W^T (no bias), fp32 or -- bf16 operands -- STORED in bf16 when the large-tile
     kernel applies.  Returns (P0, img2d as the GEMM consumed it).  cu_limit > 0: the persistent large-tile GEMM leaves

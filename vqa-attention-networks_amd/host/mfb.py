@@ -11,8 +11,8 @@ back on nn.LSTM / MIOpen).
 import torch
 import torch.nn as nn
 
-from .functions import (LinearFn, AttHeadFn, ImgFuseFn, ImgProjFn, ImgProjLateFn, MfbFuseFn, FinalMfbFn, LstmBatchFn,
-                        UnitPoolFn, DeadParamsFn, NormLink, img_project)
+from .functions import (LinearFn, AttHeadFn, ImgFuseFn, ImgProjFn, ImgProjLateFn, ImgProjDeferFn, MfbFuseFn, FinalMfbFn,
+                        LstmBatchFn, UnitPoolFn, DeadParamsFn, NormLink, img_project)
 
 
 def _image_is_data(img, gemm_dtype="fp32"):
@@ -84,6 +84,9 @@ class _SideStream:
             # the projection stays its own autograd node but runs on the caller's stream: created first, its
             # backward (the weight-gradient GEMM) is the LAST node autograd runs, so every other gradient bucket
             # is already being all-reduced (on RCCL's stream) while that 15 ms GEMM computes
+            if not bf16 and _SideStream.DEFER and img.dtype == torch.float32:
+                # ... and its PRODUCT is issued by join(), behind the question encoder (functions.ImgProjDeferFn)
+                return ("defer", ImgProjDeferFn.apply(img, conv.weight), img, conv.weight), None
             return ImgProjFn.apply(img, conv.weight, bf16), None
         # a second stream: the product is computed NOW, without an autograd node; join() creates the node late, so that
         # its backward (the weight gradient) is issued early in the backward pass (functions.ImgProjLateFn) and overlaps
@@ -97,9 +100,16 @@ class _SideStream:
             P0, img2 = img_project(img, conv.weight, bf16, cu_limit)
         return (P0, img2, conv.weight, cu_limit), side
 
+    DEFER = True       # one-stream form: issue the projection's product behind the question encoder (A/B switch)
+
     @staticmethod
     def join(P0, side):
         if side is None:
+            if isinstance(P0, tuple) and P0[0] == "defer":
+                _, P, img, w = P0
+                with torch.no_grad():
+                    ImgProjDeferFn.fill(P, img, w)
+                return P
             return P0
         P0, img2, w, cu_limit = P0
         with torch.cuda.stream(side):            # the node's stream = the stream its backward will run on
