@@ -70,7 +70,7 @@ const char* vqf_build_info(void);
 #define VQF_OPT_GEMM_F32_BIG 4       /* 0 = never use the 256x256-tile fp32 kernel */
 #define VQF_OPT_GEMM_BF16_BIG 5      /* 0 = never use the 256x256-tile bf16 kernel */
 #define VQF_OPT_GEMM_F32_WAVE 6      /* small-M per-wave-tile kernel: 0 = never, 1 = every wave streams its own B slab (r02), 2 = B staged once per workgroup (default) */
-#define VQF_OPT_FUSE_COAL 7          /* MFB fusion kernels: 0 / 1 force the LDS-transposed P / dP access off / on */
+#define VQF_OPT_FUSE_COAL 7          /* MFB fusion kernels: 0 = direct (strided) P / dP access everywhere, 1 = LDS-transposed with the forward's register prefetch, default = LDS-transposed, forward without prefetch */
 #define VQF_OPT_FUSE_LS 8            /* MFB fusion forward: row splits per sample (>= 1), tuning probe */
 #define VQF_OPT_FUSE_LS_BWD 9        /* MFB fusion backward: row splits per sample (1..16), tuning probe */
 #define VQF_OPT_GEMM_CU_LIMIT 10     /* persistent large-tile GEMMs use at most this many CUs (multiple of 8; leaves the rest

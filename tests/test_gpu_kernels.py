@@ -328,3 +328,27 @@ def test_mfb_fuse_philox_16bit_draws(ops, O):
     dP, _, _, _ = ops.mfb_fuse_bwd(torch.ones_like(Y), Y, norm, inv, P, q, N, L, O, seed=99, p_drop=0.25)
     same = float(((dP != 0) == kept).float().mean())
     assert same > 0.999, same                               # (dP can be exactly 0 where the pooled sum is 0)
+
+
+@pytest.mark.parametrize("pbf16", [False, True])
+def test_mfb_fuse_access_variants_give_the_same_bits(ops, pbf16):
+    """The three access forms of the fusion kernels (library option fuse_coal: 0 direct / strided, 1 LDS-transposed with the
+    forward's register prefetch, default LDS-transposed without it) do the same arithmetic per element: bit-identical R / Y,
+    dP, dq and bias gradient, fp32 and bf16 projection storage, with Philox dropout, at a ragged shape and the reference's O."""
+    N, L, O = 5, 23, 1000
+    g = torch.Generator(device="cuda").manual_seed(17)
+    P = torch.randn((N * L, 5 * O), device="cuda", generator=g)
+    q = torch.randn((N, 5 * O), device="cuda", generator=g)
+    pb = torch.randn((5 * O,), device="cuda", generator=g)
+    dY = torch.randn((N * L, O), device="cuda", generator=g)
+    Pm = P.to(torch.bfloat16) if pbf16 else P
+    res = {}
+    for v in (0, 1, None):
+        with ops.options(fuse_coal=v):
+            Y, norm, inv, _ = ops.mfb_fuse_fwd(Pm, q, N, L, O, seed=4242, p_drop=0.1, pbias=pb)
+            out = ops.mfb_fuse_bwd(dY, Y, norm, inv, Pm, q, N, L, O, seed=4242, p_drop=0.1, want_dbias=True, pbias=pb,
+                                   dp_bf16=pbf16)
+        res[v] = (Y.clone(), out[0].clone(), out[1].clone(), out[3].clone())
+    for v in (1, None):
+        for a, b in zip(res[0], res[v]):
+            assert torch.equal(a.view(torch.uint8), b.view(torch.uint8)), v

@@ -189,7 +189,9 @@ __device__ __forceinline__ void keep_scale20(const uint8_t* __restrict__ keep, u
 // 20 q values and the 20 projection biases of its columns held in registers (one row per block re-read
 // both for every row: 3x the load instructions); the next row's P chunk is fetched before the current
 // row is reduced.  Dropout keys on the flat element index, so the masks do not depend on this mapping.
-template <typename PT, bool COAL>
+// COAL: 0 = direct (strided) P loads, 1 = LDS-transposed loads with the next row's pieces prefetched into registers,
+// 2 = LDS-transposed loads issued at the top of the row (20 registers fewer: one more block per CU; A/B, option fuse_coal = 2)
+template <typename PT, int COAL>
 __global__ void __launch_bounds__(256)
 mfb_fuse_fwd_kernel(const PT* __restrict__ P, const float* __restrict__ pbias,
                     const float* __restrict__ q,
@@ -212,15 +214,18 @@ mfb_fuse_fwd_kernel(const PT* __restrict__ P, const float* __restrict__ pbias,
     if (pbias) load20(pbias + CPT * tid, pb);
     if (!COAL && ls < L) load20(P + ((long long)n * L + ls) * W5 + CPT * tid, pn);
   }
-  if (COAL && ls < L) raw_load(P + ((long long)n * L + ls) * W5, W5, wave, lane, rn);     // every lane of the wave
+  if (COAL == 1 && ls < L) raw_load(P + ((long long)n * L + ls) * W5, W5, wave, lane, rn);     // every lane of the wave
   int it = 0;
   for (int l = ls; l < L; l += LS, ++it) {
     const long long row = (long long)n * L + l;
     const long long e0 = row * W5 + (long long)CPT * tid;
     float ssq = 0.f;
-    if (COAL) {
+    if (COAL == 1) {
       raw_to_own(rn, tl + wave * WLDS, lane, p);
       if (l + LS < L) raw_load(P + (row + LS) * W5, W5, wave, lane, rn);   // prefetch the next row of this block
+    } else if (COAL == 2) {
+      raw_load(P + row * W5, W5, wave, lane, rn);
+      raw_to_own(rn, tl + wave * WLDS, lane, p);
     }
     if (act) {
       if (!COAL) {
@@ -342,10 +347,12 @@ mfb_fuse_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ dzdr
 }
 
 // Coalesced (LDS-transposed) P / dP access.  Measured at the headline shape (tools/fuse_bench.py, profiles/r03_fuse_ab.log,
-// dropout 0.1): fp32 forward 0.64 -> 0.50 ms, fp32 backward 1.16 -> 0.89 ms, bf16-P forward 0.43 -> 0.38 ms, bf16 backward
-// 0.576 -> 0.594 ms (direct stays the default there).  Round 2 had measured the forward as a tie and the bf16 kernels as
-// slower: those variants were spilling the Philox words to scratch (see keep_scale20).  Option fuse_coal = 0 / 1 forces it
-// off / on everywhere.
+// r03_fuse_ab2.log, dropout 0.1): fp32 forward 0.64 -> 0.50 ms, fp32 backward 1.08-1.16 -> 0.83-0.89 ms, bf16-P forward 0.43 ->
+// 0.37 ms; bf16 backward 0.576 -> 0.594 on one box and 0.586 -> 0.554 on another (coalesced is the default there too).  The
+// forward WITHOUT its register prefetch of the next row (COAL = 2: 126 VGPRs, four blocks per CU instead of three) is another
+// 3 % faster: 0.496 -> 0.481 ms (5.0 TB/s), bf16-P 0.370 -> 0.358.  Round 2 had measured the forward as a tie and the bf16
+// kernels as slower: those variants were spilling the Philox words to scratch (see keep_scale20).  Option fuse_coal = 0 forces
+// the direct access everywhere, 1 the round-3 coalesced forward WITH prefetch.
 bool fuse_coalesced(bool dflt) {
   const int v = g_vqf_opt[VQF_OPT_FUSE_COAL];
   return v < 0 ? dflt : v != 0;
@@ -400,7 +407,7 @@ static int fuse_bwd_impl(const float* dY, const float* dzdrop, const float* Y, c
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(N, LS);
   // coalesced P / dP access through the LDS transpose: one pass of 256 threads over the row, whole 16-byte pieces
-  const bool coal = fuse_coalesced(!p_bf16 && !dp_bf16) && O / TPT <= 256 && (W5 % ((p_bf16 || dp_bf16) ? 8 : 4) == 0);
+  const bool coal = fuse_coalesced(true) && O / TPT <= 256 && (W5 % ((p_bf16 || dp_bf16) ? 8 : 4) == 0);
 #define VQF_BWD1(C_, D_, T_, PT_, CO_)                                                           \
   VQF_LAUNCH(KID_MFB_FUSE_BWD, (mfb_fuse_bwd_kernel<C_, D_, T_, PT_, CO_>), grid, dim3(256), 0, s, dY, dzdrop, Y, inv, \
              coefA, coefB, (const PT_*)P, pbias, q, cascade, keep, seed, thr, inv_keep, L, O, LS, (T_*)dP, dq_part, \
@@ -439,11 +446,12 @@ static int fuse_fwd_impl(const void* P, int p_bf16, const float* pbias, const fl
   const float inv_keep = (keep || p_drop > 0.f) ? 1.0f / (1.0f - p_drop) : 1.0f;
   const int LS = pick_ls_fwd(N, L);
   const bool coal = fuse_coalesced(true) && ((KP * O) % (p_bf16 ? 8 : 4) == 0);
+  const bool nopf = coal && g_vqf_opt[VQF_OPT_FUSE_COAL] != 1;   // default: no register prefetch (126 VGPRs, 4 blocks per CU)
 #define VQF_FWD(PT_, CO_)                                                                                             \
   VQF_LAUNCH(KID_MFB_FUSE_FWD, (mfb_fuse_fwd_kernel<PT_, CO_>), dim3(N, LS), dim3(256), 0, (hipStream_t)stream,         \
              (const PT_*)P, pbias, q, cascade, keep, seed, thr, inv_keep, L, O, LS, R, rowssq, zdrop)
-  if (p_bf16) { if (coal) VQF_FWD(__bf16, true); else VQF_FWD(__bf16, false); }
-  else        { if (coal) VQF_FWD(float, true); else VQF_FWD(float, false); }
+  if (p_bf16) { if (nopf) VQF_FWD(__bf16, 2); else if (coal) VQF_FWD(__bf16, 1); else VQF_FWD(__bf16, 0); }
+  else        { if (nopf) VQF_FWD(float, 2); else if (coal) VQF_FWD(float, 1); else VQF_FWD(float, 0); }
 #undef VQF_FWD
   return vqf_last_error();
 }
