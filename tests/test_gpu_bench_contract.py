@@ -100,3 +100,16 @@ def test_bench_two_ranks_on_one_gpu_gloo_rehearsal(tmp_path):
     assert len(ex) == len(d["config"]["allreduce_bucket_bytes"]) and all(b >= a - 1e-3 for a, b in zip(ex, ex[1:]))
     assert abs(d["value"] - 1024 * 1000.0 / d["ms_per_step"]) / d["value"] < 1e-3
     assert "cpu_baseline" not in d
+
+
+def test_bench_bf16_cli_run_carries_a_roofline():
+    """`bench.py --model mhb_coAtt --dtype bf16` (round 2 printed "roofline": null for every bf16 run): the bf16 image-projection
+    launch against the dense bf16 MFMA peak, its weight gradient, and no secondary block on a non-headline run."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--model", "mhb_coAtt", "--dtype", "bf16", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.strip().startswith("{")][0])
+    r = d["roofline"]
+    assert d["dtype"] == "bf16" and r is not None and r["peak"] == 2500.0 and r["launches"] == 2 and 0.1 < r["frac"] < 1.0
+    assert "gemm_bf16" in r["kernel"] and r["wgrad"]["frac"] > 0.1 and "secondary" not in d
+    assert "mhb_coAtt" in d["metric"] and d["config"]["workload"].startswith("mhb_coAtt")
