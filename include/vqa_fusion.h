@@ -375,6 +375,15 @@ int vqf_lstm_seq_bwd_persist(const float* dhs, const float* gates, const float* 
 int vqf_lstm_persist_status(const void* ws, void* stream);
 
 /* --------------------------------------------------------------------------
+ * Question-encoder front end: e = tanh(Embedding(q))   (mfb.py:68, mhb_coAtt.py:69).
+ *   W (V,E) word_embedding.weight, ids (T) int64 token ids (the (N,T) question tensor, flattened), out (T,E).
+ *   bwd: dW (V,E) = sum over the tokens of each id of dout * (1 - out^2), EVERY row written (zeros where an id does not
+ *   occur), summed in token order (deterministic, no atomics).  E <= 1024.  Ids outside [0,V) select no row. */
+int vqf_embed_tanh_fwd(const float* W, const long long* ids, int T, int V, int E, float* out, void* stream);
+int vqf_embed_tanh_bwd(const float* dout, const float* out, const long long* ids, int T, int V, int E, float* dW,
+                       void* stream);
+
+/* --------------------------------------------------------------------------
  * Input staging.  data_loader.py:30-32 loads one [2048,14,14] .npy per image
  * and makes it (196,2048) on the CPU (np.transpose(x,(1,2,0)).reshape(-1,2048)).  Here the raw
  * batch src (N, D, L) fp32 (channels outermost, as stored) is transposed on the device into the

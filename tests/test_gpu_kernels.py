@@ -352,3 +352,52 @@ def test_mfb_fuse_access_variants_give_the_same_bits(ops, pbf16):
     for v in (1, None):
         for a, b in zip(res[0], res[v]):
             assert torch.equal(a.view(torch.uint8), b.view(torch.uint8)), v
+
+
+@pytest.mark.parametrize("T,V,E", [(7168, 1000, 300), (5000, 3, 300), (130, 50, 7), (64, 9, 1024)])
+def test_embed_tanh_fwd_bwd_vs_torch_fp64(ops, T, V, E):
+    """tanh(Embedding(q)) (mfb.py:68) and its weight gradient: vs torch in fp64; the backward is a token-ordered segment
+    sum (bit-reproducible), writes every vocabulary row (zeros for unused ids) and handles ids that repeat thousands of
+    times (T = 5000 tokens over 3 ids: three rounds of the 2048-id match list)."""
+    g = torch.Generator().manual_seed(41)
+    W = torch.randn((V, E), generator=g)
+    ids = torch.randint(0, V, (T,), generator=g)
+    if V > 20:
+        ids[ids == 5] = 6                                   # id 5 never occurs: its gradient row must be exact zeros
+    dout = torch.randn((T, E), generator=g)
+    W64 = W.double().requires_grad_(True)
+    ref = torch.tanh(torch.nn.functional.embedding(ids, W64))
+    ref.backward(dout.double())
+    out = ops.embed_tanh_fwd(W.cuda(), ids.cuda())
+    assert out.shape == (T, E) and _rel(out, ref.detach()) <= 2e-6
+    dW = ops.embed_tanh_bwd(dout.cuda(), out, ids.cuda(), V)
+    assert _rel(dW, W64.grad) <= 2e-6 * max(1.0, np.sqrt(T / V) / 4)
+    if V > 20:
+        assert float(dW[5].abs().max()) == 0.0
+    assert torch.equal(dW, ops.embed_tanh_bwd(dout.cuda(), out, ids.cuda(), V))
+    # (N, T) id tensors keep their shape; ids outside [0, V) select nothing
+    ids2 = ids[: (T // 2) * 2].view(2, -1).clone()
+    ids2[0, 0], ids2[1, 1] = -1, V
+    o2 = ops.embed_tanh_fwd(W.cuda(), ids2.cuda())
+    assert o2.shape == (2, T // 2, E) and float(o2[0, 0].abs().max()) == 0.0 and float(o2[1, 1].abs().max()) == 0.0
+    ok = (ids2 >= 0) & (ids2 < V)
+    assert _rel(o2[ok.cuda()], torch.tanh(W.double()[ids2[ok]])) <= 2e-6
+
+
+def test_embed_tanh_module_path_matches_torch_embedding(ops):
+    """functions.embed_tanh on an nn.Embedding: same values and weight gradient as torch.tanh(embedding(q)); an embedding with
+    a padding_idx stays on torch (its row gets no gradient there)."""
+    import vqa_amd
+    fns = vqa_amd.functions
+    emb = torch.nn.Embedding(60, 24).cuda()
+    q = torch.randint(0, 60, (5, 9), generator=torch.Generator().manual_seed(3)).cuda()
+    up = torch.randn((5, 9, 24), generator=torch.Generator().manual_seed(4)).cuda()
+    y = fns.embed_tanh(emb, q)
+    y.backward(up)
+    g_hip, emb.weight.grad = emb.weight.grad.clone(), None
+    y2 = torch.tanh(emb(q))
+    y2.backward(up)
+    assert _rel(y, y2.detach().double().cpu()) <= 2e-6 and _rel(g_hip, emb.weight.grad.double().cpu()) <= 2e-6
+    assert type(y.grad_fn).__name__.startswith("EmbedTanhFn")
+    pad = torch.nn.Embedding(60, 24, padding_idx=0).cuda()
+    assert not type(fns.embed_tanh(pad, q).grad_fn).__name__.startswith("EmbedTanhFn")

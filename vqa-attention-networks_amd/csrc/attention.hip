@@ -161,6 +161,14 @@ __global__ void att_logits_bwd_kernel(const float* __restrict__ dl, const float*
   }
 }
 
+__global__ void split_reduced_row_kernel(const float* __restrict__ red, int n0, int n1, int n2, float* __restrict__ d0,
+                                         float* __restrict__ d1, float* __restrict__ d2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n0) d0[i] = red[i];
+  else if (i < n0 + n1) { if (d1) d1[i - n0] = red[i]; }
+  else if (i < n0 + n1 + n2) d2[i - n0 - n1] = red[i];
+}
+
 // feature element loaders: the pooled tensor is fp32 or (bf16 feature storage) bf16
 template <typename FT> __device__ __forceinline__ f32x4 load4(const FT* p);
 template <> __device__ __forceinline__ f32x4 load4<float>(const float* p) {
@@ -383,14 +391,10 @@ int vqf_att_logits_bwd_rowscale(const float* dlogits, const float* hid, const fl
   if (rc) return rc;
   rc = vqf_colreduce_2stage(part, nb, pw, red, red + pw, s);
   if (rc) return rc;
-  hipError_t e = hipMemcpyAsync(dw2, red, (size_t)G * Hh * sizeof(float), hipMemcpyDeviceToDevice, s);
-  if (e != hipSuccess) return (int)e;
-  if (dbias1) {
-    e = hipMemcpyAsync(dbias1, red + G * Hh, (size_t)Hh * sizeof(float), hipMemcpyDeviceToDevice, s);
-    if (e != hipSuccess) return (int)e;
-  }
-  e = hipMemcpyAsync(db2, red + (G + 1) * Hh, G * sizeof(float), hipMemcpyDeviceToDevice, s);
-  return e == hipSuccess ? VQF_OK : (int)e;
+  // the reduced row [dw2 (G*Hh) | dbias1 (Hh) | db2 (G)] -> its three destinations, one launch (was three device copies)
+  hipLaunchKernelGGL(split_reduced_row_kernel, dim3(((G + 1) * Hh + G + 255) / 256), dim3(256), 0, s, red, G * Hh, Hh, G, dw2,
+                     dbias1, db2);
+  return vqf_last_error();
 }
 
 }  // extern "C"

@@ -42,6 +42,8 @@ enum VqfKernelId {
   KID_FEAT_TRANSPOSE,
   KID_LSTM_CELL_FWD,
   KID_LSTM_CELL_BWD,
+  KID_EMBED_FWD,
+  KID_EMBED_BWD,
   KID_COUNT
 };
 

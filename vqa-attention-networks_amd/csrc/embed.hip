@@ -1,0 +1,110 @@
+// Question-encoder front end: e = tanh(Embedding(q)) and its backward.
+//
+//   mfb.py:68 / mhb_coAtt.py:69   que_embedded = F.tanh(self.word_embedding(questions))
+//
+// forward : out[t, :] = tanh(W[ids[t], :])                       one wave per token row, 16-byte accesses when E % 4 == 0
+// backward: dW[v, :] = sum_{t: ids[t] == v} dout[t, :] * (1 - out[t, :]^2)        for EVERY vocabulary row v (zeros where unused)
+//   One workgroup per vocabulary row: its four waves scan 2048 token ids per round (512 each, ballot) and list the matching
+//   tokens in LDS in increasing order; the workgroup then adds their rows column-parallel in that order.  No atomics, no sort: the sum
+//   order is the token order, the same on every run (torch's embedding backward sorts the indices and runs ~20 small kernels,
+//   ~0.1 ms of the MFB train step; this is one launch of ~10 us).
+// Ids outside [0, V) select no row: the forward writes zeros for them, the backward ignores them (the reference's ids come
+// from its own vocabulary, utils.py:185,303-304; torch would raise).
+#include "common.h"
+
+namespace {
+
+__global__ void embed_tanh_fwd_kernel(const float* __restrict__ W, const long long* __restrict__ ids, int T, int V, int E,
+                                      float* __restrict__ out) {
+  const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (t >= T) return;
+  const int lane = threadIdx.x & 63;
+  const long long id = ids[t];
+  const bool ok = id >= 0 && id < V;
+  const float* w = W + (ok ? id : 0) * (long long)E;
+  float* o = out + (long long)t * E;
+  if ((E & 3) == 0 && aligned16_dev(W) && aligned16_dev(out)) {
+    for (int c = lane * 4; c < E; c += 256) {
+      f32x4 x = ok ? *reinterpret_cast<const f32x4*>(w + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 y = {tanhf(x[0]), tanhf(x[1]), tanhf(x[2]), tanhf(x[3])};
+      *reinterpret_cast<f32x4*>(o + c) = y;
+    }
+  } else {
+    for (int c = lane; c < E; c += 64) o[c] = ok ? tanhf(w[c]) : 0.f;
+  }
+}
+
+constexpr int EB_CHUNK = 2048;     // token ids scanned per round: 512 per wave (the match lists live in LDS)
+
+__global__ void __launch_bounds__(256) embed_tanh_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+                                                            const long long* __restrict__ ids, int T, int E,
+                                                            float* __restrict__ dW) {
+  __shared__ int list[4][EB_CHUNK / 4];
+  __shared__ int count[4];
+  const int v = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // every thread owns columns tid, tid + 256, ... (E <= 1024: at most 4)
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int t0 = 0; t0 < T; t0 += EB_CHUNK) {
+    {                                                    // wave w lists the matches among tokens t0 + 512 w .. + 511, in order
+      const int b0 = t0 + wave * (EB_CHUNK / 4);
+      long long idv[EB_CHUNK / 4 / 64];
+#pragma unroll
+      for (int r = 0; r < EB_CHUNK / 4 / 64; ++r) {      // the 8 id loads of a wave are issued together
+        const int t = b0 + 64 * r + lane;
+        idv[r] = t < T ? ids[t] : -1;
+      }
+      int n = 0;
+#pragma unroll
+      for (int r = 0; r < EB_CHUNK / 4 / 64; ++r) {
+        const bool hit = idv[r] == (long long)v;
+        const unsigned long long m = __ballot(hit);
+        if (hit) list[wave][n + __popcll(m & ((1ull << lane) - 1ull))] = b0 + 64 * r + lane;
+        n += __popcll(m);
+      }
+      if (lane == 0) count[wave] = n;
+    }
+    __syncthreads();
+    for (int w = 0; w < 4; ++w) {                        // wave lists in wave order = token order: a fixed summation order
+      const int n = count[w];
+      for (int i = 0; i < n; ++i) {
+        const long long row = (long long)list[w][i] * E;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int c = tid + 256 * k;
+          if (c < E) {
+            const float y = out[row + c];
+            acc[k] += dout[row + c] * (1.0f - y * y);
+          }
+        }
+      }
+    }
+    __syncthreads();                                     // the lists are rewritten in the next round
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = tid + 256 * k;
+    if (c < E) dW[(long long)v * E + c] = acc[k];
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int vqf_embed_tanh_fwd(const float* W, const long long* ids, int T, int V, int E, float* out, void* stream) {
+  if (!W || !ids || !out || T <= 0 || V <= 0 || E <= 0) return VQF_E_BADARG;
+  vqf_prof_dims(T, V, E);
+  VQF_LAUNCH(KID_EMBED_FWD, embed_tanh_fwd_kernel, dim3((T + 3) / 4), dim3(256), 0, (hipStream_t)stream, W, ids, T, V, E, out);
+  return vqf_last_error();
+}
+
+int vqf_embed_tanh_bwd(const float* dout, const float* out, const long long* ids, int T, int V, int E, float* dW,
+                       void* stream) {
+  if (!dout || !out || !ids || !dW || T <= 0 || V <= 0 || E <= 0) return VQF_E_BADARG;
+  if (E > 1024) return VQF_E_UNSUPPORTED;
+  vqf_prof_dims(T, V, E);
+  VQF_LAUNCH(KID_EMBED_BWD, embed_tanh_bwd_kernel, dim3(V), dim3(256), 0, (hipStream_t)stream, dout, out, ids, T, E, dW);
+  return vqf_last_error();
+}
+
+}  // extern "C"

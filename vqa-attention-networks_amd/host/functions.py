@@ -27,6 +27,34 @@ def _bf16_ok(*dims):
     return all(d % 8 == 0 for d in dims)
 
 
+class EmbedTanhFn(torch.autograd.Function):
+    """que_embedded = tanh(word_embedding(questions))   (mfb.py:68, mhb_coAtt.py:69): gather + tanh in one launch, and a
+    deterministic one-launch weight gradient (csrc/embed.hip) instead of torch's sort-based embedding backward."""
+
+    @staticmethod
+    def forward(ctx, ids, weight):
+        ids = ids.contiguous()
+        out = ops.embed_tanh_fwd(_c(weight), ids)
+        ctx.save_for_backward(ids, out)
+        ctx.V = weight.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        ids, out = ctx.saved_tensors
+        return None, ops.embed_tanh_bwd(_c(dout), out, ids, ctx.V)
+
+
+def embed_tanh(embedding, ids):
+    """tanh(embedding(ids)) on the HIP path when the nn.Embedding is a plain lookup (no padding_idx / max_norm / sparse grads /
+    frequency scaling) with an fp32 GPU weight of width <= 1024; torch otherwise."""
+    w = embedding.weight
+    if (w.is_cuda and w.dtype == torch.float32 and ids.is_cuda and ids.dtype == torch.int64 and embedding.padding_idx is None
+            and embedding.max_norm is None and not embedding.sparse and not embedding.scale_grad_by_freq and w.shape[1] <= 1024):
+        return EmbedTanhFn.apply(ids, w)
+    return torch.tanh(embedding(ids))
+
+
 class NormLink:
     """F.normalize folded into its consumer (mfb.py:105-109: fusion_normed is consumed by co_att_conv1 alone).
 

@@ -3,16 +3,16 @@
 Mirrors the reference interface (mfb.py:6-140): `MFB(cfg)`,
 `forward(img_features, questions, is_training=True) -> logits (N, a_vocab_size)`,
 identical state_dict keys/shapes, so it drops into solver.py / train_models.py.
-Embedding lookup, tanh and dropout_l of the question encoder (mfb.py:68-70) are
-PyTorch-ROCm element-wise ops; its LSTM recursion and everything from the question
-attention to the logits run in libvqa_fusion.so (`use_hip_lstm = False` puts the LSTM
-back on nn.LSTM / MIOpen).
+The question encoder's embedding lookup + tanh (mfb.py:68, csrc/embed.hip), its LSTM
+recursion and everything from the question attention to the logits run in
+libvqa_fusion.so (`use_hip_lstm = False` puts the LSTM back on nn.LSTM / MIOpen);
+dropout_l (mfb.py:70) is torch's nn.Dropout.
 """
 import torch
 import torch.nn as nn
 
 from .functions import (LinearFn, AttHeadFn, ImgFuseFn, ImgProjFn, ImgProjLateFn, ImgProjDeferFn, MfbFuseFn, FinalMfbFn,
-                        LstmBatchFn, UnitPoolFn, DeadParamsFn, NormLink, img_project)
+                        LstmBatchFn, UnitPoolFn, DeadParamsFn, NormLink, img_project, embed_tanh)
 
 
 def _image_is_data(img, gemm_dtype="fp32"):
@@ -241,7 +241,7 @@ class MFB(nn.Module):
         proj = self._side.project(img_features, self.img_conv1d, bf16_img,
                                   self.overlap_streams == "same-stream", self.side_cu_limit) if side else None
         # a2: question encoder                                               mfb.py:68-70
-        que_embedded = torch.tanh(self.word_embedding(questions))
+        que_embedded = embed_tanh(self.word_embedding, questions)
         lstm_o = batch_first_lstm(self.lstm, que_embedded, self.use_hip_lstm, _lstm_bf16(self.gemm_dtype))
         ques_feature = self.dropout_l(lstm_o).contiguous()                 # (N,T,H)
         N, T, H = ques_feature.shape

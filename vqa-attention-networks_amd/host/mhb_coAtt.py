@@ -9,7 +9,7 @@ import torch.nn as nn
 
 from . import ops
 from .functions import (LinearFn, AttHeadFn, ImgFuseFn, MfbFuseFn, FinalMfbFn, LstmSeqFn, LstmBatchFn, LogSoftmaxRowsFn,
-                        NormLink)
+                        NormLink, embed_tanh)
 from .mfb import _DropSeeds, _image_is_data, _SideStream, _lstm_bf16, batch_first_lstm, warn_once
 
 
@@ -62,7 +62,7 @@ class MHBCoAtt(nn.Module):
         side = self.overlap_streams and not (bf16_img and self.fuse_bf16_dp and not (self.overlap_streams is True and self.side_bf16))
         proj = self._side.project(img_features, self.img_conv1d, bf16_img,
                                   self.overlap_streams == "same-stream", self.side_cu_limit) if side else None
-        que_embedded = torch.tanh(self.word_embedding(questions))            # (N,T,E)
+        que_embedded = embed_tanh(self.word_embedding, questions)            # (N,T,E)
         if self.cfg.glove:
             assert glove_matrix is not None, 'glove should not be NoneType.'
             que_embedded = torch.cat((que_embedded, glove_matrix), dim=2)

@@ -579,6 +579,36 @@ def lstm_persist_status(device=None):
 
 
 # ---------------------------------------------------------------------------
+# question-encoder front end (mfb.py:68)
+def _chk_ids(ids):
+    if not ids.is_cuda or ids.dtype != torch.int64 or not ids.is_contiguous():
+        raise _l.VqfError("contiguous int64 GPU token ids expected")
+
+
+def embed_tanh_fwd(weight, ids):
+    """tanh(weight[ids]): weight (V,E) fp32, ids any shape int64 -> ids.shape + (E,)"""
+    _chk(weight)
+    _chk_ids(ids)
+    V, E = weight.shape
+    T = ids.numel()
+    out = torch.empty(tuple(ids.shape) + (E,), dtype=torch.float32, device=weight.device)
+    _l.check(_lib().vqf_embed_tanh_fwd(_ptr(weight), ctypes.c_void_p(ids.data_ptr()), T, V, E, _ptr(out), _stream()),
+             "vqf_embed_tanh_fwd")
+    return out
+
+
+def embed_tanh_bwd(dout, out, ids, V):
+    """-> dW (V,E): deterministic segment sum of dout * (1 - out^2) over the tokens of each id"""
+    _chk(dout, out)
+    _chk_ids(ids)
+    E = out.shape[-1]
+    dW = torch.empty((V, E), dtype=torch.float32, device=out.device)
+    _l.check(_lib().vqf_embed_tanh_bwd(_ptr(dout), _ptr(out), ctypes.c_void_p(ids.data_ptr()), ids.numel(), V, E, _ptr(dW),
+                                       _stream()), "vqf_embed_tanh_bwd")
+    return dW
+
+
+# ---------------------------------------------------------------------------
 # input staging (data_loader.py:30-32)
 def feat_transpose(src, out=None, bf16=False):
     """src (N, D, L) fp32 as stored by the feature extractor -> (N, L, D) fp32 | bf16."""
