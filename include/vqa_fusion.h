@@ -382,6 +382,9 @@ int vqf_lstm_persist_status(const void* ws, void* stream);
 int vqf_embed_tanh_fwd(const float* W, const long long* ids, int T, int V, int E, float* out, void* stream);
 int vqf_embed_tanh_bwd(const float* dout, const float* out, const long long* ids, int T, int V, int E, float* dW,
                        void* stream);
+/* the plain lookup e = Embedding(q) and its weight gradient (hieCoAtten.py:27, networks.py:23,56, mhb_coAtt.py:181) */
+int vqf_embed_fwd(const float* W, const long long* ids, int T, int V, int E, float* out, void* stream);
+int vqf_embed_bwd(const float* dout, const long long* ids, int T, int V, int E, float* dW, void* stream);
 
 /* --------------------------------------------------------------------------
  * Input staging.  data_loader.py:30-32 loads one [2048,14,14] .npy per image

@@ -401,3 +401,19 @@ def test_embed_tanh_module_path_matches_torch_embedding(ops):
     assert type(y.grad_fn).__name__.startswith("EmbedTanhFn")
     pad = torch.nn.Embedding(60, 24, padding_idx=0).cuda()
     assert not type(fns.embed_tanh(pad, q).grad_fn).__name__.startswith("EmbedTanhFn")
+
+
+def test_embed_plain_lookup_is_exact(ops):
+    """functions.embed (hieCoAtten.py:27, networks.py:23,56, mhb_coAtt.py:181): the lookup is a copy (bitwise torch's); the weight
+    gradient is the token-ordered segment sum, vs torch in fp64, and bit-reproducible."""
+    import vqa_amd
+    fns = vqa_amd.functions
+    emb = torch.nn.Embedding(300, 40).cuda()
+    q = torch.randint(0, 300, (7, 22), generator=torch.Generator().manual_seed(5)).cuda()
+    up = torch.randn((7, 22, 40), generator=torch.Generator().manual_seed(6)).cuda()
+    y = fns.embed(emb, q)
+    assert type(y.grad_fn).__name__.startswith("EmbedTanhFn") and torch.equal(y.detach(), emb(q).detach())
+    y.backward(up)
+    ref = torch.zeros((300, 40), dtype=torch.float64).index_add_(0, q.cpu().reshape(-1), up.double().cpu().reshape(-1, 40))
+    assert _rel(emb.weight.grad, ref) <= 1e-6
+    assert torch.equal(emb.weight.grad, ops.embed_tanh_bwd(up, None, q, 300))

@@ -1,6 +1,7 @@
-// Question-encoder front end: e = tanh(Embedding(q)) and its backward.
+// Question-encoder front end: e = tanh(Embedding(q)) or e = Embedding(q), and the backward.
 //
 //   mfb.py:68 / mhb_coAtt.py:69   que_embedded = F.tanh(self.word_embedding(questions))
+//   hieCoAtten.py:27, networks.py:23,56, mhb_coAtt.py:181   plain lookups (vqf_embed_fwd / _bwd: the same kernels without the tanh)
 //
 // forward : out[t, :] = tanh(W[ids[t], :])                       one wave per token row, 16-byte accesses when E % 4 == 0
 // backward: dW[v, :] = sum_{t: ids[t] == v} dout[t, :] * (1 - out[t, :]^2)        for EVERY vocabulary row v (zeros where unused)
@@ -14,7 +15,8 @@
 
 namespace {
 
-__global__ void embed_tanh_fwd_kernel(const float* __restrict__ W, const long long* __restrict__ ids, int T, int V, int E,
+template <bool TANH>
+__global__ void embed_fwd_kernel(const float* __restrict__ W, const long long* __restrict__ ids, int T, int V, int E,
                                       float* __restrict__ out) {
   const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (t >= T) return;
@@ -26,17 +28,19 @@ __global__ void embed_tanh_fwd_kernel(const float* __restrict__ W, const long lo
   if ((E & 3) == 0 && aligned16_dev(W) && aligned16_dev(out)) {
     for (int c = lane * 4; c < E; c += 256) {
       f32x4 x = ok ? *reinterpret_cast<const f32x4*>(w + c) : f32x4{0.f, 0.f, 0.f, 0.f};
-      f32x4 y = {tanhf(x[0]), tanhf(x[1]), tanhf(x[2]), tanhf(x[3])};
+      f32x4 y = x;
+      if (TANH) y = f32x4{tanhf(x[0]), tanhf(x[1]), tanhf(x[2]), tanhf(x[3])};
       *reinterpret_cast<f32x4*>(o + c) = y;
     }
   } else {
-    for (int c = lane; c < E; c += 64) o[c] = ok ? tanhf(w[c]) : 0.f;
+    for (int c = lane; c < E; c += 64) o[c] = ok ? (TANH ? tanhf(w[c]) : w[c]) : 0.f;
   }
 }
 
 constexpr int EB_CHUNK = 2048;     // token ids scanned per round: 512 per wave (the match lists live in LDS)
 
-__global__ void __launch_bounds__(256) embed_tanh_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+template <bool TANH>
+__global__ void __launch_bounds__(256) embed_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
                                                             const long long* __restrict__ ids, int T, int E,
                                                             float* __restrict__ dW) {
   __shared__ int list[4][EB_CHUNK / 4];
@@ -72,8 +76,12 @@ __global__ void __launch_bounds__(256) embed_tanh_bwd_kernel(const float* __rest
         for (int k = 0; k < 4; ++k) {
           const int c = tid + 256 * k;
           if (c < E) {
-            const float y = out[row + c];
-            acc[k] += dout[row + c] * (1.0f - y * y);
+            if (TANH) {
+              const float y = out[row + c];
+              acc[k] += dout[row + c] * (1.0f - y * y);
+            } else {
+              acc[k] += dout[row + c];
+            }
           }
         }
       }
@@ -94,7 +102,7 @@ extern "C" {
 int vqf_embed_tanh_fwd(const float* W, const long long* ids, int T, int V, int E, float* out, void* stream) {
   if (!W || !ids || !out || T <= 0 || V <= 0 || E <= 0) return VQF_E_BADARG;
   vqf_prof_dims(T, V, E);
-  VQF_LAUNCH(KID_EMBED_FWD, embed_tanh_fwd_kernel, dim3((T + 3) / 4), dim3(256), 0, (hipStream_t)stream, W, ids, T, V, E, out);
+  VQF_LAUNCH(KID_EMBED_FWD, embed_fwd_kernel<true>, dim3((T + 3) / 4), dim3(256), 0, (hipStream_t)stream, W, ids, T, V, E, out);
   return vqf_last_error();
 }
 
@@ -103,7 +111,23 @@ int vqf_embed_tanh_bwd(const float* dout, const float* out, const long long* ids
   if (!dout || !out || !ids || !dW || T <= 0 || V <= 0 || E <= 0) return VQF_E_BADARG;
   if (E > 1024) return VQF_E_UNSUPPORTED;
   vqf_prof_dims(T, V, E);
-  VQF_LAUNCH(KID_EMBED_BWD, embed_tanh_bwd_kernel, dim3(V), dim3(256), 0, (hipStream_t)stream, dout, out, ids, T, E, dW);
+  VQF_LAUNCH(KID_EMBED_BWD, embed_bwd_kernel<true>, dim3(V), dim3(256), 0, (hipStream_t)stream, dout, out, ids, T, E, dW);
+  return vqf_last_error();
+}
+
+int vqf_embed_fwd(const float* W, const long long* ids, int T, int V, int E, float* out, void* stream) {
+  if (!W || !ids || !out || T <= 0 || V <= 0 || E <= 0) return VQF_E_BADARG;
+  vqf_prof_dims(T, V, E);
+  VQF_LAUNCH(KID_EMBED_FWD, embed_fwd_kernel<false>, dim3((T + 3) / 4), dim3(256), 0, (hipStream_t)stream, W, ids, T, V, E, out);
+  return vqf_last_error();
+}
+
+int vqf_embed_bwd(const float* dout, const long long* ids, int T, int V, int E, float* dW, void* stream) {
+  if (!dout || !ids || !dW || T <= 0 || V <= 0 || E <= 0) return VQF_E_BADARG;
+  if (E > 1024) return VQF_E_UNSUPPORTED;
+  vqf_prof_dims(T, V, E);
+  const float* none = nullptr;
+  VQF_LAUNCH(KID_EMBED_BWD, embed_bwd_kernel<false>, dim3(V), dim3(256), 0, (hipStream_t)stream, dout, none, ids, T, E, dW);
   return vqf_last_error();
 }
 

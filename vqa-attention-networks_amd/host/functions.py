@@ -32,27 +32,38 @@ class EmbedTanhFn(torch.autograd.Function):
     deterministic one-launch weight gradient (csrc/embed.hip) instead of torch's sort-based embedding backward."""
 
     @staticmethod
-    def forward(ctx, ids, weight):
+    def forward(ctx, ids, weight, tanh=True):
         ids = ids.contiguous()
-        out = ops.embed_tanh_fwd(_c(weight), ids)
-        ctx.save_for_backward(ids, out)
+        out = ops.embed_tanh_fwd(_c(weight), ids, tanh)
+        ctx.save_for_backward(ids, out if tanh else None)
         ctx.V = weight.shape[0]
         return out
 
     @staticmethod
     def backward(ctx, dout):
         ids, out = ctx.saved_tensors
-        return None, ops.embed_tanh_bwd(_c(dout), out, ids, ctx.V)
+        return None, ops.embed_tanh_bwd(_c(dout), out, ids, ctx.V), None
+
+
+def _plain_embedding(embedding, ids):
+    w = embedding.weight
+    return (w.is_cuda and w.dtype == torch.float32 and ids.is_cuda and ids.dtype == torch.int64 and embedding.padding_idx is None
+            and embedding.max_norm is None and not embedding.sparse and not embedding.scale_grad_by_freq and w.shape[1] <= 1024)
 
 
 def embed_tanh(embedding, ids):
     """tanh(embedding(ids)) on the HIP path when the nn.Embedding is a plain lookup (no padding_idx / max_norm / sparse grads /
     frequency scaling) with an fp32 GPU weight of width <= 1024; torch otherwise."""
-    w = embedding.weight
-    if (w.is_cuda and w.dtype == torch.float32 and ids.is_cuda and ids.dtype == torch.int64 and embedding.padding_idx is None
-            and embedding.max_norm is None and not embedding.sparse and not embedding.scale_grad_by_freq and w.shape[1] <= 1024):
-        return EmbedTanhFn.apply(ids, w)
+    if _plain_embedding(embedding, ids):
+        return EmbedTanhFn.apply(ids, embedding.weight, True)
     return torch.tanh(embedding(ids))
+
+
+def embed(embedding, ids):
+    """embedding(ids) (hieCoAtten.py:27, networks.py:23,56, mhb_coAtt.py:181) on the HIP path under the same conditions."""
+    if _plain_embedding(embedding, ids):
+        return EmbedTanhFn.apply(ids, embedding.weight, False)
+    return embedding(ids)
 
 
 class NormLink:

@@ -10,7 +10,7 @@ state_dict keys.  Reference behaviour kept on purpose:
 import torch
 import torch.nn as nn
 
-from .functions import LinearFn, DropoutFn, TanhDropFn, BmmFn, AttPoolFn
+from .functions import LinearFn, DropoutFn, TanhDropFn, BmmFn, AttPoolFn, embed
 from .mfb import _DropSeeds
 
 
@@ -46,7 +46,7 @@ class HieCoAtten(nn.Module):
         img = lin(img_features.reshape(N * L, D), self.img_emb, True)          # :25-26 (relu fused)
         img = DropoutFn.apply(img, *self._drop_args('img'))
         E = img.shape[1]
-        que = self.que_emb(que_features).reshape(N * T, E)                      # :27
+        que = embed(self.que_emb, que_features).reshape(N * T, E)                      # :27
         que = DropoutFn.apply(que, *self._drop_args('que'))                     # :28
 
         Cv = lin(img, self.fc_Wbv)                                              # :30

@@ -9,7 +9,7 @@ import torch.nn as nn
 
 from . import ops
 from .functions import (LinearFn, AttHeadFn, ImgFuseFn, MfbFuseFn, FinalMfbFn, LstmSeqFn, LstmBatchFn, LogSoftmaxRowsFn,
-                        NormLink, embed_tanh)
+                        NormLink, embed_tanh, embed)
 from .mfb import _DropSeeds, _image_is_data, _SideStream, _lstm_bf16, batch_first_lstm, warn_once
 
 
@@ -156,7 +156,7 @@ class MHB(nn.Module):
         L = img3.shape[1]
         _, i_sum = ops.glimpse_pool_fwd(img3, torch.zeros((batch_size * L, 1), device=img3.device), True)
         i_mean = i_sum * (1.0 / L)
-        q_embedded = self.Embedding(questions).permute(1, 0, 2)              # (T,N,E)  :181-182
+        q_embedded = embed(self.Embedding, questions).permute(1, 0, 2)              # (T,N,E)  :181-182
         if (self.use_hip_lstm and q_embedded.is_cuda and self.LSTM.num_layers == 1 and not self.LSTM.bidirectional
                 and self.LSTM.hidden_size % 4 == 0):
             lstm_outs = LstmBatchFn.apply(q_embedded.contiguous(), self.LSTM.weight_ih_l0, self.LSTM.weight_hh_l0,

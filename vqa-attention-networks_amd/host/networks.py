@@ -12,7 +12,7 @@ Parameter names (and therefore state_dict keys) are the reference's:
 import torch
 import torch.nn as nn
 
-from .functions import LinearFn, DropoutFn
+from .functions import LinearFn, DropoutFn, embed
 from .modules import Attention_layer
 from .mfb import _DropSeeds
 
@@ -62,7 +62,7 @@ class iBOWIMG(nn.Module, _AlwaysDropout):
     def forward(self, img_features, que_features):
         image = torch.relu(self.img_bn(_linear(self.img_emb, img_features)))      # :17-21
         image = self._drop(image, 'img')                                          # :22
-        words = self._drop_tokens(self.que_emb(que_features), 'que')              # :23-24
+        words = self._drop_tokens(embed(self.que_emb, que_features), 'que')       # :23-24
         bag = words.sum(dim=1)                                                    # :25
         return _linear(self.fc, torch.cat((image, bag), dim=1))                   # :26-28
 
@@ -91,7 +91,7 @@ class AttentionNet(nn.Module, _AlwaysDropout):
         n, regions, channels = img_features.shape
         image = _linear(self.img_emb, img_features.reshape(n * regions, channels), relu=True)   # :51-54
         image = self._drop(image, 'img').view(n, regions, -1)                                   # :55
-        words = self._drop_tokens(self.que_emb(que_features), 'que')                            # :56-57
+        words = self._drop_tokens(embed(self.que_emb, que_features), 'que')                     # :56-57
         que_att = img_att = None
         for idx in range(self.att_num):                                                         # :58-62
             if idx % 2 == 0:

@@ -585,26 +585,30 @@ def _chk_ids(ids):
         raise _l.VqfError("contiguous int64 GPU token ids expected")
 
 
-def embed_tanh_fwd(weight, ids):
-    """tanh(weight[ids]): weight (V,E) fp32, ids any shape int64 -> ids.shape + (E,)"""
+def embed_tanh_fwd(weight, ids, tanh=True):
+    """tanh(weight[ids]) (tanh=False: weight[ids]): weight (V,E) fp32, ids any shape int64 -> ids.shape + (E,)"""
     _chk(weight)
     _chk_ids(ids)
     V, E = weight.shape
     T = ids.numel()
     out = torch.empty(tuple(ids.shape) + (E,), dtype=torch.float32, device=weight.device)
-    _l.check(_lib().vqf_embed_tanh_fwd(_ptr(weight), ctypes.c_void_p(ids.data_ptr()), T, V, E, _ptr(out), _stream()),
-             "vqf_embed_tanh_fwd")
+    fn = _lib().vqf_embed_tanh_fwd if tanh else _lib().vqf_embed_fwd
+    _l.check(fn(_ptr(weight), ctypes.c_void_p(ids.data_ptr()), T, V, E, _ptr(out), _stream()), "vqf_embed_fwd")
     return out
 
 
 def embed_tanh_bwd(dout, out, ids, V):
-    """-> dW (V,E): deterministic segment sum of dout * (1 - out^2) over the tokens of each id"""
+    """-> dW (V,E): deterministic segment sum of dout * (1 - out^2) over the tokens of each id (out=None: of dout, the plain lookup)"""
     _chk(dout, out)
     _chk_ids(ids)
-    E = out.shape[-1]
-    dW = torch.empty((V, E), dtype=torch.float32, device=out.device)
-    _l.check(_lib().vqf_embed_tanh_bwd(_ptr(dout), _ptr(out), ctypes.c_void_p(ids.data_ptr()), ids.numel(), V, E, _ptr(dW),
-                                       _stream()), "vqf_embed_tanh_bwd")
+    E = dout.shape[-1]
+    dW = torch.empty((V, E), dtype=torch.float32, device=dout.device)
+    if out is None:
+        _l.check(_lib().vqf_embed_bwd(_ptr(dout), ctypes.c_void_p(ids.data_ptr()), ids.numel(), V, E, _ptr(dW), _stream()),
+                 "vqf_embed_bwd")
+    else:
+        _l.check(_lib().vqf_embed_tanh_bwd(_ptr(dout), _ptr(out), ctypes.c_void_p(ids.data_ptr()), ids.numel(), V, E, _ptr(dW),
+                                           _stream()), "vqf_embed_tanh_bwd")
     return dW
 
 
