@@ -484,6 +484,9 @@ def main():
                     "'gloo' lets several ranks share one GPU for rehearsals")
     ap.add_argument("--gemm-workgroups", default=None, choices=["per-tile", "persistent"],
                     help="large-tile GEMM launch form under data parallelism (default: per-tile at N > 1, see host/parallel.py)")
+    ap.add_argument("--one-rank-group", action="store_true",
+                    help="N = 1 only: run the data-parallel machinery anyway (a one-rank RCCL group, buckets, hooks, per-tile "
+                         "GEMM launches): what data parallelism costs a rank before any byte crosses xGMI")
     args = ap.parse_args()
 
     import vqa_amd
@@ -494,7 +497,7 @@ def main():
 
     if args.no_defer:
         import_module("vqa-attention-networks_amd.host.mfb")._SideStream.DEFER = False
-    rank, world, local = parallel.init_distributed(args.backend)
+    rank, world, local = parallel.init_distributed(args.backend, force=args.one_rank_group)
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N ranks with `python -m torch.distributed.run "
                          "--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...`"
@@ -509,7 +512,8 @@ def main():
     if args.model == "hieCoAtten" and args.batch == 512:
         B = 256                                       # BASELINE config 4
     wl = Workload(vqa_amd, args.model, args.dtype, B, rank, dev, args)
-    reducer = parallel.GradientAllReducer(wl.model, gemm_workgroups=args.gemm_workgroups)   # broadcasts rank 0's weights; no-op at world 1
+    reducer = parallel.GradientAllReducer(wl.model, gemm_workgroups=args.gemm_workgroups,   # broadcasts rank 0's weights; no-op at world 1
+                                          single_rank=args.one_rank_group)
     wl.reducer = reducer
 
     def fence():
@@ -628,7 +632,7 @@ def main():
         }
     headline_default = (args.model == "mfb" and args.dtype == "f32" and B == 512 and not args.pruned
                         and not args.forward_only and not args.miopen_lstm)
-    if world == 1 and headline_default and not args.no_secondary:
+    if world == 1 and headline_default and not args.no_secondary and not args.one_rank_group:
         wl.free()
         del reducer
         out["secondary"] = {}
@@ -638,11 +642,11 @@ def main():
             except Exception as e:          # the headline line must survive a secondary failure; say what happened
                 out["secondary"][which] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.one_rank_group:
             out["cpu_baseline"] = cpu_baseline(batch=args.cpu_batch)
             out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

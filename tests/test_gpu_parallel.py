@@ -130,6 +130,74 @@ def test_two_rank_gradients_equal_shardwise_and_full_batch_gradients():
         assert float((g - ref).norm()) <= tol * float(ref.norm()) + 1e-7, (k, float((g - ref).norm()), float(ref.norm()))
 
 
+def _rccl_worker(store, q_out):
+    try:
+        os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+        vqa, model, img, q, a = _model_and_data(live=True)
+        from importlib import import_module
+        par = import_module("vqa-attention-networks_amd.host.parallel")
+
+        def grads(reducer):
+            out = []
+            for step in range(3):
+                model.zero_grad(set_to_none=True)
+                torch.nn.functional.cross_entropy(model.forward(img, q), a).backward()
+                if reducer is not None:
+                    reducer.finish()
+                torch.cuda.synchronize()
+                out.append({k: p.grad.detach().clone() for k, p in model.named_parameters()})
+            return out
+        plain = grads(None)
+        par.init_distributed(backend="nccl", init_method="file://" + store, force=True)
+        info = dict(backend=dist.get_backend(), world=dist.get_world_size())
+        for mode in ("same-stream", True):                  # gradients of one bucket produced on one / on two streams
+            model.overlap_streams = mode
+            with par.GradientAllReducer(model, bucket_bytes=1 << 20, single_rank=True) as red:
+                red.timing = True
+                got = grads(red)
+                info["buckets"] = len(red.buckets)
+                info["exposed_%s" % mode] = red.exposed_ms()
+                info["workgroups_%s" % mode] = red.gemm_workgroups()
+            for step, (g, ref) in enumerate(zip(got, plain)):
+                for k in ref:
+                    if not torch.equal(g[k], ref[k]):
+                        raise AssertionError("mode %s step %d: %s differs after the one-rank RCCL all-reduce" % (mode, step, k))
+        info["workgroups_after"] = par.GradientAllReducer(model).gemm_workgroups()
+        dist.barrier()
+        dist.destroy_process_group()
+        q_out.put(("ok", info))
+    except Exception:
+        q_out.put(("error", traceback.format_exc()))
+        raise
+
+
+def test_reducer_over_rccl_in_a_one_rank_group_leaves_gradients_bit_identical():
+    """The collective backend the driver's N > 1 runs use (nccl = RCCL), as far as ONE GPU allows: a one-rank RCCL group,
+    reducer forced on (single_rank=True).  The averaged gradients of three steps -- asynchronous collectives on RCCL's
+    stream, ordered against the compute / side streams by events -- must equal the plain gradients BIT for bit in both
+    stream modes; the exposed-tail timing returns one entry per bucket; the GEMM launch form is one workgroup per tile
+    while the reducer lives and restored afterwards."""
+    ctx = mp.get_context("spawn")
+    qo = ctx.Queue()
+    with tempfile.TemporaryDirectory(prefix="vqf_rccl_") as d:
+        p = ctx.Process(target=_rccl_worker, args=(os.path.join(d, "store"), qo))
+        p.start()
+        try:
+            status, info = qo.get(timeout=300)
+            assert status == "ok", info
+            p.join(timeout=120)
+            assert p.exitcode == 0
+        finally:
+            if p.is_alive():
+                p.kill()
+    assert info["backend"] == "nccl" and info["world"] == 1 and info["buckets"] > 1
+    for mode in ("same-stream", True):
+        assert len(info["exposed_%s" % mode]) == info["buckets"]
+        assert info["workgroups_%s" % mode]["f32"] == "one per tile"
+    assert info["workgroups_after"]["f32"] == "persistent, one per CU"
+    print("one-rank RCCL reducer:", info)
+
+
 def test_same_stream_mode_runs_the_projection_weight_gradient_last():
     """bench.py's default stream configuration at every N ('same-stream'): the image projection is its own autograd
     node created FIRST, so autograd runs its backward -- the 15 ms weight-gradient GEMM -- LAST; every other

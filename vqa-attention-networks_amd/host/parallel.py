@@ -18,8 +18,9 @@ import torch
 import torch.distributed as dist
 
 
-def init_distributed(backend=None, init_method=None):
+def init_distributed(backend=None, init_method=None, force=False):
     """Initialise torch.distributed from the torchrun environment.  Returns (rank, world, local_rank).
+    force: create the process group at WORLD_SIZE 1 too (a one-rank RCCL group: the rehearsal a one-GPU box allows).
 
     `init_method` (or the environment variable VQF_DIST_INIT) overrides the env:// rendezvous, e.g.
     "file:///tmp/x/store" — used by the tests, whose parent cannot hold a TCP port open for its children."""
@@ -27,7 +28,7 @@ def init_distributed(backend=None, init_method=None):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     init_method = init_method or os.environ.get("VQF_DIST_INIT") or None
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -62,12 +63,16 @@ class GradientAllReducer:
     "per-tile" or "persistent" -- how the large-tile GEMMs launch while this reducer is alive (see __init__).
     """
 
-    def __init__(self, module, bucket_bytes=64 << 20, process_group=None, broadcast=True, gemm_workgroups=None):
+    def __init__(self, module, bucket_bytes=64 << 20, process_group=None, broadcast=True, gemm_workgroups=None,
+                 single_rank=False):
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # single_rank: run the buckets, hooks and collectives in a ONE-rank group as well (the average over one rank is the
+        # identity): exercises the RCCL stream semantics on a one-GPU box
+        self.active = self.world > 1 or (single_rank and dist.is_initialized())
         self.params = [p for p in module.parameters() if p.requires_grad]
-        if self.world > 1 and broadcast:
+        if self.active and broadcast:
             self.broadcast_parameters()
         self.buckets = []       # list of dict(flat, params=[(p, offset, numel)], pending, handle)
         self._index = {}
@@ -78,7 +83,7 @@ class GradientAllReducer:
         self._marks = []
         self._saved_options = None
         self._hooks = []
-        if self.world > 1:
+        if self.active:
             # The large-tile GEMMs normally run as PERSISTENT workgroups (one per CU, holding all of its LDS for the whole
             # launch: csrc/gemm_f32_big.hip).  The collective's kernels could then not get onto a CU before the 14-ms
             # weight-gradient GEMM they are meant to overlap with has ended.  Data-parallel runs therefore launch one
@@ -198,7 +203,7 @@ class GradientAllReducer:
 
     def finish(self):
         """wait for the collectives and expose the averaged gradients as p.grad."""
-        if self.world == 1:
+        if not self.active:
             return
         for b in self.buckets:
             if b["pending"] != 0:
