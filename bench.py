@@ -237,17 +237,30 @@ def pmc_kernel_lookup(name):
     return None, None
 
 
-def gemm_roofline(ops, kernel_id, dtype, M, N, K, what, peak):
-    """roofline object of one GEMM launch family timed by the library's hipEvent profiler (shape-tagged)."""
-    n, ms = ops.prof_shape(kernel_id, M, N, K)
-    if not n:
-        return None
+def gemm_roofline(ops, kernel_id, dtype, M, N, K, what, peak, ta=0, tb=0):
+    """roofline object of one GEMM of the step, timed by the library's hipEvent profiler (shape-tagged launches).  A mid-size
+    fp32 product is TWO launches (vqf_gemm_f32_big_rows: whole rounds of the 256x256-tile kernel + the remaining rows on the
+    128x128 kernel): the object then covers both -- all of the product's FLOPs over the sum of the two durations."""
+    rows = ops.gemm_big_rows(ta, tb, M, N, K) if dtype == "f32" else M
+    parts = [M] if rows in (0, M) else [rows, M - rows]
+    n, ms, per = None, 0.0, []
+    for m in parts:
+        n_i, ms_i = ops.prof_shape(kernel_id, m, N, K)
+        if not n_i or (n is not None and n_i != n):
+            return None
+        n, ms = n_i, ms + ms_i
+        per.append({"rows": m, "avg_launch_ms": round(ms_i / n_i, 4)})
     flops = 2.0 * M * N * K
     ach = flops / (ms / n * 1e-3) / 1e12
     traffic, note, source = pmc_lookup(dtype, M, N, K)
-    return {"bound": "mfma", "kernel": what, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": source, "traffic_note": note,
-            "avg_launch_ms": round(ms / n, 4), "launches": n, "flops_per_launch": flops}
+    out = {"bound": "mfma", "kernel": what, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+           "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": source, "traffic_note": note,
+           "avg_launch_ms": round(ms / n, 4), "launches": n, "flops_per_launch": flops}
+    if len(per) == 2:
+        per[0]["kernel"], per[1]["kernel"] = "gemm_f32_big.hip (256x256 tiles, whole rounds of the CUs)", "gemm_f32.hip (128x128 tiles)"
+        out["launch_split"] = per
+        out["avg_launch_ms_note"] = "sum of the two launches that make up this product"
+    return out
 
 
 class Workload:
@@ -330,7 +343,7 @@ def dominant_mnk(model_name, B):
 
 def timed_steps(wl, ops, warmup, steps, fence):
     """W untimed warm-ups, then EXACTLY `steps` timed steps between fences.  Inside the timed region only the dominant GEMM
-    launches (M * N * K >= half of the image projection's) carry hipEvent brackets: a bracket costs the stream ~6-10 us
+    launches (M * N * K >= a quarter of the image projection's: both launches of a row-split product) carry hipEvent brackets: a bracket costs the stream ~6-10 us
     between two kernels (rocprofv3 kernel trace of r03: 10.4 us gaps between bracketed launches, none between unbracketed
     ones; ~135 launches per MFB step), so bracketing every kernel would tax the step it measures by ~2 % (13 % for
     HieCoAtten).  The per-kernel table comes from census_steps() afterwards."""
@@ -339,7 +352,7 @@ def timed_steps(wl, ops, warmup, steps, fence):
     if wl.reducer is not None:
         wl.reducer.timing = True
     ops.prof_reset()
-    ops.prof_enable(True, min_mnk=dominant_mnk(wl.name, wl.B) // 2)
+    ops.prof_enable(True, min_mnk=dominant_mnk(wl.name, wl.B) // 4)
     fence()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -430,7 +443,7 @@ def secondary_config(vqa_amd, which, dev, steps, warmup):
                              "gemm_f32_a0b0)" % (M, N, K), FP32_MFMA_PEAK_TFLOPS)
         if roof is not None:
             w = gemm_roofline(ops, "gemm_f32_a1b1(wgrad)", "f32", N, K, M, "its weight gradient (M=%d,N=%d,K=%d)" % (N, K, M),
-                              FP32_MFMA_PEAK_TFLOPS)
+                              FP32_MFMA_PEAK_TFLOPS, ta=1, tb=1)
             if w is not None:
                 roof["wgrad"] = {k: w[k] for k in ("kernel", "achieved", "frac", "avg_launch_ms", "launches", "traffic", "traffic_source")}
         workload = ("HieCoAtten train step (fwd+CE+bwd+Adam), batch 256, img_size 2048, embed 512, 14 tokens, fp32, "
@@ -541,12 +554,12 @@ def main():
             "accumulate; profiler id gemm_bf16)" % (proj, M, N, K)) if is_bf16 else (
         "%s forward GEMM (M=%d,N=%d,K=%d; %s; profiler id gemm_f32_a0b0)"
         % (proj, M, N, K, "gemm_f32_big.hip, 256x256 tiles, LDS-DMA, staggered wave halves" if Nn == 5000
-           else "gemm_f32.hip 128x128 tiles"))
+           else "gemm_f32_big.hip on whole rounds of 256x256 tiles + gemm_f32.hip 128x128 tiles on the remaining rows"))
     roofline = gemm_roofline(ops, fam[0], "bf16" if is_bf16 else "f32", M, N, K, what, peak)
     flops = 2.0 * M * N * K
     if roofline is not None:
         w = gemm_roofline(ops, fam[1], "bf16" if is_bf16 else "f32", N, K, M,
-                          "%s img_conv1d wgrad (K-major operands, split-K)" % fam[1], peak)
+                          "%s img_conv1d wgrad (K-major operands, split-K)" % fam[1], peak, ta=1, tb=1)
         if w is not None:
             roofline["wgrad"] = {"kernel": w["kernel"], "achieved": w["achieved"], "frac": w["frac"],
                                  "avg_launch_ms": w["avg_launch_ms"], "launches": w["launches"],

@@ -76,7 +76,8 @@ const char* vqf_build_info(void);
 #define VQF_OPT_GEMM_CU_LIMIT 10     /* persistent large-tile GEMMs use at most this many CUs (multiple of 8; leaves the rest
                                         of the chip to kernels of other streams); <= 0 or -1 = all */
 #define VQF_OPT_GEMM_F32_EDGE 11      /* 0 = the large-tile fp32 GEMM treats a short last column tile like a full one (A/B) */
-#define VQF_OPT_COUNT 12
+#define VQF_OPT_GEMM_F32_ROUNDS 12    /* 0 = mid-size fp32 GEMMs are NOT split at a whole number of rounds of the large-tile kernel (A/B; see vqf_gemm_f32_big_rows) */
+#define VQF_OPT_COUNT 13
 int vqf_set_option(int option, int value, int* previous);
 int vqf_get_option(int option, int* value);
 
@@ -120,10 +121,17 @@ int vqf_gemm_f32(int ta, int tb, int M, int N, int K,
  *   C[m,n] = relu?( rowscale[m / rows_per_scale] * sum_k Aop[m,k] Bop[n,k] + bias[n] )
  * -- the co-attention conv applied to the UN-NORMALISED fusion output R of a sample (mfb.py:105-109: F.normalize, then
  * co_att_conv1): rowscale = 1 / max(||R_n||, eps), rows_per_scale = L, so the normalised tensor is never written.
- * Always the 128x128-tile kernel, no split-K, no VQF_GEMM_ACCUM. */
+ * No split-K, no VQF_GEMM_ACCUM; routed like vqf_gemm_f32 (see vqf_gemm_f32_big_rows). */
 int vqf_gemm_f32_rowscale(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                           float* C, int ldc, const float* bias, int flags, const float* rowscale, int rows_per_scale,
                           void* stream);
+
+/* How vqf_gemm_f32 / vqf_gemm_f32_rowscale route a product (for tools and bench.py's per-launch lookups): the number of
+ * leading rows that run on the 256x256-tile kernel -- M (all), 0 (none: 128x128 / per-wave kernels), or, for a mid-size
+ * shape whose tile count is not a whole number of rounds of the chip's CUs, the largest row block that is (a multiple
+ * of 256 rows); the remaining M - rows rows are a second launch on the other kernels.  Depends on the library options
+ * gemm_f32_big / gemm_f32_rounds and the device's CU count only. */
+int vqf_gemm_f32_big_rows(int ta, int tb, int M, int N, int K);
 
 /* Batched form: for b < batch, C_b = Aop_b * Bop_b^T with A_b = A + b*strideA etc.
  * (element strides).  No bias, no split-K.  Per-sample products of

@@ -213,6 +213,82 @@ def test_gemm_f32_big_short_last_column_tile(ops, rem):
     assert _rel(wide[:, 3:N + 3], ref) <= tol and bool((wide[:, :3] == 3.0).all()) and bool((wide[:, N + 3:] == 3.0).all())
 
 
+MID = [
+    # ta, tb, M, N, K, rows on the large-tile kernel, what
+    (0, 0, 100352, 1024, 1000, 98304, "co_att_conv1 forward (mfb.py:109): 1568 tiles = 6.125 rounds -> 6 rounds + 2048 rows; K % 16 = 8"),
+    (0, 1, 100352, 1000, 1024, 98304, "co_att_conv1 dgrad: K-major weight, N = 1000 (232 live columns in the last tile)"),
+    (0, 0, 50176, 512, 2048, 32768, "HieCoAtten img_emb (hieCoAtten.py:25): 392 tiles = 1.53 rounds -> 1 round + 17408 rows"),
+    (0, 1, 50176, 2048, 512, 49152, "its dgrad: 1568 tiles, K = 512"),
+    (0, 0, 16740, 1024, 520, 16384, "65.4 x 4 tiles -> 64 row tiles + 356 rows (a ragged last 128-row tile); K % 16 = 8"),
+    (0, 0, 7168, 4096, 304, 4096, "LSTM input projection: 28 x 16 tiles -> 16 row tiles"),
+    (0, 0, 66000, 640, 1024, 0, "N = 640: a third column tile with 128 of 256 live columns -> no split"),
+    (1, 0, 98304, 1024, 1024, 0, "K-major A: never split"),
+]
+
+
+@pytest.mark.parametrize("ta,tb,M,N,K,rows,what", MID)
+def test_mid_size_products_run_whole_rounds_on_the_large_tile_kernel(ops, ta, tb, M, N, K, rows, what):
+    """Round 3: mid-size products are split by rows -- the largest block whose 256x256 tiles fill whole rounds of the 256 CUs
+    runs on gemm_f32_big.hip (incl. a zero-filled last slab when K % 16 != 0), the rest on the 128x128 kernel.  vs fp64, with
+    bias + ReLU; the routing as vqf_gemm_f32_big_rows reports it; and the same BITS as the unsplit 128x128 launch (both
+    kernels add a row's k in the same order; the remainder launch takes no split-K)."""
+    assert ops.gemm_big_rows(ta, tb, M, N, K) == rows, what
+    A = _u((K, M) if ta else (M, K), 231)
+    B = _u((K, N) if tb else (N, K), 232, 0.5)
+    bias = _u((N,), 233)
+    n_big, n_small = ops.stat("gemm_f32_big"), ops.stat("gemm_f32_tile128")
+    out = ops.gemm(A, B, ta=bool(ta), tb=bool(tb), bias=bias, relu=True)
+    assert ops.stat("gemm_f32_big") - n_big == (1 if rows else 0)
+    assert ops.stat("gemm_f32_tile128") - n_small == (1 if rows < M else 0)
+    ref = torch.relu(_ref64(A, B, ta, tb, bias))
+    tol = 2e-6 * max(1.0, np.sqrt(K) / 8)
+    assert _rel(out, ref) <= tol, (what, _rel(out, ref), tol)
+    if rows:
+        assert _rel(out[rows - 300:rows + 300], ref[rows - 300:rows + 300]) <= tol      # the seam
+        with ops.options(gemm_f32_rounds=0):
+            assert ops.gemm_big_rows(ta, tb, M, N, K) == 0
+            assert torch.equal(out, ops.gemm(A, B, ta=bool(ta), tb=bool(tb), bias=bias, relu=True)), "the split changed a value"
+        with ops.options(gemm_cu_limit=128):
+            assert ops.gemm_big_rows(ta, tb, M, N, K) == rows          # rounds are counted on all CUs whatever the limit
+            assert torch.equal(out, ops.gemm(A, B, ta=bool(ta), tb=bool(tb), bias=bias, relu=True))
+
+
+def test_co_att_conv1_rowscale_launch_split_vs_fp64(ops):
+    """The launch the headline step makes for co_att_conv1 (NormLink: relu(inv[m / 196] * (R W^T) + b), M = 100352, N = 1024,
+    K = 1000): per-sample scale in the large-tile kernel's epilogue for the first 98304 rows, in the 128x128 kernel's (with
+    the row offset) for the last 2048; vs fp64 and bit-identical to the unsplit launch."""
+    M, N, K, L = 100352, 1024, 1000, 196
+    R = _u((M, K), 241, 2.0)
+    W = _u((N, K), 242, 0.05)
+    b = _u((N,), 243)
+    inv = (_u((M // L,), 244) * 0.4 + 0.6)
+    n_big = ops.stat("gemm_f32_big")
+    out = ops.gemm_rowscale(R, W, inv, L, bias=b, relu=True)
+    assert ops.stat("gemm_f32_big") == n_big + 1
+    ref = torch.relu(_ref64(R, W, 0, 0) * inv.double().repeat_interleave(L)[:, None] + b.double())
+    assert _rel(out, ref) <= 2e-6 * max(1.0, np.sqrt(K) / 8)
+    with ops.options(gemm_f32_rounds=0):
+        assert torch.equal(out, ops.gemm_rowscale(R, W, inv, L, bias=b, relu=True)) and ops.stat("gemm_f32_big") == n_big + 1
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("K", [68, 1000, 1036])
+def test_gemm_f32_big_zero_filled_last_slab(ops, ta, tb, K):
+    """K % 16 = 4, 8, 12 in every layout (library option gemm_f32_big = 2 forces the large-tile kernel): the copies past K
+    in the last slab read 16 zero bytes; K = 68 is shorter than the 4-slab prologue plus the tail."""
+    M, N = 1500, 1304
+    A = _u((K, M) if ta else (M, K), 251)
+    B = _u((K, N) if tb else (N, K), 252, 0.5)
+    ref = _ref64(A, B, ta, tb)
+    with ops.options(gemm_f32_big=2):
+        n0 = _big_launches(ops)
+        out = ops.gemm(A, B, ta=bool(ta), tb=bool(tb), splitk=False)
+        assert _big_launches(ops) == n0 + 1
+    assert _rel(out, ref) <= 2e-6 * max(1.0, np.sqrt(K) / 8)
+    with ops.options(gemm_f32_big=0):
+        assert torch.equal(out, ops.gemm(A, B, ta=bool(ta), tb=bool(tb), splitk=False))
+
+
 def test_headline_fp32_forward_launch_edge_tiles_bitwise(ops):
     """The roofline launch itself (M = 100352, N = 5000, K = 2048): with and without the short-edge path, persistent and
     one workgroup per tile -- four launches, one bit pattern; fp64 on sampled rows."""

@@ -81,7 +81,9 @@ int vqf_gemm_bf16_big_try(int ta, int tb, int M, int N, int K, const void* A, in
 size_t vqf_gemm_bf16_big_ws_bytes(int ta, int tb, int M, int N, int K);
 // gemm_f32_big.hip: the same structure for fp32 operands
 int vqf_gemm_f32_big_try(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
-                         int ldc, const float* bias, int flags, void* ws, size_t ws_bytes, hipStream_t s, int* rc);
+                         int ldc, const float* bias, int flags, const float* rowscale, int rps, void* ws, size_t ws_bytes,
+                         hipStream_t s, int* rc, int* rows_done);
+int vqf_gemm_f32_big_rows_impl(int ta, int tb, int M, int N, int K, int flags, size_t ws_bytes);
 size_t vqf_gemm_f32_big_ws_bytes(int ta, int tb, int M, int N, int K);
 // gemm_f32_wave.hip: small-M products, one 32x64 tile per wave, no split-K slabs; returns 0 when it does not apply
 int vqf_gemm_f32_wave_try(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,

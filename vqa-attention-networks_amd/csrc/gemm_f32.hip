@@ -70,8 +70,9 @@ struct GemmArgs {
   int tiles_m, tiles_n;
   int vecA, vecB;          // 16-B vector loads allowed
   long long sA, sB, sC;    // batch strides (grid.z), 0 when not batched
-  const float* rowscale;   // epilogue: C = rowscale[row / rps] * acc + bias (vqf_gemm_f32_rowscale), or nullptr
+  const float* rowscale;   // epilogue: C = rowscale[(row0 + row) / rps] * acc + bias (vqf_gemm_f32_rowscale), or nullptr
   int rps;
+  int row0;                // rows of the product that another launch computed (the large-tile kernel's whole-rounds block)
 };
 
 // Thread -> (row, k) of its i-th float4 in the K-contiguous ("RK") tile image.  A ds_write_b128
@@ -437,7 +438,7 @@ __global__ void __launch_bounds__(NTHREADS, VQF_GEMM_WAVES_PER_SIMD) gemm_f32_ke
         const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (row < g.M) {
           float* pc = out + (long long)row * ldo + col;
-          float v = (g.rowscale ? acc[i][j][r] * g.rowscale[row / g.rps] : acc[i][j][r]) + bv;
+          float v = (g.rowscale ? acc[i][j][r] * g.rowscale[(g.row0 + row) / g.rps] : acc[i][j][r]) + bv;
           if (!to_slab) {
             if (g.flags & VQF_GEMM_ACCUM) v += *pc;
             if (g.flags & VQF_GEMM_RELU) v = fmaxf(v, 0.f);
@@ -503,8 +504,13 @@ extern "C" size_t vqf_gemm_f32_ws_bytes(int ta, int tb, int M, int N, int K) {
 }
 
 static int gemm_tile128(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
-                        int ldc, const float* bias, int flags, const float* rowscale, int rps, void* ws, size_t ws_bytes,
-                        hipStream_t s);
+                        int ldc, const float* bias, int flags, const float* rowscale, int rps, int row0, void* ws,
+                        size_t ws_bytes, hipStream_t s);
+
+extern "C" int vqf_gemm_f32_big_rows(int ta, int tb, int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  return vqf_gemm_f32_big_rows_impl(ta, tb, M, N, K, 0, (size_t)1 << 40);
+}
 
 extern "C" int vqf_gemm_f32(int ta, int tb, int M, int N, int K, const float* A, int lda,
                             const float* B, int ldb, float* C, int ldc, const float* bias,
@@ -513,12 +519,18 @@ extern "C" int vqf_gemm_f32(int ta, int tb, int M, int N, int K, const float* A,
     return VQF_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
   if (aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0)) {
-    int rc = VQF_OK;      // large shapes take the 256x256-tile LDS-DMA kernel (gemm_f32_big.hip)
-    if (vqf_gemm_f32_big_try(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, ws, ws_bytes, s, &rc)) return rc;
+    int rc = VQF_OK, done = 0;   // large shapes take the 256x256-tile LDS-DMA kernel (gemm_f32_big.hip) ...
+    if (vqf_gemm_f32_big_try(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, nullptr, 1, ws, ws_bytes, s, &rc, &done)) {
+      if (rc != VQF_OK || done >= M) return rc;
+      // ... mid-size ones its whole-rounds row block only (ta == 0 there): the remaining rows follow below
+      // (always the 128x128 kernel, without split-K: it adds a row's k in the same order, so the split product has the bits of the unsplit one)
+      A += (size_t)done * lda; C += (size_t)done * ldc; M -= done;
+      ws = nullptr; ws_bytes = 0;
+    }
     // small-M products (the LSTM's recurrent GEMMs): one tile per wave, no split-K slabs / reduce launch (gemm_f32_wave.hip)
-    if (vqf_gemm_f32_wave_try(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, s, &rc)) return rc;
+    else if (vqf_gemm_f32_wave_try(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, s, &rc)) return rc;
   }
-  return gemm_tile128(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, nullptr, 1, ws, ws_bytes, s);
+  return gemm_tile128(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, nullptr, 1, 0, ws, ws_bytes, s);
 }
 
 extern "C" int vqf_gemm_f32_rowscale(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B,
@@ -527,19 +539,28 @@ extern "C" int vqf_gemm_f32_rowscale(int ta, int tb, int M, int N, int K, const 
   if (!A || !B || !C || !rowscale || rows_per_scale <= 0 || M <= 0 || N <= 0 || K <= 0 || lda <= 0 || ldb <= 0 || ldc < N)
     return VQF_E_BADARG;
   if (flags & VQF_GEMM_ACCUM) return VQF_E_UNSUPPORTED;
-  return gemm_tile128(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, rowscale, rows_per_scale, nullptr, 0,
-                      (hipStream_t)stream);
+  hipStream_t s = (hipStream_t)stream;
+  int row0 = 0;
+  if (aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0)) {
+    int rc = VQF_OK, done = 0;
+    if (vqf_gemm_f32_big_try(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, rowscale, rows_per_scale, nullptr, 0, s, &rc,
+                             &done)) {
+      if (rc != VQF_OK || done >= M) return rc;
+      A += (size_t)done * lda; C += (size_t)done * ldc; M -= done; row0 = done;
+    }
+  }
+  return gemm_tile128(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, rowscale, rows_per_scale, row0, nullptr, 0, s);
 }
 
 // the 128x128-tile kernel of this file (ws == nullptr: no split-K)
 static int gemm_tile128(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
-                        int ldc, const float* bias, int flags, const float* rowscale, int rps, void* ws, size_t ws_bytes,
-                        hipStream_t s) {
+                        int ldc, const float* bias, int flags, const float* rowscale, int rps, int row0, void* ws,
+                        size_t ws_bytes, hipStream_t s) {
   GemmArgs g;
   g.A = A; g.B = B; g.C = C; g.bias = bias; g.slab = nullptr;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.flags = flags;
   g.sA = g.sB = g.sC = 0;
-  g.rowscale = rowscale; g.rps = rps;
+  g.rowscale = rowscale; g.rps = rps; g.row0 = row0;
   g.tiles_m = (M + BM - 1) / BM;
   g.tiles_n = (N + BN - 1) / BN;
   g.vecA = aligned16(A) && (lda % 4 == 0);
@@ -597,7 +618,7 @@ extern "C" int vqf_gemm_f32_batched(int ta, int tb, int batch, int M, int N, int
   g.A = A; g.B = B; g.C = C; g.bias = nullptr; g.slab = nullptr;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.flags = flags;
   g.sA = strideA; g.sB = strideB; g.sC = strideC;
-  g.rowscale = nullptr; g.rps = 1;
+  g.rowscale = nullptr; g.rps = 1; g.row0 = 0;
   g.tiles_m = (M + BM - 1) / BM;
   g.tiles_n = (N + BN - 1) / BN;
   g.vecA = aligned16(A) && (lda % 4 == 0) && (strideA % 4 == 0);

@@ -26,7 +26,7 @@
 //   * three loop forms (gemm_f32_big_kernel's MODE, VQF_GEMM_F32_PP): lockstep (0), the ping-pong loop of
 //     gemm_bf16_big.hip (1: 5 % slower with 64-cycle MFMAs) and, the default, lockstep with waves 4-7 half a slab behind
 //     waves 0-3 (2).
-// Preconditions (else the caller uses gemm_f32.hip): K % 16 == 0, M >= 256, N >= 128, >= 1024 workgroups (tiles x
+// Preconditions (else the caller uses gemm_f32.hip): K % 4 == 0 (a last slab shorter than 16 k is zero-filled), M >= 256, N >= 128, >= 1024 workgroups (tiles x
 // splits), no accumulate flag, 16-byte aligned bases, lda/ldb % 4 == 0, a K-major operand's row extent % 4 == 0.
 #include "common.h"
 #include <algorithm>
@@ -72,6 +72,9 @@ struct BigArgs {
   // but a SHORT last one), phase 2 deals the short edge tiles e = 0 .. tiles_m-1 (column tile tiles_n-1) to the workgroups
   // (edge_w0 + e % edge_wn) % gridDim.x
   int tiles_n_full, edge_w0, edge_wn;
+  const float* rowscale;   // epilogue: C = rowscale[row / rps] * acc + bias (vqf_gemm_f32_rowscale), or nullptr
+  int rps;
+  const float* zeros;      // 16 bytes of zeros in device memory: source of the copies past K in the last slab when K % 16 != 0
 #ifdef VQF_F32BIG_CLOCK
   unsigned long long* dbg;   // diagnostic build only (tools/f32_clock.py): per workgroup and wave half, s_memtime / s_memrealtime stamps
 #endif
@@ -118,6 +121,39 @@ __device__ __forceinline__ void stage_operand(gfloat* (&q)[NG], int ld, char* s,
     lds_char* dst = (lds_char*)(s + (i * 8 + wave) * 1024);    // wave-uniform; the DMA adds lane * 16
     __builtin_amdgcn_global_load_lds(q[i], dst, 16, 0, 0);
     q[i] += T ? (long long)TK * ld : TK;
+  }
+}
+
+// The LAST slab of a K that is not a multiple of 16 (K % 4 == 0: co_att_conv1's K = 1000): copies whose 4 k lie past K take
+// the 16 zero bytes instead (both operands, so nothing beyond either matrix is read and 0 * 0 is added).
+template <bool T>
+__device__ __forceinline__ void stage_operand_tail(gfloat* (&q)[NG], char* s, int wave, int lane, int kvalid, gfloat* zeros) {
+  typedef __attribute__((address_space(3))) char lds_char;
+#pragma unroll
+  for (int i = 0; i < NG; ++i) {
+    bool ok;
+    if (!T) {
+      constexpr int RPW = 1024 / ROW_B;
+      const int rho = i * (8 * RPW) + wave * RPW + lane / CH;
+      ok = 4 * ((lane % CH) ^ swz(rho)) < kvalid;
+    } else {
+      ok = i * 8 + wave < kvalid;
+    }
+    lds_char* dst = (lds_char*)(s + (i * 8 + wave) * 1024);
+    __builtin_amdgcn_global_load_lds(ok ? q[i] : zeros, dst, 16, 0, 0);
+  }
+}
+
+// one slab of both operands into a slot; kvalid = the slab's k inside K (TK except in a short last slab)
+template <bool TA, bool TB>
+__device__ __forceinline__ void stage_slab(const BigArgs& g, gfloat* (&qa)[NG], gfloat* (&qb)[NG], char* slot_base, int wave,
+                                           int lane, int kvalid) {
+  if (kvalid == TK) {                                  // (wave-uniform)
+    stage_operand<TA>(qa, g.lda, slot_base, wave);
+    stage_operand<TB>(qb, g.ldb, slot_base + OP_BYTES, wave);
+  } else {
+    stage_operand_tail<TA>(qa, slot_base, wave, lane, kvalid, (gfloat*)g.zeros);
+    stage_operand_tail<TB>(qb, slot_base + OP_BYTES, wave, lane, kvalid, (gfloat*)g.zeros);
   }
 }
 
@@ -205,6 +241,27 @@ __device__ __forceinline__ void store_tile(const BigArgs& g, float* C, const f32
   }
 }
 
+// rowscale epilogue (vqf_gemm_f32_rowscale: F.normalize folded into co_att_conv1): acc *= rowscale[row / rps] ahead of the
+// bias / relu / store pass, which stays as it is
+template <bool TA>
+__device__ __forceinline__ void scale_acc(const BigArgs& g, f32x16 (&acc)[2][4], int row0, int lane) {
+  const int h = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    float rs[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int rm = (e & 3) + 8 * (e >> 2) + 4 * h;
+      const int row = min(row0 + (TA ? 2 * rm + i : 32 * i + rm), g.M - 1);
+      rs[e] = g.rowscale[row / g.rps];
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j][e] *= rs[e];
+  }
+}
+
 // blocked edge strips: accumulator tile (i, j) of a wave whose strip keeps the identity column order holds output column
 // strip column 32 j + cm; only the first nj column tiles were multiplied.  Dword stores: these are the few short edge tiles.
 template <bool TA>
@@ -274,7 +331,7 @@ __device__ __forceinline__ void mma_kstep(const FragA<TA>& fa, const FragB<TB>& 
 template <bool TA, bool TB, int MODE, int NJ>
 __device__ __forceinline__ void k_loop(const BigArgs& g, char* smem, int& slot, const int S, gfloat* (&qa)[NG],
                                        gfloat* (&qb)[NG], f32x16 (&acc)[2][4], const int wave, const int lane,
-                                       const int wr, const int wc, const int late) {
+                                       const int wr, const int wc, const int late, const int kt) {
   constexpr bool PP = MODE == 1;
   if (MODE == 0 || (MODE == 2 && late == 0)) {
     for (int s = 0; s < S; ++s) {
@@ -288,8 +345,7 @@ __device__ __forceinline__ void k_loop(const BigArgs& g, char* smem, int& slot, 
       fb[0].template load<NJ>(sB, wc * 128, 0, lane);
       if (s + NSLOT - 1 < S) {                         // refill the slot of slab s-1 (its address math hides LDS latency)
         const int sl = (slot == 0) ? NSLOT - 1 : slot - 1;
-        stage_operand<TA>(qa, g.lda, smem + sl * SLOT_BYTES, wave);
-        stage_operand<TB>(qb, g.ldb, smem + sl * SLOT_BYTES + OP_BYTES, wave);
+        stage_slab<TA, TB>(g, qa, qb, smem + sl * SLOT_BYTES, wave, lane, (s + NSLOT == S) ? kt : TK);
       }
 #pragma unroll
       for (int ks = 0; ks < TK / 8; ++ks) {
@@ -315,8 +371,7 @@ __device__ __forceinline__ void k_loop(const BigArgs& g, char* smem, int& slot, 
       fb[0].template load<NJ>(sB, wc * 128, 0, lane);
       if (s + NSLOT - 1 < S) {                         // slab s+4 into the slot of slab s-1
         const int sl = (slot == 0) ? NSLOT - 1 : slot - 1;
-        stage_operand<TA>(qa, g.lda, smem + sl * SLOT_BYTES, wave);
-        stage_operand<TB>(qb, g.ldb, smem + sl * SLOT_BYTES + OP_BYTES, wave);
+        stage_slab<TA, TB>(g, qa, qb, smem + sl * SLOT_BYTES, wave, lane, (s + NSLOT == S) ? kt : TK);
       }
       fa[1].template load<NJ>(sA, wr * 64, 1, lane);
       fb[1].template load<NJ>(sB, wc * 128, 1, lane);
@@ -348,8 +403,7 @@ __device__ __forceinline__ void k_loop(const BigArgs& g, char* smem, int& slot, 
       }
       if (s + NSLOT - 1 < S) {                         // slab s+4 into the slot of slab s-1
         const int sl = (slot == 0) ? NSLOT - 1 : slot - 1;
-        stage_operand<TA>(qa, g.lda, smem + sl * SLOT_BYTES, wave);
-        stage_operand<TB>(qb, g.ldb, smem + sl * SLOT_BYTES + OP_BYTES, wave);
+        stage_slab<TA, TB>(g, qa, qb, smem + sl * SLOT_BYTES, wave, lane, (s + NSLOT == S) ? kt : TK);
       }
       wait_copies(min(s + NSLOT - 1, S - 1) - (s + 1));   // my copies of slab s+1; later slabs stay in flight
       __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0)
@@ -406,7 +460,7 @@ __global__ void __launch_bounds__(NT, 2) gemm_f32_big_kernel(const BigArgs g) {
     if (r < 0) r += G;
     cur_e = r < g.edge_wn ? r : E;
   }
-  int z = 0, m0 = 0, n0 = 0, kbeg = 0, S = 0, nj = 4;  // current work item (uniform over the workgroup); nj: this wave's live column tiles
+  int z = 0, m0 = 0, n0 = 0, kbeg = 0, S = 0, kt = TK, nj = 4;  // current work item (uniform over the workgroup); nj: this wave's live column tiles
 #ifdef VQF_F32BIG_CLOCK
   int w_dbg = 0;
 #endif
@@ -442,7 +496,11 @@ __global__ void __launch_bounds__(NT, 2) gemm_f32_big_kernel(const BigArgs g) {
     }
     m0 = tm * TM; n0 = tn * TN;
     kbeg = z * g.kchunk;
-    S = (min(g.K, kbeg + g.kchunk) - kbeg) / TK;       // slabs of this split
+    {
+      const int klen = min(g.K, kbeg + g.kchunk) - kbeg;
+      S = (klen + TK - 1) / TK;                        // slabs of this split
+      kt = klen - (S - 1) * TK;                        // k of the last slab (TK, or K % TK: only the last split can be short)
+    }
     // live columns of the two column strips: a K-contiguous B strip with <= 64 of them is staged in identity order and its
     // waves multiply 1 or 2 column tiles; a strip without any multiplies nothing
     const int live0 = g.N - n0, live1 = g.N - n0 - 128;
@@ -455,8 +513,7 @@ __global__ void __launch_bounds__(NT, 2) gemm_f32_big_kernel(const BigArgs g) {
 #pragma unroll
     for (int p = 0; p < NSLOT - 1; ++p) {
       if (p < S) {
-        stage_operand<TA>(qa, g.lda, smem + sl * SLOT_BYTES, wave);
-        stage_operand<TB>(qb, g.ldb, smem + sl * SLOT_BYTES + OP_BYTES, wave);
+        stage_slab<TA, TB>(g, qa, qb, smem + sl * SLOT_BYTES, wave, lane, (p + 1 == S) ? kt : TK);
       }
       sl = (sl + 1 == NSLOT) ? 0 : sl + 1;
     }
@@ -480,10 +537,10 @@ __global__ void __launch_bounds__(NT, 2) gemm_f32_big_kernel(const BigArgs g) {
   const unsigned long long c1 = __builtin_amdgcn_s_memtime();
 #endif
   // (wave-uniform branches; a K-major B cannot be re-ordered per strip, so it only knows full and empty strips)
-  if (nj == 4)                k_loop<TA, TB, MODE, 4>(g, smem, slot, S, qa, qb, acc, wave, lane, wr, wc, late);
-  else if (!TB && nj == 2)    k_loop<TA, TB, MODE, 2>(g, smem, slot, S, qa, qb, acc, wave, lane, wr, wc, late);
-  else if (!TB && nj == 1)    k_loop<TA, TB, MODE, 1>(g, smem, slot, S, qa, qb, acc, wave, lane, wr, wc, late);
-  else                        k_loop<TA, TB, MODE, 0>(g, smem, slot, S, qa, qb, acc, wave, lane, wr, wc, late);
+  if (nj == 4)                k_loop<TA, TB, MODE, 4>(g, smem, slot, S, qa, qb, acc, wave, lane, wr, wc, late, kt);
+  else if (!TB && nj == 2)    k_loop<TA, TB, MODE, 2>(g, smem, slot, S, qa, qb, acc, wave, lane, wr, wc, late, kt);
+  else if (!TB && nj == 1)    k_loop<TA, TB, MODE, 1>(g, smem, slot, S, qa, qb, acc, wave, lane, wr, wc, late, kt);
+  else                        k_loop<TA, TB, MODE, 0>(g, smem, slot, S, qa, qb, acc, wave, lane, wr, wc, late, kt);
 
 #ifdef VQF_F32BIG_CLOCK
   const unsigned long long c2 = __builtin_amdgcn_s_memtime(), r2 = __builtin_amdgcn_s_memrealtime();
@@ -495,6 +552,7 @@ __global__ void __launch_bounds__(NT, 2) gemm_f32_big_kernel(const BigArgs g) {
   const bool vec = (g.N % 4 == 0) && (g.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
                    (!split || (((size_t)g.M * g.N) % 4 == 0));
   const int row0 = m0 + wr * 64, col0 = n0 + wc * 128;
+  if (g.rowscale && !split && nj > 0) scale_acc<TA>(g, acc, row0, lane);
   if (nj == 4) {
     if (vec) {
       if (m0 + TM <= g.M) store_tile<TA, false, true>(g, C, acc, row0, col0, lane, relu, use_bias);
@@ -618,10 +676,11 @@ int launch(const BigArgs& g_in, hipStream_t s) {
 #define F32BIG_WGRAD_MIN_BLOCKS 256   // co_att_conv1's wgrad: 16 tiles x 16 splits = one full round, 1.71 -> 1.52 ms
 #endif
 bool big_applies(int ta, int tb, int M, int N, int K, int flags, size_t ws_bytes) {
-  const bool enabled = vqf_opt(VQF_OPT_GEMM_F32_BIG, 1) != 0;   // A/B switch: 0 selects the 128x128 kernel everywhere
-  if (!enabled || (K % TK) || M < TM || N < 128 || (flags & VQF_GEMM_ACCUM)) return false;
+  const int sw = vqf_opt(VQF_OPT_GEMM_F32_BIG, 1);   // A/B switch: 0 selects the 128x128 kernel everywhere, 2 this one wherever it CAN run
+  if (sw == 0 || (K % 4) || K < 4 * TK || M < TM || N < 128 || (flags & VQF_GEMM_ACCUM)) return false;
   if (ta && (M % 4)) return false;
   if (tb && (N % 4)) return false;
+  if (sw == 2) return true;
   // Only the large projections: a workgroup that needs a whole CU's LDS starts when the CU has drained, which
   // costs mid-size launches more than the kernel gains (HieCoAtten, 392-tile GEMMs: step 5.57 -> 5.77 ms) ...
   const int tiles = ((M + TM - 1) / TM) * ((N + TN - 1) / TN);
@@ -631,6 +690,41 @@ bool big_applies(int ta, int tb, int M, int N, int K, int flags, size_t ws_bytes
   // splits of 784 slabs each, co_att_conv1's 4 x 4 tiles x 16 splits (one workgroup per CU, 392 slabs each).
   if (ta && tb && K >= 16384 && tiles * pick_splits(tiles, K, M, N, ws_bytes) >= F32BIG_WGRAD_MIN_BLOCKS) return true;   // needs its slabs
   return false;
+}
+
+// Mid-size shapes (co_att_conv1 forward / dgrad: 1568 tiles = 6.125 rounds of 256 CUs; HieCoAtten's 392-tile products: 1.53):
+// on whole rounds this kernel beats the 128x128 one by 8-9 % also at K = 512 .. 1024 (142 vs 131 TF, tools/gemm_mid_probe.py),
+// but a last partial round costs it a whole one.  So such a product is SPLIT BY ROWS: the first r row tiles -- the largest r
+// whose r x tiles_n tiles fill whole rounds to within 4 % -- run here, the remaining rows go back to the caller (128x128 /
+// per-wave kernels).  Row blocks are independent, every output element keeps one fixed summation order.  Returns the rows
+// taken (a multiple of 256), 0 = no split.  Rounds are counted on ALL CUs whatever gemm_cu_limit says, so the split -- and
+// with it every bit of the result -- does not depend on that option.
+int whole_round_rows(int ta, int tb, int M, int N, int K, int flags) {
+  if (vqf_opt(VQF_OPT_GEMM_F32_BIG, 1) == 0 || vqf_opt(VQF_OPT_GEMM_F32_ROUNDS, 1) == 0) return 0;
+  if (ta || (flags & VQF_GEMM_ACCUM) || (K % 4) || K < 256 || N < 128 || (tb && (N % 4))) return 0;
+  const int tn = (N + TN - 1) / TN;
+  if ((long long)tn * TN * 100 > (long long)N * 107) return 0;       // a ragged last column tile: > 7 % of the MFMAs on dead columns
+  const int cus = vqf_cu_count() & ~7;
+  if (cus < 8) return 0;
+  for (int r = M / TM; r >= 1 && r * tn >= cus; --r) {
+    const int tiles = r * tn, rounds = (tiles + cus - 1) / cus;
+    if ((rounds * cus - tiles) * 25 <= rounds * cus) return r * TM;
+  }
+  return 0;
+}
+
+// 16 zero bytes in device memory (BigArgs::zeros), per device
+__device__ __attribute__((aligned(16))) float vqf_f32big_zeros[4] = {0.f, 0.f, 0.f, 0.f};
+const float* zeros16() {
+  static const float* ptr[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (!ptr[dev]) {
+    void* q = nullptr;
+    if (hipGetSymbolAddress(&q, HIP_SYMBOL(vqf_f32big_zeros)) != hipSuccess) return nullptr;
+    ptr[dev] = (const float*)q;
+  }
+  return ptr[dev];
 }
 
 }  // namespace
@@ -643,18 +737,37 @@ size_t vqf_gemm_f32_big_ws_bytes(int ta, int tb, int M, int N, int K) {
   return sp > 1 ? (size_t)sp * M * N * sizeof(float) : 0;
 }
 
-// 0 = this kernel does not apply (caller falls back to gemm_f32.hip), 1 = launched (rc holds the status)
+// rows of a (ta, tb, M, N, K) product that the large-tile kernel takes: M (all of it), 0 (none), or the whole-rounds row
+// block of a mid-size shape (the rest runs on the 128x128 / per-wave kernels)
+int vqf_gemm_f32_big_rows_impl(int ta, int tb, int M, int N, int K, int flags, size_t ws_bytes) {
+  if (big_applies(ta, tb, M, N, K, flags, ws_bytes)) return M;
+  return whole_round_rows(ta, tb, M, N, K, flags);
+}
+
+// 0 = this kernel does not apply (caller falls back to gemm_f32.hip), 1 = launched (rc holds the status) on the first
+// *rows_done rows (M, or the whole-rounds block of a mid-size shape: the caller computes the remaining rows)
 int vqf_gemm_f32_big_try(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
-                          int ldc, const float* bias, int flags, void* ws, size_t ws_bytes, hipStream_t s, int* rc) {
-  if (!big_applies(ta, tb, M, N, K, flags, (ws && aligned16(ws)) ? ws_bytes : 0)) return 0;
+                          int ldc, const float* bias, int flags, const float* rowscale, int rps, void* ws, size_t ws_bytes,
+                          hipStream_t s, int* rc, int* rows_done) {
+  const size_t ws_ok = (ws && aligned16(ws)) ? ws_bytes : 0;
+  const bool whole = big_applies(ta, tb, M, N, K, flags, ws_ok);
+  const int Mb = whole ? M : whole_round_rows(ta, tb, M, N, K, flags);
+  if (Mb <= 0) return 0;
   BigArgs g;
   g.A = A; g.B = B; g.C = C; g.bias = bias;
-  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.flags = flags;
-  g.tiles_m = (M + TM - 1) / TM;
+  g.M = Mb; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.flags = flags;
+  g.rowscale = rowscale; g.rps = rps > 0 ? rps : 1;
+  g.zeros = nullptr;
+  if (K % TK) {
+    g.zeros = zeros16();
+    if (!g.zeros) return 0;
+  }
+  g.tiles_m = (Mb + TM - 1) / TM;
   g.tiles_n = (N + TN - 1) / TN;
   const int tiles = g.tiles_m * g.tiles_n;
-  int splits = pick_splits(tiles, K, M, N, (ws && aligned16(ws)) ? ws_bytes : 0);
-  const int slabs = K / TK;
+  int splits = whole ? pick_splits(tiles, K, Mb, N, ws_ok) : 1;
+  if (splits > 1 && (rowscale || (K % TK))) return 0;        // (neither occurs: split-K shapes are the deep-K weight gradients)
+  const int slabs = (K + TK - 1) / TK;
   const int per = (slabs + splits - 1) / splits;
   g.kchunk = per * TK;
   splits = (K + g.kchunk - 1) / g.kchunk;
@@ -670,10 +783,11 @@ int vqf_gemm_f32_big_try(int ta, int tb, int M, int N, int K, const float* A, in
 #ifdef VQF_F32BIG_CLOCK
   g.dbg = (splits == 1 && ws && ws_bytes >= (size_t)tiles * 2 * 8 * 8) ? (unsigned long long*)ws : nullptr;
 #endif
-  vqf_prof_dims(M, N, K);
+  vqf_prof_dims(Mb, N, K);
   vqf_stat_bump(VQF_STAT_GEMM_F32_BIG);
   if (ta) *rc = tb ? launch<true, true>(g, s) : launch<true, false>(g, s);
   else    *rc = tb ? launch<false, true>(g, s) : launch<false, false>(g, s);
-  if (*rc == VQF_OK && splits > 1) *rc = vqf_splitk_reduce((const float*)ws, splits, M, N, C, ldc, bias, flags, s);
+  if (*rc == VQF_OK && splits > 1) *rc = vqf_splitk_reduce((const float*)ws, splits, Mb, N, C, ldc, bias, flags, s);
+  *rows_done = Mb;
   return 1;
 }

@@ -12,7 +12,7 @@ namespace {
 const char* const kOptEnv[VQF_OPT_COUNT] = {
     "VQF_GEMM_F32_PERSIST", "VQF_GEMM_BF16_PERSIST", "VQF_GEMM_F32_PP", "VQF_GEMM_BF16_PP", "VQF_GEMM_F32_BIG",
     "VQF_GEMM_BF16_BIG", "VQF_GEMM_F32_WAVE", "VQF_FUSE_COAL", "VQF_FUSE_LS", "VQF_FUSE_LS_BWD", "VQF_GEMM_CU_LIMIT",
-    "VQF_GEMM_F32_EDGE"};
+    "VQF_GEMM_F32_EDGE", "VQF_GEMM_F32_ROUNDS"};
 // the environment is read ONCE, when the library is loaded (command-line A/Bs); never on a launch path
 struct OptInit {
   OptInit() {

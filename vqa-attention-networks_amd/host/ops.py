@@ -68,7 +68,7 @@ def workspace(device, nbytes):
 # library options (include/vqa_fusion.h VQF_OPT_*): process-wide launch policy, cached in the library
 OPTIONS = {"gemm_f32_persist": 0, "gemm_bf16_persist": 1, "gemm_f32_loop": 2, "gemm_bf16_loop": 3, "gemm_f32_big": 4,
            "gemm_bf16_big": 5, "gemm_f32_wave": 6, "fuse_coal": 7, "fuse_ls": 8, "fuse_ls_bwd": 9, "gemm_cu_limit": 10,
-           "gemm_f32_edge": 11}
+           "gemm_f32_edge": 11, "gemm_f32_rounds": 12}
 
 
 def set_option(name, value):
@@ -148,9 +148,15 @@ def gemm(a, b, ta=False, tb=False, bias=None, relu=False, out=None, accumulate=F
     return out
 
 
+def gemm_big_rows(ta, tb, M, N, K):
+    """leading rows of an fp32 (ta, tb, M, N, K) product that run on the 256x256-tile kernel (M, 0, or the whole-rounds block of
+    a mid-size shape: the other M - rows rows are a second launch): include/vqa_fusion.h vqf_gemm_f32_big_rows"""
+    return int(_lib().vqf_gemm_f32_big_rows(int(bool(ta)), int(bool(tb)), int(M), int(N), int(K)))
+
+
 def gemm_rowscale(a, b, rowscale, rows_per_scale, bias=None, relu=False):
-    """C = relu?(rowscale[m // rows_per_scale] * (a @ b^T) + bias): a (M,K), b (N,K) fp32; the 128x128-tile kernel with the
-    per-sample scale in its epilogue (the co-attention conv on the un-normalised fusion output)."""
+    """C = relu?(rowscale[m // rows_per_scale] * (a @ b^T) + bias): a (M,K), b (N,K) fp32; the per-sample scale sits in the
+    GEMM epilogue (the co-attention conv on the un-normalised fusion output)."""
     _chk(a, b, rowscale, bias)
     M, K = a.shape
     N = b.shape[0]
