@@ -153,6 +153,11 @@ int vqf_gemm_bf16(int ta, int tb, int M, int N, int K,
                   const void* A, int lda, const void* B, int ldb,
                   float* C, int ldc, const float* bias, int flags,
                   void* ws, size_t ws_bytes, void* stream);
+/* the bf16 form of vqf_gemm_f32_rowscale: C = relu?( rowscale[m / rows_per_scale] * sum_k Aop Bop + bias ), fp32 C; no
+ * split-K, no VQF_GEMM_ACCUM / VQF_GEMM_OUT_BF16 (bf16 mode of the co-attention conv on the un-normalised fusion output) */
+int vqf_gemm_bf16_rowscale(int ta, int tb, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
+                           float* C, int ldc, const float* bias, int flags, const float* rowscale, int rows_per_scale,
+                           void* stream);
 
 /* y (R x ldy, bf16) = round-to-nearest-even(x (R x C, fp32)), columns C..ldy-1 zero-filled
  * (padding K up to a multiple of 8/32 for vqf_gemm_bf16).  ldy % 8 == 0. */

@@ -76,22 +76,38 @@ def _cond_check(name, got, r64, r32, k=8.0, floor=2e-3):
 
 # ---------------------------------------------------------------------------------------------------------------
 # reference formulas (dtype-generic torch)
-def ref_fuse(P, q, N, L):
-    """mfb.py:98-106 / mhb_coAtt.py:100-108 without dropout: product, k=5 sum-pool, signed sqrt, per-sample L2."""
+def ref_fuse(P, q, N, L, normalise=True):
+    """mfb.py:98-106 / mhb_coAtt.py:100-108 without dropout: product, k=5 sum-pool, signed sqrt, per-sample L2
+    (normalise=False: the signed square roots R themselves, the output of a fusion node with a NormLink)."""
     z = P.view(N, L, -1) * q[:, None, :]
     s = z.view(N, L, -1, 5).sum(-1)
     r = torch.sqrt(torch.relu(s)) - torch.sqrt(torch.relu(-s))
+    if not normalise:
+        return r.reshape(N * L, -1)
     nrm = r.reshape(N, -1).norm(dim=1).clamp_min(1e-12)
     return (r / nrm[:, None, None]).reshape(N * L, -1)
 
 
-def ref_att_head(x, feat, w1, b1, w2, b2, bf16):
-    """AttHeadFn without the multilayer conv, live softmax: conv1 + ReLU -> 2 logits -> softmax over S -> glimpse sums."""
+def linked_cotangent(R, dYs, N):
+    """A fusion node with a NormLink outputs R and is handed dYs = dL/dR with 1/||R_n|| held CONSTANT (its consumer applies
+    that factor in its GEMM epilogue).  The total gradient adds the dependence of 1/||R_n|| on R:
+    dR = dYs - R_n (sum_n R dYs) / ||R_n||^2   (F.normalize's backward written for the un-normalised tensor)."""
+    Rn, d = R.detach().reshape(N, -1), dYs.reshape(N, -1)
+    s = (Rn * d).sum(1, keepdim=True)
+    n2 = (Rn * Rn).sum(1, keepdim=True).clamp_min(1e-24)
+    return (d - Rn * s / n2).reshape(R.shape)
+
+
+def ref_att_head(x, feat, w1, b1, w2, b2, bf16, inv_rows=None):
+    """AttHeadFn without the multilayer conv, live softmax: conv1 + ReLU -> 2 logits -> softmax over S -> glimpse sums.
+    inv_rows (N*S,): the NormLink form -- x is the un-normalised fusion output, the per-sample 1/norm (a CONSTANT of this
+    node) multiplies the conv's accumulator; the gradient that enters the bf16 products is rounded AFTER that factor."""
     N, S, C = feat.shape
+    sc = 1.0 if inv_rows is None else inv_rows[:, None]
     if bf16:
-        hid = _GradRound.apply(_RoundSTE.apply(x) @ _RoundSTE.apply(w1).t()) + b1
+        hid = _GradRound.apply(_RoundSTE.apply(x) @ _RoundSTE.apply(w1).t()) * sc + b1
     else:
-        hid = x @ w1.t() + b1
+        hid = (x @ w1.t()) * sc + b1
     hid = torch.relu(hid)
     logits = (hid @ w2.t() + b2).view(N, S, -1)
     wts = torch.softmax(logits, dim=1)                       # over the S positions, per glimpse
@@ -141,12 +157,15 @@ class _Recorder:
             return out
         return call
 
-    def replay(self, rec):
-        """the node alone: fresh leaves from the recorded inputs -> (output, {arg index: gradient})"""
+    def replay(self, rec, between=None):
+        """the node alone: fresh leaves from the recorded inputs -> (output, {arg index: gradient}); `between` runs after the
+        forward (a linked fusion node gets its consumer's (dlogits, lin) back there)"""
         args2 = [a.detach().clone().requires_grad_(a.requires_grad) if (torch.is_tensor(a) and a.is_floating_point()) else a
                  for a in rec["args"]]
         out = self.orig[rec["cls"]](*args2)
         saved = tuple(out.grad_fn.saved_tensors)          # before the backward frees them (the kernel's own P, qq, vv)
+        if between is not None:
+            between()
         idx = [i for i, a in enumerate(args2) if torch.is_tensor(a) and a.requires_grad]
         grads = torch.autograd.grad(out, [args2[i] for i in idx], grad_outputs=rec["dout"], allow_unused=True)
         return out, dict(zip(idx, grads)), saved
@@ -187,7 +206,9 @@ def _check_logsoftmax(rec, out, grads, rep):
 
 def _check_att_head(rec, out, grads, rep):
     x, feat, w1, b1, wm, bm, w2, b2, unit, bf16 = rec["args"][:10]
-    assert wm is None and not unit and (len(rec["args"]) < 11 or rec["args"][10] is None)    # no NormLink in the bf16 head
+    link = rec["args"][10] if len(rec["args"]) > 10 else None
+    assert wm is None and not unit
+    inv_rows = link.inv.detach().double().repeat_interleave(link.L) if link is not None else None
     bf16 = bool(bf16)
     dt = torch.float64
     leaves = {0: _dbl(x, dt), 2: _dbl(w1.reshape(w1.shape[0], -1), dt), 3: _dbl(b1, dt),
@@ -196,7 +217,7 @@ def _check_att_head(rec, out, grads, rep):
         leaves[1] = _dbl(feat, dt)
     for t in leaves.values():
         t.requires_grad_(True)
-    y = ref_att_head(leaves[0], leaves.get(1, _dbl(feat, dt)), leaves[2], leaves[3], leaves[6], leaves[7], bf16)
+    y = ref_att_head(leaves[0], leaves.get(1, _dbl(feat, dt)), leaves[2], leaves[3], leaves[6], leaves[7], bf16, inv_rows)
     want = [i for i in leaves if i in grads and grads[i] is not None]
     g64 = torch.autograd.grad(y, [leaves[i] for i in want], rec["dout"].double())
     tol = BENIGN_TOL_BF16 if bf16 else BENIGN_TOL_F32
@@ -211,12 +232,13 @@ def _check_att_head(rec, out, grads, rep):
             continue
         assert e <= tol, ("AttHeadFn grad of arg %d" % i, e, tuple(x.shape))
         worst = max(worst, e)
-    rep.append("AttHeadFn%s x%s: %.1e" % ("[bf16]" if bf16 else "", tuple(x.shape), worst))
+    rep.append("AttHeadFn%s%s x%s: %.1e" % ("[bf16]" if bf16 else "", "[linked]" if link is not None else "", tuple(x.shape), worst))
 
 
 def _check_img_fuse(rec, out, grads, rep, saved):
     img, wi, bi, q, keep, seed, p_drop, bf16 = rec["args"][:8]
-    assert bool(bf16) and keep is None and p_drop == 0.0 and (len(rec["args"]) < 9 or rec["args"][8] is None)
+    assert bool(bf16) and keep is None and p_drop == 0.0
+    linked = len(rec["args"]) > 8 and rec["args"][8] is not None       # NormLink: the node outputs R, receives dYs
     N, L, D = img.shape
     img_b, P_k = saved[0], saved[3]                               # saved: (img2d bf16, wi, q, P, Y, norm, inv, keep)
     assert img_b.dtype == torch.bfloat16 and P_k.dtype == torch.bfloat16, "config 3 stores the image grid and P in bf16"
@@ -234,8 +256,8 @@ def _check_img_fuse(rec, out, grads, rep, saved):
     res = {}
     for dt in (torch.float64, torch.float32):
         Pl, ql = P_k.to(dt).requires_grad_(True), q.detach().to(dt).requires_grad_(True)
-        Y = ref_fuse(Pl, ql, N, L)
-        dP, dq = torch.autograd.grad(Y, [Pl, ql], dY.to(dt))
+        Y = ref_fuse(Pl, ql, N, L, normalise=not linked)
+        dP, dq = torch.autograd.grad(Y, [Pl, ql], linked_cotangent(Y, dY.to(dt), N) if linked else dY.to(dt))
         dwi = (bf(dP).double().t() @ img_b.double()).view_as(wi)         # the bf16 hand-off: dW = RNE(dP)^T X
         res[dt] = (Y.detach(), dq, dP.sum(0), dwi)
         del Pl, ql, Y, dP
@@ -244,7 +266,7 @@ def _check_img_fuse(rec, out, grads, rep, saved):
     worst = 0.0
     for name, i, j in (("dq", 3, 1), ("dbias", 2, 2), ("dW (bf16 dP hand-off)", 1, 3)):
         worst = max(worst, _cond_check("ImgFuseFn " + name, grads[i], res[torch.float64][j], res[torch.float32][j]))
-    rep.append("ImgFuseFn[bf16] N=%d: Y %.1e, P bit-equal %.4f, grads err/bound %.2f" % (N, y_err, eq, worst))
+    rep.append("ImgFuseFn[bf16]%s N=%d: Y %.1e, P bit-equal %.4f, grads err/bound %.2f" % ("[linked]" if linked else "", N, y_err, eq, worst))
 
 
 def _check_img_proj_late(rec, out, grads, rep):
@@ -268,12 +290,13 @@ def _check_mfb_fuse(rec, out, grads, rep):
     """side-stream form of the image fusion: bf16 P0 (+ bias inside the kernel) in, bf16 dP out."""
     P0, bi, q, keep, seed, p_drop, N, L = rec["args"][:8]
     assert P0.dtype == torch.bfloat16 and keep is None and p_drop == 0.0
+    linked = len(rec["args"]) > 8 and rec["args"][8] is not None
     res = {}
     for dt in (torch.float64, torch.float32):
         Pl = P0.detach().to(dt).requires_grad_(True)
         bl, ql = bi.detach().to(dt).requires_grad_(True), q.detach().to(dt).requires_grad_(True)
-        Y = ref_fuse(Pl + bl, ql, N, L)
-        dP, db, dq = torch.autograd.grad(Y, [Pl, bl, ql], rec["dout"].to(dt))
+        Y = ref_fuse(Pl + bl, ql, N, L, normalise=not linked)
+        dP, db, dq = torch.autograd.grad(Y, [Pl, bl, ql], linked_cotangent(Y, rec["dout"].to(dt), N) if linked else rec["dout"].to(dt))
         res[dt] = (Y.detach(), dP, db, dq)
         del Pl, Y
     y_err = _nrel(out, res[torch.float64][0])
@@ -282,7 +305,7 @@ def _check_mfb_fuse(rec, out, grads, rep):
     worst = _cond_check("MfbFuseFn dP (bf16)", grads[0].float(), res[torch.float64][1], res[torch.float32][1], floor=5e-3)
     worst = max(worst, _cond_check("MfbFuseFn dbias", grads[1], res[torch.float64][2], res[torch.float32][2]))
     worst = max(worst, _cond_check("MfbFuseFn dq", grads[2], res[torch.float64][3], res[torch.float32][3]))
-    rep.append("MfbFuseFn[bf16 P/dP] N=%d: Y %.1e, grads err/bound %.2f" % (N, y_err, worst))
+    rep.append("MfbFuseFn[bf16 P/dP]%s N=%d: Y %.1e, grads err/bound %.2f" % ("[linked]" if linked else "", N, y_err, worst))
 
 
 def _check_final_mfb(rec, out, grads, rep, saved):
@@ -373,8 +396,24 @@ def test_config3_every_node_of_the_bf16_step_at_batch_512(bf16_mode, monkeypatch
     produced = {id(r["out"]): r for r in recd.records}
     into = {}                                    # id(intermediate tensor) -> list of node-local gradients handed to it
     seen_params, rep = set(), []
+    # a fusion node with a NormLink and the attention head that consumes its output share the link object: the head's backward
+    # leaves (dlogits, lin) in it for the fusion node's backward.  Replayed alone, the head goes first and the fusion node gets
+    # that pair back between its forward (which re-arms the link) and its backward.
+    cache = {}
     for rec in recd.records:
-        out2, grads, saved = recd.replay(rec)
+        name = rec["cls"].__name__
+        link = (rec["args"][8] if len(rec["args"]) > 8 else None) if name in ("ImgFuseFn", "MfbFuseFn") else None
+        if link is not None:
+            head = [r for r in recd.records if r["cls"].__name__ == "AttHeadFn" and len(r["args"]) > 10 and r["args"][10] is link]
+            assert len(head) == 1
+            cache[id(head[0])] = recd.replay(head[0])
+            lin = link.lin
+            assert lin is not None
+            out2, grads, saved = recd.replay(rec, between=lambda: setattr(link, "lin", lin))
+        elif id(rec) in cache:
+            out2, grads, saved = cache.pop(id(rec))
+        else:
+            out2, grads, saved = recd.replay(rec)
         torch.cuda.synchronize()
         assert torch.equal(out2, rec["out"]), (rec["cls"].__name__, "a node replayed alone is not bit-identical")
         for i, g in grads.items():

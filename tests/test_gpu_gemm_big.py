@@ -138,6 +138,27 @@ def test_config3_co_attention_bf16_launches_vs_fp64(ops):
     assert _rel(dW, _ref64(D, Y, 1, 1)) <= 2e-5 * np.sqrt(R) / 16
 
 
+def test_config3_co_attention_bf16_rowscale_launch_vs_fp64(ops):
+    """The bf16 form of the NormLink conv (relu(inv[m / 196] * (bf16(R) bf16(W)^T) + b)) at config 3's shape -- the 16x16x32
+    large-tile kernel with the per-sample scale in its epilogue -- and at a small ragged shape on the 128x128 bf16 kernel;
+    with the 16x16x32 loop switched off the large shape falls back to the 128x128 kernel: same formula, fp64 again."""
+    L = 196
+    for (M, N, K, big) in ((512 * L, 512, 1024, 1), (3 * L + 5, 200, 64, 0)):
+        R = _u((M, K), 151, 2.0).to(torch.bfloat16)
+        W = _u((N, K), 152, 0.1).to(torch.bfloat16)
+        b = _u((N,), 153)
+        inv = _u(((M + L - 1) // L,), 154) * 0.4 + 0.6
+        ref = torch.relu(_ref64(R, W, 0, 0) * inv.double().repeat_interleave(L)[:M, None] + b.double())
+        n0 = ops.stat("gemm_bf16_big")
+        out = ops.gemm_bf16_rowscale(R, W, inv, L, bias=b, relu=True)
+        assert ops.stat("gemm_bf16_big") - n0 == big
+        assert _rel(out, ref) <= 2e-5 * 2, (M, N, K, _rel(out, ref))
+        if big:
+            with ops.options(gemm_bf16_loop=0):
+                out0 = ops.gemm_bf16_rowscale(R, W, inv, L, bias=b, relu=True)
+                assert ops.stat("gemm_bf16_big") - n0 == 1 and _rel(out0, ref) <= 2e-5 * 2
+
+
 def test_headline_fp32_weight_gradient_launch_vs_fp64(ops):
     """The launch behind roofline.wgrad: ops.gemm(dP, X, ta=True, tb=True), M=5000, N=2048, K=100352 (split-K),
     on LIVE operands (in faithful MFB dP is exactly zero).  fp64 reference, 2e-6 * sqrt(K)/8 = 7.9e-5."""

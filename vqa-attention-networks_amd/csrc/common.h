@@ -77,7 +77,8 @@ int vqf_splitk_reduce(const float* slab, int splits, int M, int N, float* C, int
 
 // gemm_bf16_big.hip: 256x256-tile kernel; returns 0 when it does not apply to the shape
 int vqf_gemm_bf16_big_try(int ta, int tb, int M, int N, int K, const void* A, int lda, const void* B, int ldb, float* C,
-                          int ldc, const float* bias, int flags, void* ws, size_t ws_bytes, hipStream_t s, int* rc);
+                          int ldc, const float* bias, int flags, const float* rowscale, int rps, void* ws, size_t ws_bytes,
+                          hipStream_t s, int* rc);
 size_t vqf_gemm_bf16_big_ws_bytes(int ta, int tb, int M, int N, int K);
 // gemm_f32_big.hip: the same structure for fp32 operands
 int vqf_gemm_f32_big_try(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,

@@ -46,6 +46,8 @@ struct GemmArgs {
   int flags;
   int kchunk;
   int tiles_m, tiles_n;
+  const float* rowscale;   // epilogue: C = rowscale[row / rps] * acc + bias (vqf_gemm_bf16_rowscale), or nullptr
+  int rps;
 };
 
 // thread -> (row, k) of its i-th 16-byte chunk
@@ -233,7 +235,7 @@ __global__ void __launch_bounds__(NTHREADS, 4) gemm_bf16_kernel(GemmArgs g) {
         const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (row < g.M) {
           float* pc = out + (long long)row * ldo + col;
-          float v = acc[i][j][r] + bv;
+          float v = (g.rowscale ? acc[i][j][r] * g.rowscale[row / g.rps] : acc[i][j][r]) + bv;
           if (!to_slab) {
             if (g.flags & VQF_GEMM_ACCUM) v += *pc;
             if (g.flags & VQF_GEMM_RELU) v = fmaxf(v, 0.f);
@@ -281,9 +283,26 @@ size_t vqf_gemm_bf16_ws_bytes(int ta, int tb, int M, int N, int K) {
   return vqf_gemm_bf16_big_ws_bytes(ta, tb, M, N, K);
 }
 
+static int gemm_bf16_impl(int ta, int tb, int M, int N, int K, const void* A, int lda, const void* B, int ldb, float* C,
+                          int ldc, const float* bias, int flags, const float* rowscale, int rps, void* ws, size_t ws_bytes,
+                          void* stream);
+
 int vqf_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A, int lda, const void* B,
                   int ldb, float* C, int ldc, const float* bias, int flags, void* ws,
                   size_t ws_bytes, void* stream) {
+  return gemm_bf16_impl(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, nullptr, 1, ws, ws_bytes, stream);
+}
+
+int vqf_gemm_bf16_rowscale(int ta, int tb, int M, int N, int K, const void* A, int lda, const void* B, int ldb, float* C,
+                           int ldc, const float* bias, int flags, const float* rowscale, int rows_per_scale, void* stream) {
+  if (!rowscale || rows_per_scale <= 0) return VQF_E_BADARG;
+  if (flags & (VQF_GEMM_ACCUM | VQF_GEMM_OUT_BF16)) return VQF_E_UNSUPPORTED;
+  return gemm_bf16_impl(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, rowscale, rows_per_scale, nullptr, 0, stream);
+}
+
+static int gemm_bf16_impl(int ta, int tb, int M, int N, int K, const void* A, int lda, const void* B, int ldb, float* C,
+                          int ldc, const float* bias, int flags, const float* rowscale, int rps, void* ws, size_t ws_bytes,
+                          void* stream) {
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || lda <= 0 || ldb <= 0 || ldc < N)
     return VQF_E_BADARG;
   if (!aligned16(A) || !aligned16(B) || (lda % 8) || (ldb % 8)) return VQF_E_UNSUPPORTED;
@@ -294,19 +313,20 @@ int vqf_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A, int lda, c
   hipStream_t s = (hipStream_t)stream;
   {
     int rc = VQF_OK;      // the two big projections take the 256x256-tile kernel
-    if (vqf_gemm_bf16_big_try(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, ws, ws_bytes, s, &rc)) return rc;
+    if (vqf_gemm_bf16_big_try(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, rowscale, rps, ws, ws_bytes, s, &rc)) return rc;
     if (flags & VQF_GEMM_OUT_BF16) return VQF_E_UNSUPPORTED;   // bf16 output exists in the large-tile kernel only
   }
   GemmArgs g;
   g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C; g.bias = bias; g.slab = nullptr;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.flags = flags;
+  g.rowscale = rowscale; g.rps = rps;
   g.tiles_m = (M + BM - 1) / BM;
   g.tiles_n = (N + BN - 1) / BN;
   const long long tiles = (long long)g.tiles_m * g.tiles_n;
   const int ktiles = (K + BK - 1) / BK;
   int splits = 1;
   const int slots = 512;
-  if (ws && tiles < 1024 && ktiles >= 32) {
+  if (ws && !rowscale && tiles < 1024 && ktiles >= 32) {
     double best = 1e30;
     for (int sp = 1; sp <= 16; ++sp) {
       if (ktiles / sp < 16) break;

@@ -67,6 +67,8 @@ struct BigArgs {
   const bf16_t* B;
   float* C;              // output, or the split-K slabs (then ldc = N, no bias / relu)
   const float* bias;
+  const float* rowscale; // (0,0) layout, 16x16x32 kernel only: C = rowscale[row / rps] * acc + bias (vqf_gemm_bf16_rowscale), or nullptr
+  int rps;
   int M, N, K, lda, ldb, ldc, flags;
   int tiles_m, tiles_n, kchunk, splits;
   int group_m;           // row tiles per group of the tile order (pick_group_m)
@@ -620,6 +622,19 @@ __global__ void __launch_bounds__(NT, 2) gemm_bf16_pp16_kernel(const BigArgs g) 
   const bool use_bias = !split && g.bias != nullptr;
   const int row0 = m0 + wr * 128, col0 = n0 + wc * 64;
   const bool full = m0 + TM <= g.M;
+  if (g.rowscale && !split) {                          // per-sample scale ahead of bias / relu (F.normalize folded into co_att_conv1)
+    const int rq = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float rs[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) rs[e] = g.rowscale[min(row0 + 16 * i + 4 * rq + e, g.M - 1) / g.rps];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j][e] *= rs[e];
+    }
+  }
   if (g.flags & VQF_GEMM_OUT_BF16) {                   // bf16 storage of the result (round-to-nearest-even), never with split-K
     __bf16* Cb = reinterpret_cast<__bf16*>(g.C);
     const bool vec = (g.N % 4 == 0) && (g.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(Cb) & 7) == 0);
@@ -726,10 +741,17 @@ size_t vqf_gemm_bf16_big_ws_bytes(int ta, int tb, int M, int N, int K) {
 
 // 0 = this kernel does not apply (caller falls back to gemm_bf16.hip), 1 = launched (rc holds the status)
 int vqf_gemm_bf16_big_try(int ta, int tb, int M, int N, int K, const void* A, int lda, const void* B, int ldb, float* C,
-                          int ldc, const float* bias, int flags, void* ws, size_t ws_bytes, hipStream_t s, int* rc) {
+                          int ldc, const float* bias, int flags, const float* rowscale, int rps, void* ws, size_t ws_bytes,
+                          hipStream_t s, int* rc) {
   if (!big_applies(ta, tb, M, N, K, flags)) return 0;
+  if (rowscale) {      // the epilogue scale lives in the 16x16x32 (0,0) kernel only; anything else falls back to the 128x128 kernel
+    const int loopf = vqf_opt(VQF_OPT_GEMM_BF16_LOOP, 1);
+    if (ta || tb || loopf == 0 || loopf == 3) return 0;
+    ws = nullptr; ws_bytes = 0;                        // no split-K
+  }
   BigArgs g;
   g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C; g.bias = bias;
+  g.rowscale = rowscale; g.rps = rps > 0 ? rps : 1;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.flags = flags;
   g.tiles_m = (M + TM - 1) / TM;
   g.tiles_n = (N + TN - 1) / TN;

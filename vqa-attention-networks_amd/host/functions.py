@@ -147,9 +147,15 @@ class AttHeadFn(torch.autograd.Function):
         if ctx.link is not None:
             # x is the UN-NORMALISED fusion output: 1/norm of the sample goes into the conv GEMM's epilogue, and the logit
             # kernel also returns the part of each logit that is linear in x (NormLink)
-            if ctx.bf16 or wm is not None or b1 is None:
-                raise ops._l.VqfError("AttHeadFn: a NormLink needs the fp32, single-hidden-layer head with a bias")
-            hid1 = ops.gemm_rowscale(x, _w2d(w1), link.inv, link.L, bias=b1, relu=True)
+            if wm is not None or b1 is None:
+                raise ops._l.VqfError("AttHeadFn: a NormLink needs the single-hidden-layer head with a bias")
+            ctx.bf16 = ctx.bf16 and _bf16_ok(_w2d(w1).shape[0], _w2d(w1).shape[1])
+            if ctx.bf16:       # bf16 operands (BASELINE config 3): the un-normalised R is cast, 1/norm rides in the bf16 GEMM's epilogue
+                xb, w1b = ops.cast_bf16(x, 32), ops.cast_bf16(_w2d(w1), 32)
+                hid1 = ops.gemm_bf16_rowscale(xb, w1b, link.inv, link.L, bias=b1, relu=True, K=xb.shape[1])
+                x = xb
+            else:
+                hid1 = ops.gemm_rowscale(x, _w2d(w1), link.inv, link.L, bias=b1, relu=True)
             logits, lin = ops.att_logits_fwd_lin(hid1, _w2d(w2), b2, b1)
             wts, pooled = ops.glimpse_pool_fwd(feat, logits, unit_softmax)
             ctx.save_for_backward(x, feat, w1, None, w2, hid1, None, wts, lin)
@@ -184,6 +190,12 @@ class AttHeadFn(torch.autograd.Function):
             d1s, dw2, db2, db1 = ops.att_logits_bwd(dlogits, hid1, _w2d(w2), relu_mask=True, rowscale=link.inv,
                                                     rows_per_scale=link.L)          # stored rows already times 1/norm
             link.lin = (dlogits, lin)                                               # -> sum(Y * dY) in the producer's backward
+            if ctx.bf16:
+                cin = _w2d(w1).shape[1]
+                d1b = ops.cast_bf16(d1s)
+                dw1 = ops.gemm_bf16(d1b, x, ta=True, tb=True)[:, :cin].contiguous().view_as(w1)
+                dx = ops.gemm_bf16(d1b, ops.cast_bf16(_w2d(w1), 32), tb=True, N=cin) if ctx.needs_input_grad[0] else None
+                return dx, dfeat, dw1, db1, None, None, dw2.view_as(w2), db2, None, None, None
             dw1 = ops.gemm(d1s, x, ta=True, tb=True).view_as(w1)                    # = dpre^T Y
             dx = ops.gemm(d1s, _w2d(w1), tb=True) if ctx.needs_input_grad[0] else None   # dYs = dY / norm
             return dx, dfeat, dw1, db1, None, None, dw2.view_as(w2), db2, None, None, None

@@ -44,6 +44,7 @@ SIGNATURES = {
                                    c_f, c_i, ctypes.c_longlong, c_f, c_i, ctypes.c_longlong, c_i, c_p]),
     "vqf_gemm_bf16_ws_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i]),
     "vqf_gemm_bf16": (c_i, [c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_i, c_f, c_i, c_f, c_i, c_p, c_sz, c_p]),
+    "vqf_gemm_bf16_rowscale": (c_i, [c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_i, c_f, c_i, c_f, c_i, c_f, c_i, c_p]),
     "vqf_cast_f32_bf16": (c_i, [c_f, c_i, c_i, c_i, c_p, c_i, c_p]),
     "vqf_colsum_ws_bytes": (c_sz, [c_i, c_i]),
     "vqf_colsum_f32": (c_i, [c_f, c_i, c_i, c_i, c_f, c_p, c_sz, c_p]),

@@ -262,7 +262,7 @@ class MFB(nn.Module):
         seed, p = self._seeds.next(self.training, pm)
         k1 = keep.get('m1')
         coatt_bf16 = self.gemm_dtype in ("bf16", "bf16-att", "bf16-all")
-        link = NormLink() if (self.fold_norm and not self.multilayer and not coatt_bf16) else None
+        link = NormLink() if (self.fold_norm and not self.multilayer) else None
         if proj is not None:
             P0 = self._side.join(*proj)
             Y = MfbFuseFn.apply(P0, self.img_conv1d.bias, qp, k1, seed, pm if k1 is not None else p, N, L, link)

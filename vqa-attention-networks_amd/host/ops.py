@@ -216,6 +216,22 @@ def gemm_bf16(a, b, ta=False, tb=False, bias=None, relu=False, M=None, N=None, K
     return out
 
 
+def gemm_bf16_rowscale(a, b, rowscale, rows_per_scale, bias=None, relu=False, K=None):
+    """gemm_rowscale with bf16 operands: C fp32 = relu?(rowscale[m // rows_per_scale] * (a @ b^T) + bias), a (M, >=K), b (N, >=K)"""
+    _chk_bf16(a, b)
+    _chk(rowscale, bias)
+    M, N = a.shape[0], b.shape[0]
+    if K is None:
+        K = a.shape[1]
+    if b.shape[1] < K or a.shape[1] < K or rowscale.numel() * rows_per_scale < M:
+        raise _l.VqfError("gemm_bf16_rowscale: shape mismatch")
+    out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    _l.check(_lib().vqf_gemm_bf16_rowscale(0, 0, M, N, K, _ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(out), N, _ptr(bias),
+                                           GEMM_RELU if relu else 0, _ptr(rowscale), int(rows_per_scale), _stream()),
+             "vqf_gemm_bf16_rowscale")
+    return out
+
+
 def bgemm(a, b, ta=False, tb=False, out=None, accumulate=False):
     """Batched: a (B,M,K)|(B,K,M), b (B,N,K)|(B,K,N) -> (B,M,N)."""
     _chk(a, b, out)
