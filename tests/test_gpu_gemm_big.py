@@ -274,6 +274,23 @@ def test_mid_size_products_run_whole_rounds_on_the_large_tile_kernel(ops, ta, tb
             assert torch.equal(out, ops.gemm(A, B, ta=bool(ta), tb=bool(tb), bias=bias, relu=True))
 
 
+def test_mid_size_row_split_on_row_strided_operands(ops):
+    """The split hands A + rows * lda and C + rows * ldc to the second launch: A as a view of a wider tensor (lda > K), the
+    output as a view of a wider tensor (ldc > N, the columns beside it untouched), a K-major B view as well."""
+    M, N, K = 16740, 1024, 520
+    Aw = _u((M, K + 24), 261)
+    Bw = _u((K, N + 8), 262, 0.5)
+    A, B = Aw[:, 8:8 + K], Bw[:, 4:4 + N]                 # 16-byte aligned views (offsets of 8 and 4 floats)
+    assert ops.gemm_big_rows(0, 1, M, N, K) == 16384
+    wide = torch.full((M, N + 12), 7.0, device="cuda")
+    n_big, n_small = ops.stat("gemm_f32_big"), ops.stat("gemm_f32_tile128")
+    ops.gemm(A, B, tb=True, out=wide[:, 4:4 + N])
+    assert ops.stat("gemm_f32_big") == n_big + 1 and ops.stat("gemm_f32_tile128") == n_small + 1
+    ref = _ref64(A.contiguous(), B.contiguous(), 0, 1)
+    assert _rel(wide[:, 4:4 + N], ref) <= 2e-6 * max(1.0, np.sqrt(K) / 8)
+    assert bool((wide[:, :4] == 7.0).all()) and bool((wide[:, 4 + N:] == 7.0).all())
+
+
 def test_co_att_conv1_rowscale_launch_split_vs_fp64(ops):
     """The launch the headline step makes for co_att_conv1 (NormLink: relu(inv[m / 196] * (R W^T) + b), M = 100352, N = 1024,
     K = 1000): per-sample scale in the large-tile kernel's epilogue for the first 98304 rows, in the 128x128 kernel's (with
