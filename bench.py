@@ -181,6 +181,29 @@ def live_wgrad_probe(ops, B, dev, reps=6):
     return n, ms, red
 
 
+def hbm_copy_yardstick(B, dev, reps=6):
+    """What this chip reaches on a plain device copy of the fusion kernels' byte mix: a (B*196, 5000) fp32 tensor -- the
+    projection P, 2 GB -- copied to another one (read : write = 1 : 1, torch's copy kernel, `reps` copies back to back between
+    two events on the current stream).  The HBM-bound kernels of the step are priced against the 8 TB/s pin rate; this says
+    what fraction of it a pure streaming kernel gets here."""
+    src = torch.empty((B * 196, 5000), dtype=torch.float32, device=dev).normal_()
+    dst = torch.empty_like(src)
+    for _ in range(2):
+        dst.copy_(src)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / reps
+    nbytes = 2.0 * src.numel() * 4
+    del src, dst
+    return {"what": "torch device copy of a (%d, 5000) fp32 tensor, %d back to back: bytes read + written / time" % (B * 196, reps),
+            "achieved": round(nbytes / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "ms": round(ms, 4)}
+
+
 def standalone_bf16_projection(ops, B, dev, reps=6):
     """The bf16 image-projection launch ALONE on the chip (all CUs, nothing beside it), live operands, bf16 output: what the
     kernel itself reaches when config 3's step does not make it share the chip with the LSTM recursion."""
@@ -582,6 +605,9 @@ def main():
             if tr is not None:
                 roofline["wgrad_live"].update(traffic=tr, traffic_source=src)
     kernels = kernel_table(rep, CENSUS_STEPS)
+    yardstick = None
+    if world == 1 and args.dtype == "f32" and args.model == "mfb" and not args.forward_only and B == 512:
+        yardstick = hbm_copy_yardstick(B, dev)
     # secondary roofline: the HBM-bound kernels of the step.  algorithmic bytes per step: fusion fwd reads P (+q) and
     # writes R for the L=196 stage and the final block; bwd reads P, dY, Y and writes dP; the glimpse passes
     # read the image tensor once; att_logits_bwd reads + writes the co-attention hidden layer.  `traffic` = HBM bytes per
@@ -641,6 +667,7 @@ def main():
             "roofline": roofline,
             "step_roofline": step_roofline(args.model, B, ms_per_step, args.dtype) if not (args.forward_only or args.pruned) else None,
             "roofline_hbm_kernels": roofline_hbm,
+            "hbm_copy_yardstick": yardstick,
             "kernels_ms_per_step": kernels, "kernels_note": KERNELS_NOTE,
         }
     headline_default = (args.model == "mfb" and args.dtype == "f32" and B == 512 and not args.pruned

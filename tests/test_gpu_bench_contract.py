@@ -49,6 +49,9 @@ def test_bench_prints_one_contract_line():
     for k in ("mfb_fuse_fwd", "mfb_fuse_bwd", "glimpse_pool_fwd", "glimpse_pool_bwd", "att_logits_bwd"):
         h = d["roofline_hbm_kernels"][k]
         assert h["bound"] == "hbm" and 0.05 < h["frac"] < 1.0 and "traffic" in h
+    assert "scale_rows" not in d["roofline_hbm_kernels"] and "rowdot" not in d["roofline_hbm_kernels"]   # folded into co_att_conv1
+    y = d["hbm_copy_yardstick"]                              # what a plain device copy reaches on this chip, same units
+    assert y["unit"] == "GB/s" and y["peak"] == 8000.0 and 0.3 < y["frac"] < 1.0
     # BASELINE configs 3 and 4, timed in the same process after the headline, each with its own roofline object
     sec = d["secondary"]
     for which, model, batch, dtype, peak in (("config3", "mhb_coAtt", 512, "bf16", 2500.0), ("config4", "hieCoAtten", 256, "f32", 157.3),
