@@ -40,6 +40,16 @@ def init_distributed(backend=None, init_method=None, force=False):
             local = local % max(torch.cuda.device_count(), 1)
             torch.cuda.set_device(local)
             kw["device_id"] = torch.device("cuda", local)
+            # RCCL's kernels on a HIGH-PRIORITY stream.  HIP multiplexes its streams onto a few hardware queues per priority
+            # (4 by default); measured with rocprofv3 on the one-rank rehearsal (profiles/r03_dp_queues.md): the collective's
+            # default-priority stream had landed on the SAME hardware queue as the compute stream, so every all-reduce kernel
+            # ran serialised with the backward instead of beside it.  A different priority is a different hardware queue.
+            try:
+                opts = dist.ProcessGroupNCCL.Options()
+                opts.is_high_priority_stream = True
+                kw["pg_options"] = opts
+            except Exception:                     # an older torch without the option object: default stream priority
+                pass
         dist.init_process_group(backend, **kw)
     return rank, world, local
 
@@ -178,10 +188,12 @@ class GradientAllReducer:
     def _on_grad(self, p):
         bi, off = self._index[p]
         b = self.buckets[bi]
-        b["flat"][off:off + p.numel()].copy_(p.grad.reshape(-1))
+        # The gradient is only NOTED here; the bucket is filled by ONE multi-tensor copy when its last gradient has arrived
+        # (a copy kernel per parameter put ~100 small launches on the backward's critical path: 0.3 ms of the headline step).
+        b.setdefault("ready", []).append((b["flat"][off:off + p.numel()], p.grad.reshape(-1)))
         if p.is_cuda:
             # gradients of one bucket may be produced on different streams (the image projection and
-            # its weight gradient run on a side stream): remember where each copy was enqueued
+            # its weight gradient run on a side stream): remember where each one was produced
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(p.device))
             b.setdefault("events", []).append(ev)
@@ -193,8 +205,12 @@ class GradientAllReducer:
         if b.get("events"):
             cur = torch.cuda.current_stream(b["flat"].device)
             for ev in b["events"]:
-                cur.wait_event(ev)             # the collective is ordered after EVERY copy into the bucket
+                cur.wait_event(ev)             # the fill (and the collective behind it) is ordered after EVERY gradient
             b["events"] = []
+        ready = b.get("ready") or []
+        if ready:
+            torch._foreach_copy_([d for d, _ in ready], [g for _, g in ready])
+            b["ready"] = []
         b["handle"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.AVG if self._has_avg() else dist.ReduceOp.SUM,
                                       group=self.group, async_op=True)
 
