@@ -372,8 +372,6 @@ def timed_steps(wl, ops, warmup, steps, fence):
     HieCoAtten).  The per-kernel table comes from census_steps() afterwards."""
     for _ in range(warmup):
         wl.step()
-    if wl.reducer is not None:
-        wl.reducer.timing = True
     ops.prof_reset()
     ops.prof_enable(True, min_mnk=dominant_mnk(wl.name, wl.B) // 4)
     fence()
@@ -384,6 +382,20 @@ def timed_steps(wl, ops, warmup, steps, fence):
     elapsed = time.perf_counter() - t0
     ops.prof_enable(False)
     return elapsed, loss
+
+
+def exposed_allreduce_steps(wl, steps, fence):
+    """`steps` further UNTIMED steps with the reducer's event marks on (one timed hipEvent per bucket on the compute stream in
+    finish(): ~10 us each, which is why the timed region runs without them) -> per-bucket exposed all-reduce time, ms."""
+    if wl.reducer is None or not getattr(wl.reducer, "active", False):
+        return []
+    wl.reducer.timing = True
+    for _ in range(steps):
+        wl.step()
+    fence()
+    out = wl.reducer.exposed_ms()
+    wl.reducer.timing = False
+    return out
 
 
 def census_steps(wl, ops, steps, fence):
@@ -589,7 +601,7 @@ def main():
                                  "operands": ("in-step launch; in faithful MFB dP is EXACTLY ZERO (singleton-axis "
                                               "softmax): see wgrad_live for random operands")
                                  if (args.model == "mfb" and not args.pruned) else "in-step launch, live operands"}
-    exposed = reducer.exposed_ms()
+    exposed = exposed_allreduce_steps(wl, CENSUS_STEPS, fence)
     rep = census_steps(wl, ops, CENSUS_STEPS, fence)
     gemm_wg = reducer.gemm_workgroups()
     if roofline is not None and world == 1 and args.dtype == "f32" and args.model == "mfb" and not args.forward_only:
