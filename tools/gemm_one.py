@@ -1,5 +1,5 @@
 """A few launches of ONE hot GEMM on live random operands, for rocprofv3 --pmc passes.
-    python tools/gemm_one.py --dtype f32|bf16 --shape fwd|wgrad [--out-bf16]"""
+    python tools/gemm_one.py --dtype f32|bf16 --shape fwd|wgrad|hie_fwd|hie_wgrad|coatt_fwd [--out-bf16]"""
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, vqa_amd
@@ -18,6 +18,21 @@ if args.shape == "fwd":       # P = X W^T + b          (mfb.py:96)
     B = (torch.randn((5000, 2048), generator=g) * 0.03).cuda()
     ta = tb = False
     bias = torch.zeros(5000, device="cuda")
+elif args.shape == "hie_fwd":  # HieCoAtten img_emb (hieCoAtten.py:25), B = 256: one round of 256x256 tiles + 17408 rows of 128x128 tiles
+    A = torch.relu(torch.randn((256 * 196, 2048), generator=g)).cuda()
+    B = (torch.randn((512, 2048), generator=g) * 0.03).cuda()
+    ta = tb = False
+    bias = torch.zeros(512, device="cuda")
+elif args.shape == "hie_wgrad":
+    A = ((torch.rand((256 * 196, 512), generator=g) - 0.5) * 0.1).cuda()
+    B = torch.relu(torch.randn((256 * 196, 2048), generator=g)).cuda()
+    ta = tb = True
+    bias = None
+elif args.shape == "coatt_fwd":  # co_att_conv1 forward (mfb.py:109), K = 1000: 6 whole rounds + 2048 rows
+    A = torch.randn((R, 1000), generator=g).cuda()
+    B = (torch.randn((1024, 1000), generator=g) * 0.03).cuda()
+    ta = tb = False
+    bias = torch.zeros(1024, device="cuda")
 else:                          # dW = dP^T X            (autograd of mfb.py:96), live dP
     A = ((torch.rand((R, 5000), generator=g) - 0.5) * 0.1).cuda()
     B = torch.relu(torch.randn((R, 2048), generator=g)).cuda()

@@ -4,6 +4,7 @@
 #   part "hbm":   three PMC passes over the HBM-bound kernels at the headline shapes (tools/hbm_kernels_one.py)
 #   part "trace": kernel trace + stats of the bench step (headline + secondary configs 3 and 4 in the same process)
 #   part "gemm":  three PMC passes over the dominant GEMM launches (tools/gemm_one.py)
+#   part "mid":   the same over the row-split mid-size products (HieCoAtten img_emb forward / weight gradient, co_att_conv1 forward)
 set -u
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -28,6 +29,9 @@ for part in "$@"; do
            pmc f32_wgrad $R/tools/gemm_one.py --dtype f32 --shape wgrad
            pmc bf16_fwd $R/tools/gemm_one.py --dtype bf16 --shape fwd --out-bf16
            pmc bf16_wgrad $R/tools/gemm_one.py --dtype bf16 --shape wgrad ;;
+    mid)   pmc hie_fwd $R/tools/gemm_one.py --dtype f32 --shape hie_fwd
+           pmc hie_wgrad $R/tools/gemm_one.py --dtype f32 --shape hie_wgrad
+           pmc coatt_fwd $R/tools/gemm_one.py --dtype f32 --shape coatt_fwd ;;
     trace) timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o r03 -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --secondary-steps 5 --secondary-warmup 2 > $O/trace.log 2>&1 || echo "trace failed" ;;
   esac
 done
