@@ -231,6 +231,9 @@ def standalone_bf16_projection(ops, B, dev, reps=6):
                     "clock under continuous bf16 MFMA load; once per step in the one-stream form of this step it takes 1.68 ms = 0.49)" % reps}
 
 
+_PMC_EXTRA = {}      # (dtype, M, N, K) -> {clock_ghz, mfma_busy_frac, l2_hit_rate} of the committed counter pass, filled by pmc_lookup
+
+
 def pmc_lookup(dtype, M, N, K):
     """Beyond-L2 bytes per launch of a GEMM from the committed rocprofv3 --pmc passes (PMC passes cannot run inside
     the timed process): newest profiles/r*_pmc_*.json whose dtype / M / N / K match.  -> (bytes, note, source) or Nones."""
@@ -242,6 +245,7 @@ def pmc_lookup(dtype, M, N, K):
         for pmc in (recs if isinstance(recs, list) else [recs]):
             try:
                 if pmc.get("dtype", "f32") == dtype and (pmc["M"], pmc["N"], pmc["K"]) == (M, N, K):
+                    _PMC_EXTRA[(dtype, M, N, K)] = {k: pmc[k] for k in ("clock_ghz", "mfma_busy_frac", "l2_hit_rate") if k in pmc}
                     return pmc["traffic_bytes"], pmc.get("note", "") + "; " + pmc.get("formula", ""), os.path.relpath(src, ROOT)
             except Exception:
                 continue
@@ -279,6 +283,13 @@ def gemm_roofline(ops, kernel_id, dtype, M, N, K, what, peak, ta=0, tb=0):
     out = {"bound": "mfma", "kernel": what, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
            "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": source, "traffic_note": note,
            "avg_launch_ms": round(ms / n, 4), "launches": n, "flops_per_launch": flops}
+    extra = _PMC_EXTRA.get((dtype, M, N, K))
+    if extra:
+        # counters of the committed --pmc pass of this launch: the matrix pipes' busy fraction and the clock the chip SUSTAINED
+        # under it (GRBM_GUI_ACTIVE / time); `peak` above is the boost-clock figure (2.4 GHz), so frac <= clock / 2.4
+        out["pmc"] = dict(extra, source=source)
+        if "clock_ghz" in extra and dtype == "f32":
+            out["pmc"]["peak_at_sustained_clock"] = round(peak * extra["clock_ghz"] / 2.4, 1)
     if len(per) == 2:
         per[0]["kernel"], per[1]["kernel"] = "gemm_f32_big.hip (256x256 tiles, whole rounds of the CUs)", "gemm_f32.hip (128x128 tiles)"
         out["launch_split"] = per
