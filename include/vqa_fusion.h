@@ -51,15 +51,17 @@ extern "C" {
                                   to nearest even; VQF_E_UNSUPPORTED unless the 256x256-tile kernel applies */
 
 /* ABI version (2: LSTM entry points take a workspace and flags, large-tile GEMMs, solver tail, staging; 4: library
- * options, row-scaled GEMM) and build information ("libvqa_fusion gfx950 fp32-mfma(...) tiles ...") */
+ * options, row-scaled GEMM; 5: the whole-sequence LSTM entry points left the library, HBM yardsticks, fused epilogues of
+ * the HieCoAtten path) and build information ("libvqa_fusion gfx950 fp32-mfma(...) tiles ...") */
 int vqf_abi_version(void);
 const char* vqf_build_info(void);
 
 /* --------------------------------------------------------------------------
  * Library options: process-wide launch policy, an int per option, read by the launchers as a plain load (no
  * getenv on the launch path).  -1 = the library's default.  The initial value of each option is taken ONCE, when
- * the library is loaded, from the environment variable of the same name (VQF_GEMM_F32_PERSIST=0 python bench.py
- * still works for command-line A/Bs); after that only vqf_set_option changes it.
+ * the library is loaded, from the environment variable of the same name -- VQF_OPT_X reads VQF_X, see
+ * vqf_option_env_name (VQF_GEMM_F32_PERSIST=0 python bench.py still works for command-line A/Bs; the r02 spellings
+ * VQF_GEMM_F32_PP / VQF_GEMM_BF16_PP of the two *_LOOP options are still accepted); after that only vqf_set_option changes it.
  * vqf_set_option stores `value` (negative = back to the default) and, if `previous` != NULL, hands back the value
  * it replaced so that a caller can restore it; both return VQF_OK or VQF_E_BADARG (unknown id / NULL out pointer).
  */
@@ -77,9 +79,13 @@ const char* vqf_build_info(void);
                                         of the chip to kernels of other streams); <= 0 or -1 = all */
 #define VQF_OPT_GEMM_F32_EDGE 11      /* 0 = the large-tile fp32 GEMM treats a short last column tile like a full one (A/B) */
 #define VQF_OPT_GEMM_F32_ROUNDS 12    /* 0 = mid-size fp32 GEMMs are NOT split at a whole number of rounds of the large-tile kernel (A/B; see vqf_gemm_f32_big_rows) */
-#define VQF_OPT_COUNT 13
+#define VQF_OPT_GEMM_SPLITK_FUSED 13  /* 0 = split-K products write slabs and run a separate vqf_splitk_reduce launch (r01-r03); default: the
+                                        last-arriving workgroup of an output tile sums the slabs in split order inside the GEMM launch */
+#define VQF_OPT_COUNT 14
 int vqf_set_option(int option, int value, int* previous);
 int vqf_get_option(int option, int* value);
+/* the environment variable read for `option` at load time: "VQF_" + the name of its VQF_OPT_* constant ("" if unknown) */
+const char* vqf_option_env_name(int option);
 
 /* Launch counters since the library was loaded (which GEMM kernel family a call was routed to: tests and tools use them
  * to prove that a shape reached the kernel they mean to check; the fp32 families give bit-identical results, so the
@@ -371,22 +377,6 @@ int vqf_lstm_cell_fwd(float* gates, const float* c_prev, int B, int H, float* c_
 int vqf_lstm_cell_bwd(const float* dhs_t, const float* dh_carry, const float* gates, const float* c_t,
                       const float* c_prev, int first, int B, int H, float* dc_carry, float* dG, void* stream);
 
-/* The same recursion as ONE launch for the whole sequence (csrc/lstm_persist.hip): W_hh stays in
- * registers, the H/4 workgroups hand the recurrent state to each other through HBM with
- * write-through stores + per-step arrival counters (forward: all-gather of h_s; backward:
- * reduce-scatter of the partial products dG_s W_hh, summed in a fixed order).  Same tensors as
- * above; the backward takes W_hh itself, not its transpose.  ws: vqf_lstm_persist_ws_bytes(S,B,H)
- * bytes (the forward only needs the counters at its start).  Supported: B <= 16, H in
- * {256,512,768,1024}.  All spins are bounded: vqf_lstm_persist_status(ws, stream) synchronises the
- * stream and returns VQF_E_TIMEOUT if the last launch gave up (its outputs then hold NaN). */
-int vqf_lstm_persist_supported(int B, int H);
-size_t vqf_lstm_persist_ws_bytes(int S, int B, int H);
-int vqf_lstm_seq_fwd_persist(const float* xw, const float* w_hh, int S, int B, int H, float* hs, float* cs,
-                             float* gates, void* ws, size_t ws_bytes, void* stream);
-int vqf_lstm_seq_bwd_persist(const float* dhs, const float* gates, const float* cs, const float* w_hh,
-                             int S, int B, int H, float* dgates, void* ws, size_t ws_bytes, void* stream);
-int vqf_lstm_persist_status(const void* ws, void* stream);
-
 /* --------------------------------------------------------------------------
  * Question-encoder front end: e = tanh(Embedding(q))   (mfb.py:68, mhb_coAtt.py:69).
  *   W (V,E) word_embedding.weight, ids (T) int64 token ids (the (N,T) question tensor, flattened), out (T,E).
@@ -439,6 +429,17 @@ typedef struct VqfAdamTensor {
 } VqfAdamTensor;
 int vqf_adam_step(const VqfAdamTensor* tensors, int count, double lr, double beta1, double beta2, double eps,
                   double weight_decay, long long step, void* stream);
+
+/* --------------------------------------------------------------------------
+ * HBM yardsticks (measurement only; bench.py's `hbm_yardsticks`): what a plain streaming kernel of this library reaches,
+ * in the units the HBM-bound stages above are priced in.  16 bytes per lane, grid-stride, 8 workgroups of 256 threads
+ * per CU, four loads in flight per lane; nt != 0: non-temporal loads / stores.  nbytes % 16 == 0, 16-byte aligned.
+ *   vqf_hbm_copy        dst[0..nbytes) = src[0..nbytes)            (read : write = 1 : 1)
+ *   vqf_hbm_read_sweep  block_sums[b] = sum of the fp32 values workgroup b read (b < vqf_hbm_read_sweep_blocks(nbytes)):
+ *                       a pure read stream whose loads cannot be dropped. */
+int vqf_hbm_copy(const void* src, void* dst, long long nbytes, int nt, void* stream);
+int vqf_hbm_read_sweep_blocks(long long nbytes);
+int vqf_hbm_read_sweep(const void* src, long long nbytes, int nt, float* block_sums, void* stream);
 
 /* --------------------------------------------------------------------------
  * Opt-in profiler: hipEvent pairs around every kernel launch, on the stream

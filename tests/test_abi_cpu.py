@@ -39,7 +39,7 @@ def test_library_exports_every_declared_symbol(vqa):
 def test_binding_table_covers_the_header(vqa):
     assert sorted(vqa.lib.SIGNATURES.keys()) == _header_symbols()
     lib = vqa.lib.load()
-    assert lib.vqf_abi_version() == vqa.lib.ABI_VERSION == 4
+    assert lib.vqf_abi_version() == vqa.lib.ABI_VERSION == 5
     assert b"gfx950" in lib.vqf_build_info()
     assert lib.vqf_prof_num_kernels() > 10
     names = [lib.vqf_prof_kernel_name(i) for i in range(lib.vqf_prof_num_kernels())]
@@ -54,6 +54,12 @@ def test_library_options_are_explicit_and_restorable(vqa):
     ids = {m.group(1).lower(): int(m.group(2)) for m in re.finditer(r"#define VQF_OPT_([A-Z0-9_]+) (\d+)", hdr)}
     count = ids.pop("count")
     assert ids == ops.OPTIONS and sorted(ids.values()) == list(range(count))
+    # the environment variable read for an option at load time is "VQF_" + the name of its constant (two of them
+    # used to be spelt differently, so `VQF_GEMM_F32_LOOP=1 python bench.py` was silently ignored)
+    lib0 = vqa.lib.load()
+    for name, i in ids.items():
+        assert lib0.vqf_option_env_name(i).decode() == "VQF_" + name.upper()
+    assert lib0.vqf_option_env_name(count) == b""
     before = {k: ops.get_option(k) for k in ops.OPTIONS}
     env = dict(os.environ)
     with ops.options(gemm_f32_persist=0, gemm_cu_limit=240):

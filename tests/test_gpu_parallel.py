@@ -163,6 +163,37 @@ def _rccl_worker(store, q_out):
                     if not torch.equal(g[k], ref[k]):
                         raise AssertionError("mode %s step %d: %s differs after the one-rank RCCL all-reduce" % (mode, step, k))
         info["workgroups_after"] = par.GradientAllReducer(model).gemm_workgroups()
+        # HieCoAtten builds fc_Wbq and never uses it (hieCoAtten.py:11,31): without a reducer its .grad is None and Adam keeps
+        # no state for it; under the reducer it must stay that way (round 3 handed it zeros -> an Adam state under DP only)
+        torch.manual_seed(5)
+        hie = vqa.HieCoAtten(block_num=196, word_num=9, img_size=96, vocab_size=50, embed_size=64, output_size=30).cuda()
+        hie.drop_p = 0.0
+        img2, q2 = img[:4], q[:4, :9].clamp(max=49)
+
+        def hie_grads(reducer):
+            opt = vqa.Adam(hie.parameters(), lr=1e-3)
+            out = []
+            for step in range(2):
+                hie.zero_grad(set_to_none=True)
+                torch.nn.functional.cross_entropy(hie.forward(img2, q2)[0], a[:4]).backward()
+                if reducer is not None:
+                    reducer.finish()
+                out.append({k: (None if p.grad is None else p.grad.detach().clone()) for k, p in hie.named_parameters()})
+            opt.step()                                        # parameters without a gradient are skipped, like torch.optim
+            info["hie_adam_states_%s" % (reducer is not None)] = len(opt.state)
+            return out
+        import copy
+        sd = copy.deepcopy(hie.state_dict())
+        plain_h = hie_grads(None)
+        hie.load_state_dict(sd)
+        with par.GradientAllReducer(hie, bucket_bytes=1 << 18, single_rank=True) as red:
+            got_h = hie_grads(red)
+            info["hie_unused"] = sorted(k for k, p in hie.named_parameters() if id(p) in red.unused)
+        for g, ref in zip(got_h, plain_h):
+            for k in ref:
+                if (ref[k] is None) != (g[k] is None) or (ref[k] is not None and not torch.equal(g[k], ref[k])):
+                    raise AssertionError("HieCoAtten: %s differs under the reducer (None-ness or bits)" % k)
+        info["hie_none"] = sorted(k for k, v in got_h[-1].items() if v is None)
         dist.barrier()
         dist.destroy_process_group()
         q_out.put(("ok", info))
@@ -195,6 +226,8 @@ def test_reducer_over_rccl_in_a_one_rank_group_leaves_gradients_bit_identical():
         assert len(info["exposed_%s" % mode]) == info["buckets"]
         assert info["workgroups_%s" % mode]["f32"] == "one per tile"
     assert info["workgroups_after"]["f32"] == "persistent, one per CU"
+    assert info["hie_none"] == ["fc_Wbq.bias", "fc_Wbq.weight"] == info["hie_unused"]
+    assert info["hie_adam_states_True"] == info["hie_adam_states_False"] > 0
     print("one-rank RCCL reducer:", info)
 
 

@@ -44,6 +44,8 @@ enum VqfKernelId {
   KID_LSTM_CELL_BWD,
   KID_EMBED_FWD,
   KID_EMBED_BWD,
+  KID_HBM_COPY,
+  KID_HBM_READ,
   KID_COUNT
 };
 

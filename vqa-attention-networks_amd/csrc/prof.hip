@@ -9,15 +9,21 @@ int g_vqf_opt[VQF_OPT_COUNT];
 long long g_vqf_stat[VQF_STAT_COUNT] = {};
 
 namespace {
+// environment variable of option i = "VQF_" + the name of its VQF_OPT_* constant (include/vqa_fusion.h says so;
+// tests/test_abi_cpu.py checks this table against the header); kOptEnvOld: the r02 spellings of two of them, still read
 const char* const kOptEnv[VQF_OPT_COUNT] = {
-    "VQF_GEMM_F32_PERSIST", "VQF_GEMM_BF16_PERSIST", "VQF_GEMM_F32_PP", "VQF_GEMM_BF16_PP", "VQF_GEMM_F32_BIG",
+    "VQF_GEMM_F32_PERSIST", "VQF_GEMM_BF16_PERSIST", "VQF_GEMM_F32_LOOP", "VQF_GEMM_BF16_LOOP", "VQF_GEMM_F32_BIG",
     "VQF_GEMM_BF16_BIG", "VQF_GEMM_F32_WAVE", "VQF_FUSE_COAL", "VQF_FUSE_LS", "VQF_FUSE_LS_BWD", "VQF_GEMM_CU_LIMIT",
-    "VQF_GEMM_F32_EDGE", "VQF_GEMM_F32_ROUNDS"};
+    "VQF_GEMM_F32_EDGE", "VQF_GEMM_F32_ROUNDS", "VQF_GEMM_SPLITK_FUSED"};
+const char* const kOptEnvOld[VQF_OPT_COUNT] = {
+    nullptr, nullptr, "VQF_GEMM_F32_PP", "VQF_GEMM_BF16_PP", nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+    nullptr, nullptr, nullptr};
 // the environment is read ONCE, when the library is loaded (command-line A/Bs); never on a launch path
 struct OptInit {
   OptInit() {
     for (int i = 0; i < VQF_OPT_COUNT; ++i) {
       const char* e = getenv(kOptEnv[i]);
+      if (!e && kOptEnvOld[i]) e = getenv(kOptEnvOld[i]);
       g_vqf_opt[i] = (e && ((e[0] >= '0' && e[0] <= '9') || e[0] == '-')) ? atoi(e) : -1;
     }
   }
@@ -42,7 +48,7 @@ const char* const kNames[KID_COUNT] = {
     "gemm_bf16", "cast_f32_bf16",
     "lstm_seq_fwd(all steps)", "lstm_seq_bwd(all steps)",
     "ce_loss", "kldiv_loss", "adam_step", "feat_transpose",
-    "lstm_cell_fwd", "lstm_cell_bwd", "embed_tanh_fwd", "embed_tanh_bwd"};
+    "lstm_cell_fwd", "lstm_cell_bwd", "embed_tanh_fwd", "embed_tanh_bwd", "hbm_copy", "hbm_read_sweep"};
 
 hipEvent_t get_event() {
   std::lock_guard<std::mutex> lk(g_mu);
@@ -71,7 +77,7 @@ void vqf_prof_end(int id, hipStream_t s) {
 void vqf_prof_dims(int d0, int d1, int d2) { t_dims[0] = d0; t_dims[1] = d1; t_dims[2] = d2; }
 
 extern "C" {
-int vqf_abi_version(void) { return 4; }
+int vqf_abi_version(void) { return 5; }
 int vqf_set_option(int option, int value, int* previous) {
   if (option < 0 || option >= VQF_OPT_COUNT) return VQF_E_BADARG;
   if (previous) *previous = g_vqf_opt[option];
@@ -88,6 +94,7 @@ int vqf_get_option(int option, int* value) {
   *value = g_vqf_opt[option];
   return VQF_OK;
 }
+const char* vqf_option_env_name(int option) { return (option >= 0 && option < VQF_OPT_COUNT) ? kOptEnv[option] : ""; }
 const char* vqf_build_info(void) {
   return "libvqa_fusion gfx950 fp32-mfma(v_mfma_f32_32x32x2_f32) tiles 128x128x16 + 256x256x16(lds-dma, staggered) + "
          "32x64-per-wave(small M) bf16-mfma(v_mfma_f32_16x16x32_bf16 / 32x32x16) tiles 128x128x32 + "

@@ -619,8 +619,7 @@ class LstmSeqFn(torch.autograd.Function):
 
     For small per-step batches B (MHBCoAtt's batch-axis recursion, mhb_coAtt.py:72-74: S = N, B = T):
     input projection and all weight gradients are MFMA GEMMs over the whole sequence; the recursion
-    itself is ONE launch for the whole sequence when B <= 16 (vqf_lstm_seq_fwd_persist / _bwd_persist,
-    ops.LSTM_PERSISTENT), else one fused kernel launch per step (vqf_lstm_seq_fwd / _bwd)."""
+    itself is one fused kernel launch per step (vqf_lstm_seq_fwd / _bwd)."""
 
     @staticmethod
     def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, bf16=False):
@@ -632,12 +631,7 @@ class LstmSeqFn(torch.autograd.Function):
         ctx.bf16_proj = bf16 == "all" and H % 8 == 0       # "bf16-all": also in the input projection and its gradients
         xw, xb, wb = _lstm_in_proj(x.view(S * B, I), w_ih, bias, ctx.bf16_proj)
         xw = xw.view(S, B, 4 * H)
-        persist = (not ctx.bf16) and bool(ops.LSTM_PERSISTENT) and ops.lstm_persist_supported(B, H)
-        ctx.persist_bwd = persist and ops.LSTM_PERSISTENT != "fwd"
-        if persist:
-            hs, cs, gates = ops.lstm_seq_fwd_persist(xw, _c(w_hh))
-        else:
-            hs, cs, gates = ops.lstm_seq_fwd(xw, _c(w_hh), bf16=ctx.bf16)
+        hs, cs, gates = ops.lstm_seq_fwd(xw, _c(w_hh), bf16=ctx.bf16)
         ctx.save_for_backward(x, w_ih, w_hh, hs, cs, gates, xb, wb)
         ctx.has_bias = b_ih is not None
         return hs
@@ -647,10 +641,7 @@ class LstmSeqFn(torch.autograd.Function):
         x, w_ih, w_hh, hs, cs, gates, xb, wb = ctx.saved_tensors
         S, B, I = x.shape
         H = w_hh.shape[1]
-        if ctx.persist_bwd:
-            dg = ops.lstm_seq_bwd_persist(_c(dhs), gates, cs, _c(w_hh))            # (S,B,4H)
-        else:
-            dg = ops.lstm_seq_bwd(_c(dhs), gates, cs, _c(w_hh), bf16=ctx.bf16)
+        dg = ops.lstm_seq_bwd(_c(dhs), gates, cs, _c(w_hh), bf16=ctx.bf16)                # (S,B,4H)
         dg2 = dg.view(S * B, 4 * H)
         dgb = ops.cast_bf16(dg2) if ctx.bf16 and H % 8 == 0 else None      # one cast serves every bf16 gradient product
         if ctx.bf16_proj:

@@ -18,7 +18,7 @@ if os.environ.get("VQF_LIB"):          # A/B builds (tools/build_variant.sh); ne
 HEADER_PATH = os.path.join(os.path.dirname(PKG_DIR), "include", "vqa_fusion.h")
 
 # The one place the expected ABI number lives (csrc/prof.hip returns it from vqf_abi_version()).
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lock = threading.Lock()
 _lib = None
@@ -35,6 +35,7 @@ SIGNATURES = {
     "vqf_build_info": (ctypes.c_char_p, []),
     "vqf_set_option": (c_i, [c_i, c_i, ctypes.POINTER(c_i)]),
     "vqf_get_option": (c_i, [c_i, ctypes.POINTER(c_i)]),
+    "vqf_option_env_name": (ctypes.c_char_p, [c_i]),
     "vqf_stat_get": (c_i, [c_i, ctypes.POINTER(ctypes.c_longlong)]),
     "vqf_gemm_f32_ws_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i]),
     "vqf_gemm_f32": (c_i, [c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_i, c_f, c_i, c_f, c_i, c_p, c_sz, c_p]),
@@ -86,11 +87,6 @@ SIGNATURES = {
     "vqf_lstm_seq_bwd": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_i, c_p, c_sz, c_p]),
     "vqf_lstm_cell_fwd": (c_i, [c_f, c_f, c_i, c_i, c_f, c_f, c_p]),
     "vqf_lstm_cell_bwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_p]),
-    "vqf_lstm_persist_supported": (c_i, [c_i, c_i]),
-    "vqf_lstm_persist_ws_bytes": (c_sz, [c_i, c_i, c_i]),
-    "vqf_lstm_seq_fwd_persist": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_p, c_sz, c_p]),
-    "vqf_lstm_seq_bwd_persist": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_p, c_sz, c_p]),
-    "vqf_lstm_persist_status": (c_i, [c_p, c_p]),
     "vqf_embed_tanh_fwd": (c_i, [c_f, c_p, c_i, c_i, c_i, c_f, c_p]),
     "vqf_embed_tanh_bwd": (c_i, [c_f, c_f, c_p, c_i, c_i, c_i, c_f, c_p]),
     "vqf_embed_fwd": (c_i, [c_f, c_p, c_i, c_i, c_i, c_f, c_p]),
@@ -101,6 +97,9 @@ SIGNATURES = {
     "vqf_kldiv_loss": (c_i, [c_f, c_f, c_i, c_i, c_f, c_f, c_p, c_sz, c_p]),
     "vqf_adam_step": (c_i, [c_p, c_i, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                             ctypes.c_double, ctypes.c_longlong, c_p]),
+    "vqf_hbm_copy": (c_i, [c_p, c_p, ctypes.c_longlong, c_i, c_p]),
+    "vqf_hbm_read_sweep_blocks": (c_i, [ctypes.c_longlong]),
+    "vqf_hbm_read_sweep": (c_i, [c_p, ctypes.c_longlong, c_i, c_f, c_p]),
     "vqf_prof_enable": (None, [c_i]),
     "vqf_prof_filter": (None, [ctypes.c_longlong]),
     "vqf_prof_reset": (None, []),

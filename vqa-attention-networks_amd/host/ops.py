@@ -68,7 +68,7 @@ def workspace(device, nbytes):
 # library options (include/vqa_fusion.h VQF_OPT_*): process-wide launch policy, cached in the library
 OPTIONS = {"gemm_f32_persist": 0, "gemm_bf16_persist": 1, "gemm_f32_loop": 2, "gemm_bf16_loop": 3, "gemm_f32_big": 4,
            "gemm_bf16_big": 5, "gemm_f32_wave": 6, "fuse_coal": 7, "fuse_ls": 8, "fuse_ls_bwd": 9, "gemm_cu_limit": 10,
-           "gemm_f32_edge": 11, "gemm_f32_rounds": 12}
+           "gemm_f32_edge": 11, "gemm_f32_rounds": 12, "gemm_splitk_fused": 13}
 
 
 def set_option(name, value):
@@ -547,59 +547,6 @@ def lstm_cell_bwd(dhs_t, dh_carry, gates, c_t, c_prev, first, dc_carry, dG):
                                       B, H, _ptr(dc_carry), _ptr(dG), _stream()), "vqf_lstm_cell_bwd")
 
 
-# whole-sequence ("persistent") LSTM: one launch for all steps (csrc/lstm_persist.hip)
-# module-level switch (A/B and tests): True / "both" = forward and backward, "fwd" = forward only,
-# False = the per-step kernels.  Env VQF_LSTM_PERSIST=0|fwd|both overrides the default.
-import os as _os
-LSTM_PERSISTENT = {"0": False, "fwd": "fwd", "both": True}.get(_os.environ.get("VQF_LSTM_PERSIST", "0"), False)
-_lstm_ws = {}
-
-
-def lstm_persist_supported(B, H):
-    return bool(_lib().vqf_lstm_persist_supported(int(B), int(H)))
-
-
-def _lstm_persist_ws(S, B, H, device):
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
-    nbytes = int(_lib().vqf_lstm_persist_ws_bytes(S, B, H))
-    b = _lstm_ws.get(key)
-    if b is None or b.numel() < nbytes:
-        b = _lstm_ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
-    return b, nbytes
-
-
-def lstm_seq_fwd_persist(xw, w_hh):
-    _chk(xw, w_hh)
-    S, B, H4 = xw.shape
-    H = H4 // 4
-    hs = torch.empty((S, B, H), dtype=torch.float32, device=xw.device)
-    cs = torch.empty_like(hs)
-    gates = torch.empty_like(xw)
-    ws, nb = _lstm_persist_ws(S, B, H, xw.device)
-    _l.check(_lib().vqf_lstm_seq_fwd_persist(_ptr(xw), _ptr(w_hh), S, B, H, _ptr(hs), _ptr(cs), _ptr(gates),
-                                             _ptr(ws), nb, _stream()), "vqf_lstm_seq_fwd_persist")
-    return hs, cs, gates
-
-
-def lstm_seq_bwd_persist(dhs, gates, cs, w_hh):
-    _chk(dhs, gates, cs, w_hh)
-    S, B, H = dhs.shape
-    dgates = torch.empty_like(gates)
-    ws, nb = _lstm_persist_ws(S, B, H, dhs.device)
-    _l.check(_lib().vqf_lstm_seq_bwd_persist(_ptr(dhs), _ptr(gates), _ptr(cs), _ptr(w_hh), S, B, H, _ptr(dgates),
-                                             _ptr(ws), nb, _stream()), "vqf_lstm_seq_bwd_persist")
-    return dgates
-
-
-def lstm_persist_status(device=None):
-    """Synchronises and raises VqfError(VQF_E_TIMEOUT) if the last persistent LSTM launch on the current
-    stream gave up on a hand-off (its outputs were poisoned with NaN)."""
-    device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
-    b = _lstm_ws.get((device, torch.cuda.current_stream(device).cuda_stream))
-    if b is not None:
-        _l.check(_lib().vqf_lstm_persist_status(_ptr(b), _stream()), "vqf_lstm_persist_status")
-
-
 # ---------------------------------------------------------------------------
 # question-encoder front end (mfb.py:68)
 def _chk_ids(ids):
@@ -705,6 +652,28 @@ def adam_step(params, grads, exp_avgs, exp_avg_sqs, step, lr, beta1=0.9, beta2=0
         tab[i].exp_avg, tab[i].exp_avg_sq, tab[i].n = m.data_ptr(), v.data_ptr(), p.numel()
     _l.check(_lib().vqf_adam_step(ctypes.cast(tab, ctypes.c_void_p), n, float(lr), float(beta1), float(beta2),
                                   float(eps), float(weight_decay), int(step), _stream()), "vqf_adam_step")
+
+
+# ---------------------------------------------------------------------------
+# HBM yardsticks (measurement only: bench.py's hbm_yardsticks)
+def hbm_copy(src, dst, nt=False):
+    """dst = src with the library's plain 16-B-per-lane grid-stride copy kernel (any dtype, same byte count)."""
+    nbytes = src.numel() * src.element_size()
+    if not (src.is_cuda and dst.is_cuda and src.is_contiguous() and dst.is_contiguous()) or dst.numel() * dst.element_size() != nbytes:
+        raise _l.VqfError("hbm_copy: contiguous GPU tensors of the same byte count expected")
+    _l.check(_lib().vqf_hbm_copy(_ptr(src), _ptr(dst), nbytes, int(bool(nt)), _stream()), "vqf_hbm_copy")
+    return dst
+
+
+def hbm_read_sweep(src, nt=False, out=None):
+    """-> per-workgroup sums (fp32) of a pure read stream over `src` (fp32, contiguous)."""
+    _chk(src)
+    nbytes = src.numel() * 4
+    nb = int(_lib().vqf_hbm_read_sweep_blocks(nbytes))
+    if out is None:
+        out = torch.empty(nb, dtype=torch.float32, device=src.device)
+    _l.check(_lib().vqf_hbm_read_sweep(_ptr(src), nbytes, int(bool(nt)), _ptr(out), _stream()), "vqf_hbm_read_sweep")
+    return out
 
 
 # ---------------------------------------------------------------------------

@@ -54,6 +54,37 @@ def init_distributed(backend=None, init_method=None, force=False):
     return rank, world, local
 
 
+# Launch form of the large-tile GEMMs while ANY reducer is alive: set by the first one, restored by the last close().  Kept
+# here, not per reducer: a second reducer built while the first is alive (or `red = GradientAllReducer(m)` rebinding, where the
+# new object exists before the old one's __del__ runs) must neither mistake the first one's value for the user's choice nor have
+# the old one's close() restore the persistent form underneath it.
+_GEMM_FORM = {"count": 0, "saved": {}}
+_GEMM_FORM_OPTIONS = ("gemm_f32_persist", "gemm_bf16_persist")
+
+
+def _gemm_form_acquire(ops, gemm_workgroups):
+    want = 1 if gemm_workgroups == "persistent" else 0
+    saved = _GEMM_FORM["saved"]
+    for name in _GEMM_FORM_OPTIONS:
+        if name in saved:                       # written by a live reducer, not by the user
+            if gemm_workgroups is not None:
+                ops.set_option(name, want)
+            continue
+        if gemm_workgroups is None and ops.get_option(name) >= 0:
+            continue                            # set explicitly by the user: respected
+        saved[name] = ops.set_option(name, want)
+    _GEMM_FORM["count"] += 1
+
+
+def _gemm_form_release(ops):
+    _GEMM_FORM["count"] -= 1
+    if _GEMM_FORM["count"] <= 0:
+        _GEMM_FORM["count"] = 0
+        for name, prev in _GEMM_FORM["saved"].items():
+            ops.set_option(name, prev)
+        _GEMM_FORM["saved"].clear()
+
+
 def shard_rows(n_global, rank, world):
     """Rows [lo, hi) of the global minibatch owned by `rank` (contiguous row blocks)."""
     per = n_global // world
@@ -69,6 +100,9 @@ class GradientAllReducer:
         opt.zero_grad(set_to_none=True); loss.backward(); reducer.finish(); opt.step()
     After finish(), every p.grad is a view into a flat bucket holding the average
     over ranks.  With world_size == 1 it is a no-op (grads are left untouched).
+    A parameter that received no gradient on ANY rank in the first step (HieCoAtten's fc_Wbq: hieCoAtten.py:11 builds it,
+    :31 never uses it) keeps p.grad = None, as without the reducer -- so it gets no optimizer state either -- and leaves
+    the buckets; the graph is taken to be static after that (such a parameter receiving a gradient later raises).
     gemm_workgroups: None (default: one workgroup per tile at world > 1 unless the library option was set explicitly),
     "per-tile" or "persistent" -- how the large-tile GEMMs launch while this reducer is alive (see __init__).
     """
@@ -91,8 +125,11 @@ class GradientAllReducer:
         # (the part of the all-reduce the backward did NOT hide)
         self.timing = False
         self._marks = []
-        self._saved_options = None
+        self._holds_gemm_form = False
         self._hooks = []
+        self._seen = set()          # id() of the parameters whose hook fired in the current step
+        self.unused = None          # id() of the parameters without a gradient on any rank (known after the first finish())
+        self._bucket_bytes = bucket_bytes
         if self.active:
             # The large-tile GEMMs normally run as PERSISTENT workgroups (one per CU, holding all of its LDS for the whole
             # launch: csrc/gemm_f32_big.hip).  The collective's kernels could then not get onto a CU before the 14-ms
@@ -104,16 +141,10 @@ class GradientAllReducer:
                 raise ValueError("gemm_workgroups: 'per-tile', 'persistent' or None")
             from . import ops, lib as _l
             try:
-                self._saved_options = {}
-                for name in ("gemm_f32_persist", "gemm_bf16_persist"):
-                    cur = ops.get_option(name)
-                    if gemm_workgroups is None and cur >= 0:
-                        continue                        # set explicitly by the user: respected
-                    want = 1 if gemm_workgroups == "persistent" else 0
-                    self._saved_options[name] = ops.set_option(name, want)
+                _gemm_form_acquire(ops, gemm_workgroups)
+                self._holds_gemm_form = True
             except _l.VqfError:
                 # library not built: only a CPU rehearsal of the reducer (gloo) may go on without it
-                self._saved_options = None
                 if any(p.is_cuda for p in self.params):
                     raise
             self._build_buckets(bucket_bytes)
@@ -124,11 +155,10 @@ class GradientAllReducer:
         for h in self._hooks:
             h.remove()
         self._hooks = []
-        if self._saved_options:
+        if self._holds_gemm_form:
             from . import ops
-            for name, prev in self._saved_options.items():
-                ops.set_option(name, prev)
-        self._saved_options = None
+            self._holds_gemm_form = False
+            _gemm_form_release(ops)
 
     def __enter__(self):
         return self
@@ -165,7 +195,8 @@ class GradientAllReducer:
         # gradients become ready roughly in reverse registration order
         cur, cur_bytes = [], 0
         groups = []
-        for p in reversed(self.params):
+        self.buckets, self._index = [], {}
+        for p in reversed([p for p in self.params if not (self.unused and id(p) in self.unused)]):
             nbytes = p.numel() * p.element_size()
             if cur and cur_bytes + nbytes > bucket_bytes:
                 groups.append(cur)
@@ -180,13 +211,17 @@ class GradientAllReducer:
             entries, off = [], 0
             for p in ps:
                 entries.append((p, off, p.numel()))
-                self._index[p] = (bi, off)
+                self._index[id(p)] = (bi, off)
                 off += p.numel()
             self.buckets.append(dict(flat=flat, params=entries, pending=len(entries), handle=None))
 
     # -- per step ------------------------------------------------------------
     def _on_grad(self, p):
-        bi, off = self._index[p]
+        if id(p) not in self._index:
+            raise RuntimeError("GradientAllReducer: a parameter that had no gradient on any rank in the first step (shape %s) "
+                               "received one now; the reducer assumes a static graph -- build a new reducer" % (tuple(p.shape),))
+        self._seen.add(id(p))
+        bi, off = self._index[id(p)]
         b = self.buckets[bi]
         # The gradient is only NOTED here; the bucket is filled by ONE multi-tensor copy when its last gradient has arrived
         # (a copy kernel per parameter put ~100 small launches on the backward's critical path: 0.3 ms of the headline step).
@@ -202,13 +237,19 @@ class GradientAllReducer:
             self._launch(b)
 
     def _launch(self, b):
+        cur = torch.cuda.current_stream(b["flat"].device) if b["flat"].is_cuda else None
         if b.get("events"):
-            cur = torch.cuda.current_stream(b["flat"].device)
             for ev in b["events"]:
                 cur.wait_event(ev)             # the fill (and the collective behind it) is ordered after EVERY gradient
             b["events"] = []
         ready = b.get("ready") or []
         if ready:
+            if b["flat"].is_cuda:
+                # A gradient may have been allocated on another stream (the side stream's dwi, functions.ImgProjLateFn) and is
+                # freed in finish(), when p.grad is re-pointed at the bucket: tell the caching allocator that THIS stream reads
+                # it, so that its block is not handed out again under the in-flight copy
+                for _, g in ready:
+                    g.record_stream(cur)
             torch._foreach_copy_([d for d, _ in ready], [g for _, g in ready])
             b["ready"] = []
         b["handle"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.AVG if self._has_avg() else dist.ReduceOp.SUM,
@@ -221,11 +262,14 @@ class GradientAllReducer:
         """wait for the collectives and expose the averaged gradients as p.grad."""
         if not self.active:
             return
+        first = self.unused is None
+        if first:
+            self.unused = self._globally_unused()
         for b in self.buckets:
             if b["pending"] != 0:
-                # parameters that received no gradient this step contribute zeros
+                # parameters that received no gradient on THIS rank this step contribute zeros
                 for p, off, n in b["params"]:
-                    if p.grad is None:
+                    if id(p) not in self._seen:
                         b["flat"][off:off + n].zero_()
                 self._launch(b)
         cuda = self.timing and self.buckets and self.buckets[0]["flat"].is_cuda
@@ -243,13 +287,27 @@ class GradientAllReducer:
             if not self._has_avg():
                 b["flat"].div_(self.world)
             for p, off, n in b["params"]:
-                p.grad = b["flat"][off:off + n].view_as(p)
+                if id(p) not in self.unused:
+                    p.grad = b["flat"][off:off + n].view_as(p)
             b["pending"] = len(b["params"])
             b["handle"] = None
+        self._seen = set()
+        if first and self.unused:
+            # the buckets of the following steps hold live gradients only (the views handed out above keep this step's alive)
+            self._build_buckets(self._bucket_bytes)
         if marks:
             self._marks.append(marks)
             if len(self._marks) > 1024:                # timing is a bench-only switch; never grow without bound
                 del self._marks[:512]
+
+    def _globally_unused(self):
+        """Parameters whose hook fired on NO rank in the step that just ran: one small MAX all-reduce of a has-gradient mask,
+        once (its result is read on the host: a synchronisation the steady state does not pay)."""
+        dev = self.params[0].device if self.params else torch.device("cpu")
+        mask = torch.tensor([1 if id(p) in self._seen else 0 for p in self.params], dtype=torch.int32, device=dev)
+        if mask.numel():
+            dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=self.group)
+        return {id(p) for p, m in zip(self.params, mask.tolist()) if not m}
 
     def exposed_ms(self):
         """Mean over the timed steps of [ms from the end of the backward kernels to bucket i's completion],
