@@ -8,10 +8,12 @@ and only as the checker / the timed CPU baseline.
 
 Pinning: every function here is checked by `tests/test_oracle_golden.py`
 against vectors captured from the *imported reference* in the build container
-(`tests/golden/make_golden.py`, outputs in `tests/golden/*.npz`).  The one
-exception is `mhb_forward` (reference class `MHB` cannot execute as shipped:
-mhb_coAtt.py:176 hard `.cuda()`, :214 undefined name) -> PARITY UNPINNED for
-that function; it follows the source text with the one-token fix mhb_22->mhb_12.
+(`tests/golden/make_golden.py`, outputs in `tests/golden/*.npz`).  `mhb_forward`
+included (round 4): the reference class `MHB` cannot execute as shipped
+(mhb_coAtt.py:176 hard `.cuda()`, :214 undefined name), so its goldens come from
+that class compiled from its own text with exactly those two edits
+(make_golden.py::load_mhb_class; `.cuda()` -> `.to(img_feature.device)`,
+`mhb_22` -> `mhb_12`), fp32 and fp64 (`tests/golden/mhb_*.npz`).
 
 Citations are file:line into the reference repository.
 Reference quirks are reproduced on purpose:
@@ -201,11 +203,11 @@ def mhbcoatt_forward(sd, cfg, img, q, glove=None, drop=None, return_all=False):
     return out
 
 
-def mhb_forward(sd, cfg, img, q, q_length, drop=None):
+def mhb_forward(sd, cfg, img, q, q_length, drop=None, return_all=False):
     """MHB.forward(img_feature, questions, q_length) -> log-probs.  mhb_coAtt.py:174-217.
 
-    PARITY UNPINNED (see module docstring).  Device-agnostic zeros instead of
-    .cuda() (:176); mhb_22 -> mhb_12 (:214).
+    Device-agnostic zeros instead of .cuda() (:176); mhb_22 -> mhb_12 (:214): the two edits
+    the goldens' reference class carries too (module docstring).
     """
     drop = drop or {}
     N, T = q.shape
@@ -228,7 +230,10 @@ def mhb_forward(sd, cfg, img, q, q_length, drop=None):
     y2 = mfb_pool_norm(z2, N)                                          # :207-211
     y = torch.cat((y1, y2), 1)                                         # :213
     logits = y @ sd["linear_out.weight"].t() + sd["linear_out.bias"]   # :214 (fixed name)
-    return F.log_softmax(logits, dim=1)                                # :215
+    out = F.log_softmax(logits, dim=1)                                 # :215
+    if return_all:
+        return dict(out=out, last=last, i_mean=i_mean, y=y)
+    return out
 
 
 # --------------------------------------------------------------------------

@@ -34,6 +34,15 @@ MHBCOATT_CASES = [
     _c("full_n2", 16, 2, model_name="mhb_coAtt", **_FULL),
 ]
 
+# MHB (mhb_coAtt.py:153-217): the class views the grid as (N, 14, 14, C) (:178), so L = 196 in every case; N = 1 cannot run in
+# the reference (torch.squeeze at :195 drops the batch axis and F.normalize(dim=1) raises), hence N >= 2
+MHB_CASES = [
+    _c("small_n2", 62, 2, model_name="mhb", L=196),
+    _c("small_n3", 63, 3, model_name="mhb", L=196),
+    _c("small_n5", 64, 5, model_name="mhb", L=196, T=9),
+    _c("full_n4", 65, 4, model_name="mhb", **_FULL),
+]
+
 HIE_CASES = [
     dict(name="small_n2", salt=21, N=2, L=20, T=7, img_size=96, V=50, E=64, A=30),
     dict(name="small_n3", salt=22, N=3, L=20, T=7, img_size=96, V=50, E=64, A=30),
@@ -44,6 +53,9 @@ HIE_CASES = [
 ATTNET_CASES = [
     dict(name="small_n3", salt=31, N=3, L=20, T=7, img_size=96, V=50, E=64, A=30, att_num=6),
     dict(name="small_n4_att2", salt=32, N=4, L=12, T=5, img_size=48, V=50, E=32, A=10, att_num=2),
+    # the shapes the reference trains with (networks.py:31 defaults except img_size / vocab / output scaled to the synthetic
+    # configs): 196 regions, 14 words, embed 512, 6 attention layers
+    dict(name="full_n4", salt=33, N=4, L=196, T=14, img_size=2048, V=1000, E=512, A=1000, att_num=6),
 ]
 
 IBOW_CASES = [

@@ -14,7 +14,19 @@ Harness shims, none of which alter arithmetic:
   3. cfg is a SimpleNamespace (easydict is not installed);
   4. torch.nn.functional.dropout -> identity while HieCoAtten / AttentionNet /
      iBOWIMG run (their functional dropout is always on, hieCoAtten.py:26...);
-  5. .eval() for the nn.Dropout models (MFB, MHBCoAtt); autograd still works.
+  5. .eval() for the nn.Dropout models (MFB, MHBCoAtt, MHB); autograd still works.
+  6. class MHB (mhb_coAtt.py:153-217) cannot execute as shipped: :176 moves a fresh tensor to the GPU with a hard
+     `.cuda()` and :214 reads a name that does not exist.  `load_mhb_class()` parses the reference file with `ast`
+     and applies EXACTLY these two edits to MHB.forward before compiling it (nothing is written anywhere):
+
+         176: -    lstm_out = torch.zeros((batch_size, self.cfg.hidden_dim), dtype=torch.float).cuda()
+              +    lstm_out = torch.zeros((batch_size, self.cfg.hidden_dim), dtype=torch.float).to(img_feature.device)
+         214: -    logits = self.linear_out(mhb_22)
+              +    logits = self.linear_out(mhb_12)
+
+     For the float64 digests (`out64`, `g64*`) one more edit is needed, in that pass only: `dtype=torch.float` at
+     :176 would truncate the LSTM states of a model.double() run to fp32 (and then fail in the fp64 Linear), so the
+     fp64 class reads `dtype=torch.double` there.  The fp32 goldens come from the two-edit class.
 """
 import os
 import sys
@@ -30,7 +42,7 @@ sys.path.insert(0, REF)
 import torch  # noqa: E402
 import torch.nn.functional as F  # noqa: E402
 import recipe  # noqa: E402
-from cases import (MFB_CASES, MHBCOATT_CASES, HIE_CASES, ATTNET_CASES, IBOW_CASES,  # noqa: E402
+from cases import (MFB_CASES, MHBCOATT_CASES, MHB_CASES, HIE_CASES, ATTNET_CASES, IBOW_CASES,  # noqa: E402
                    ATT_MODULE_CASES, make_cfg, sample_indices)
 
 torch.set_num_threads(8)
@@ -52,6 +64,82 @@ import mhb_coAtt as ref_mhb  # noqa: E402
 import hieCoAtten as ref_hie  # noqa: E402
 import networks as ref_net  # noqa: E402
 import modules as ref_mod  # noqa: E402
+
+
+def load_mhb_class(fp64=False):
+    """class MHB of the reference with the two edits of shim 6 (three for fp64=True), compiled from its own text."""
+    import ast
+    path = os.path.join(REF, "mhb_coAtt.py")
+    tree = ast.parse(open(path).read(), filename=path)
+    counts = {"cuda": 0, "mhb_22": 0, "float": 0}
+
+    class Fix(ast.NodeTransformer):
+        def visit_Call(self, node):
+            self.generic_visit(node)
+            if isinstance(node.func, ast.Attribute) and node.func.attr == "cuda" and not node.args and not node.keywords:
+                counts["cuda"] += 1
+                dev = ast.Attribute(value=ast.Name(id="img_feature", ctx=ast.Load()), attr="device", ctx=ast.Load())
+                return ast.copy_location(ast.Call(func=ast.Attribute(value=node.func.value, attr="to", ctx=ast.Load()),
+                                                  args=[dev], keywords=[]), node)
+            return node
+
+        def visit_Name(self, node):
+            if node.id == "mhb_22":
+                counts["mhb_22"] += 1
+                return ast.copy_location(ast.Name(id="mhb_12", ctx=node.ctx), node)
+            return node
+
+        def visit_Attribute(self, node):
+            self.generic_visit(node)
+            if fp64 and node.attr == "float" and isinstance(node.value, ast.Name) and node.value.id == "torch":
+                counts["float"] += 1
+                return ast.copy_location(ast.Attribute(value=node.value, attr="double", ctx=node.ctx), node)
+            return node
+
+    for cls in tree.body:
+        if isinstance(cls, ast.ClassDef) and cls.name == "MHB":
+            for fn in cls.body:
+                if isinstance(fn, ast.FunctionDef) and fn.name == "forward":
+                    Fix().visit(fn)
+    assert counts == {"cuda": 1, "mhb_22": 1, "float": 1 if fp64 else 0}, counts
+    ast.fix_missing_locations(tree)
+    ns = {"__name__": "_ref_mhb_fixed"}
+    exec(compile(tree, path, "exec"), ns)
+    return ns["MHB"]
+
+
+def run_mhb(case):
+    cfg = make_cfg(case)
+    N, T = case["N"], case["T"]
+    img = torch.from_numpy(recipe.img_features(N, cfg.img_feature_dim, cfg.img_feature_channel, case["salt"]))
+    qn = recipe.question_tokens(N, T, cfg.q_vocab_size, case["salt"])
+    q, ql = torch.from_numpy(qn), torch.from_numpy(recipe.question_lengths(qn))
+    soft = torch.from_numpy(recipe.soft_answers(N, cfg.a_vocab_size, case["salt"]))
+    out = {}
+    for fp64 in (False, True):
+        model = load_mhb_class(fp64)(cfg)
+        load_recipe(model, case["salt"])
+        model.eval()
+        if fp64:
+            model.double()
+        store = {}
+        hs = hook_io(model, ["linear_q_1", "linear_i_1", "linear_out"], store)
+        outp = model.forward(img.double() if fp64 else img, q, ql)
+        loss = torch.nn.KLDivLoss()(outp, soft.double() if fp64 else soft)          # solver.py:26-27 (mhb -> KLDiv)
+        loss.backward()
+        for h in hs:
+            h.remove()
+        if fp64:
+            out["out64"], out["loss64"] = outp.detach().numpy(), np.array(loss.item())
+            grad_digest(model, out, tag="64")
+        else:
+            out["out"], out["loss"] = outp.detach().numpy(), np.array(loss.item())
+            out["q_length"] = ql.numpy()
+            tensor_digest("lstm_out", store["linear_q_1.in"], out)
+            tensor_digest("i_mean_pooled", store["linear_i_1.in"], out)
+            tensor_digest("mhb_12", store["linear_out.in"], out)
+            grad_digest(model, out)
+    return out
 
 
 class _no_functional_dropout:
@@ -266,6 +354,8 @@ def main():
         jobs.append(("mfb_" + c["name"], lambda c=c: run_mfb_like(c, False)))
     for c in MHBCOATT_CASES:
         jobs.append(("mhbcoatt_" + c["name"], lambda c=c: run_mfb_like(c, True)))
+    for c in MHB_CASES:
+        jobs.append(("mhb_" + c["name"], lambda c=c: run_mhb(c)))
     for c in HIE_CASES:
         jobs.append(("hie_" + c["name"], lambda c=c: run_hie(c)))
     for c in ATTNET_CASES:

@@ -100,16 +100,18 @@ def check_grads64(named_grads, gold, tol=1e-8):
         assert d <= max(tol * max(np.abs(gold["g64samp/" + k]).max(), gn / np.sqrt(a.size)), floor), (k, d)
 
 
-def _report_parity(label, worst, worst_name):
-    """Drift visibility: the worst err/bound of every grad_parity call is printed and, on the
-    GPU box, appended to gpurun_out/grad_parity.log (copied to profiles/ per round)."""
+def _report_parity(label, worst, worst_name, detail=""):
+    """Drift visibility: the worst err/bound of every grad_parity call is printed and, on
+    the GPU box, appended to gpurun_out/grad_parity.log (copied to profiles/ per round) -- with the ABSOLUTE relative
+    errors behind it: err/|g64| and the fp32 noise term noise/|g64| of that tensor, and the largest of each over all
+    tensors of the call, so that a drift of the noise term itself (a looser bound, not a better kernel) shows."""
     import inspect
     if not label:
         for fr in inspect.stack()[2:8]:
             if fr.function.startswith("test_"):
                 label = fr.function
                 break
-    line = "grad_parity %-70s worst err/bound %.3f  (%s)" % (label or "?", worst, worst_name)
+    line = "grad_parity %-70s worst err/bound %.3f  (%s)%s" % (label or "?", worst, worst_name, detail)
     print(line)
     root = os.environ.get("GRAFT_REPO_ROOT")
     if root and os.path.isdir(os.path.join(root, "gpurun_out")):
@@ -130,7 +132,8 @@ def grad_parity(gpu_grads, g32, g64, k=8.0, floor=5e-4, label=""):
     reference's own fp32 gradients is not meaningful.
     """
     gmax = max(float(g.norm()) for g in g64.values() if g is not None)
-    worst, worst_name = 0.0, "-"
+    worst, worst_name, worst_rel = 0.0, "-", (0.0, 0.0)
+    max_err_rel, max_noise_rel = (0.0, "-"), (0.0, "-")
     for name, gg in gpu_grads.items():
         r64 = g64[name]
         if r64 is None:
@@ -142,7 +145,15 @@ def grad_parity(gpu_grads, g32, g64, k=8.0, floor=5e-4, label=""):
         err = float((gg.detach().cpu().double() - r64).norm())
         bound = max(k * noise, floor * float(r64.norm()), 1e-6 * gmax)
         assert err <= bound, (name, "err %.3e bound %.3e noise32 %.3e norm %.3e" % (err, bound, noise, float(r64.norm())))
+        n64 = float(r64.norm())
+        if n64 > 1e-6 * gmax:                      # relative errors of numerically-zero gradients say nothing
+            if err / n64 > max_err_rel[0]:
+                max_err_rel = (err / n64, name)
+            if noise / n64 > max_noise_rel[0]:
+                max_noise_rel = (noise / n64, name)
         if err / bound > worst:
-            worst, worst_name = err / bound, name
-    _report_parity(label, worst, worst_name)
+            worst, worst_name, worst_rel = err / bound, name, (err / max(n64, 1e-300), noise / max(n64, 1e-300))
+    _report_parity(label, worst, worst_name,
+                   "  err/|g64| %.2e noise/|g64| %.2e there; max over tensors: err/|g64| %.2e (%s), noise/|g64| %.2e (%s)"
+                   % (worst_rel[0], worst_rel[1], max_err_rel[0], max_err_rel[1], max_noise_rel[0], max_noise_rel[1]))
     return worst

@@ -75,15 +75,13 @@ def test_gemm_bf16_rejects_unsupported_shapes(ops):
 @pytest.mark.parametrize("mhb", [False, True])
 def test_models_in_bf16_mode_track_the_fp32_oracle(mhb):
     """gemm_dtype='bf16' (config 3): bf16 operands in img_conv1d / co_att_conv1, fp32 elsewhere.
-    Tolerance vs the fp32 oracle: 3e-2 relative on the outputs (8-bit mantissa operands, K = 2048),
-    gradients within 10 % in norm per tensor (sanity; bf16 gradients are not a parity target).
-    Excluded from the gradient check: img_conv1d / ques_proj1 (and the attention biases whose
-    gradient is mathematically 0).  Their gradient passes through the signed square root of the
-    196 000 pooled sums, whose derivative 0.5*|s|^-1/2 is dominated by the few sums nearest 0; a
-    bf16 rounding of the projection (4e-3 relative on P) replaces exactly those sums by noise, so
-    these two gradients move by O(1) (measured 75-90 %, tools/bf16_vs_fp32.py: the co_att_conv1
-    GEMMs in bf16 alone change them by 1.5 %).  That is a property of the model's loss surface,
-    not of the kernels: vqf_gemm_bf16 itself is checked to 2e-5 above."""
+    Tolerance vs the fp32 mode (parity-proven against the oracle elsewhere): 3e-2 relative on the outputs (8-bit mantissa
+    operands, K = 2048); every gradient finite; the classifier's gradient -- the one tensor downstream of every signed
+    square root -- within 10 %.  The OTHER gradients are not compared with the fp32 step's here (round 3 did, with a skip
+    list of four tensors and a private 15 % for co_att_conv1.bias: a bf16 rounding upstream of 0.5*|s|^-1/2 moves them by
+    O(10 %), which is the loss surface, not the kernels): they are checked node by node against fp64 evaluations of the same
+    nodes on the same bf16-rounded operands, with no exception list, in
+    tests/test_gpu_bf16_nodes.py::test_models_in_bf16_modes_every_node_at_full_dims."""
     import sys, os
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
     import vqa_amd, recipe
@@ -112,14 +110,9 @@ def test_models_in_bf16_mode_track_the_fp32_oracle(mhb):
     out, gb = res["bf16"]
     assert _rel(out, ref) <= 3e-2
     assert not torch.equal(out, ref)        # the bf16 kernels really ran
-    skip = ("img_conv1d", "ques_proj1", "co_att_conv2.bias", "ques_att_conv2.bias")
-    for k, g_ref in gref.items():
-        if float(g_ref.norm()) < 1e-9 or k.startswith(skip):
-            continue
-        # (co_att_conv1.bias, a sum over ReLU masks that a bf16 rounding flips, sits at 8.2-10.2 % in BOTH forms of the
-        #  normalisation -- folded into the conv (default) or materialised -- so its sanity bound is 15 %)
-        tol = 0.15 if k == "co_att_conv1.bias" else 0.1
-        assert float((gb[k] - g_ref).norm()) <= tol * float(g_ref.norm()) + 1e-9, k
+    assert all(torch.isfinite(g).all() for g in gb.values())
+    for k in ("linear_pred.weight", "linear_pred.bias"):
+        assert float((gb[k] - gref[k]).norm()) <= 0.1 * float(gref[k].norm()) + 1e-9, k
 
 
 @pytest.mark.parametrize("mhb", [False, True])

@@ -236,6 +236,10 @@ def test_attentionnet_matches_reference_golden(case):
         O.ce_loss(ox, ans.cpu()).backward()
         res.append({k: v.grad for k, v in sd.items()})
     grad_parity(_grads(model), res[0], res[1], k=6.0, floor=1e-3)
+    if case["name"].startswith("full"):
+        # the shapes the reference trains with (L = 196, T = 14, embed 512, 6 layers): also straight against the reference's
+        # own fp32 gradient digests (norm + 16 sampled entries per tensor)
+        check_grads(_grads(model), gold, 2e-2)
 
 
 @pytest.mark.parametrize("case", [pytest.param(c, id=c["name"]) for c in IBOW_CASES])

@@ -14,7 +14,7 @@ import pytest
 import torch
 
 import recipe
-from cases import MFB_CASES, MHBCOATT_CASES, make_cfg
+from cases import MFB_CASES, MHBCOATT_CASES, MHB_CASES, make_cfg
 from golden_util import load_golden, recipe_sd, mfb_inputs, rel_err, check_grads, grad_parity
 from oracle import ref_torch as O
 
@@ -255,8 +255,36 @@ def test_full_dims_gradients_vs_oracle_n16():
     grad_parity(_named_grads(model), g32, g64)
 
 
+@pytest.mark.parametrize("case", [pytest.param(c, id=c["name"]) for c in MHB_CASES])
+def test_mhb_matches_reference_golden(case):
+    """MHB (mhb_coAtt.py:153-217) against goldens of the reference class made executable by the two edits stated in
+    tests/golden/make_golden.py (shim 6): outputs 1e-4, gradient digests, and grad_parity against the pinned oracle."""
+    vqa = _vqa()
+    gold = load_golden("mhb_" + case["name"])
+    cfg = make_cfg(case)
+    N, T = case["N"], case["T"]
+    model = _no_dropout_train(_load(vqa.MHB(cfg), case["salt"]))
+    img = torch.from_numpy(recipe.img_features(N, cfg.img_feature_dim, cfg.img_feature_channel, case["salt"]))
+    qn = recipe.question_tokens(N, T, cfg.q_vocab_size, case["salt"])
+    q, ql = torch.from_numpy(qn), torch.from_numpy(recipe.question_lengths(qn))
+    assert np.array_equal(ql.numpy(), gold["q_length"])
+    soft = torch.from_numpy(recipe.soft_answers(N, cfg.a_vocab_size, case["salt"]))
+    out = model.forward(img.cuda(), q.cuda(), ql.cuda())
+    assert rel_err(out.detach().cpu().numpy(), gold["out"]) <= OUT_TOL
+    loss = torch.nn.KLDivLoss()(out, soft.cuda())
+    assert abs(loss.item() - float(gold["loss"])) <= 2e-4 * max(1e-3, abs(float(gold["loss"])))
+    loss.backward()
+    check_grads(_named_grads(model), gold, GRAD_TOL)
+    res = []
+    for dt in (torch.float32, torch.float64):
+        sd = {k: v.to(dt).requires_grad_(True) for k, v in recipe_sd(O.mhb_shapes(cfg), case["salt"]).items()}
+        O.kldiv_loss(O.mhb_forward(sd, cfg, img.to(dt), q, ql), soft.to(dt)).backward()
+        res.append({k: v.grad for k, v in sd.items()})
+    grad_parity(_named_grads(model), res[0], res[1])
+
+
 def test_mhb_module_vs_oracle():
-    """MHB (parity unpinned by the reference: class cannot run there) vs the oracle restatement."""
+    """MHB vs the oracle restatement on one more seeded case (the oracle itself is pinned: test_oracle_golden.py)."""
     vqa = _vqa()
     import types
     cfg = types.SimpleNamespace(q_vocab_size=50, a_vocab_size=30, emb_dim=24, hidden_dim=64, num_layers=1,

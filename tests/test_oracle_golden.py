@@ -19,8 +19,8 @@ import pytest
 import torch
 
 import recipe
-from cases import (MFB_CASES, MHBCOATT_CASES, HIE_CASES, ATTNET_CASES, IBOW_CASES,
-                   ATT_MODULE_CASES)
+from cases import (MFB_CASES, MHBCOATT_CASES, MHB_CASES, HIE_CASES, ATTNET_CASES, IBOW_CASES,
+                   ATT_MODULE_CASES, make_cfg)
 from golden_util import (load_golden, recipe_sd, mfb_inputs, rel_err, check_tensor_digest,
                          check_grads, check_grads64)
 from oracle import ref_torch as O
@@ -77,6 +77,47 @@ def test_mhbcoatt_oracle_matches_reference(case):
     check_tensor_digest("co_att_feature", t["va"], gold, OUT_TOL)
     loss.backward()
     check_grads({k: v.grad for k, v in sd.items()}, gold, GRAD_TOL)
+
+
+def _mhb_inputs(case):
+    cfg = make_cfg(case)
+    N, T = case["N"], case["T"]
+    img = torch.from_numpy(recipe.img_features(N, cfg.img_feature_dim, cfg.img_feature_channel, case["salt"]))
+    qn = recipe.question_tokens(N, T, cfg.q_vocab_size, case["salt"])
+    return cfg, img, torch.from_numpy(qn), torch.from_numpy(recipe.question_lengths(qn)), \
+        torch.from_numpy(recipe.soft_answers(N, cfg.a_vocab_size, case["salt"]))
+
+
+@pytest.mark.parametrize("case", _fast(MHB_CASES))
+def test_mhb_oracle_matches_reference(case):
+    """MHB (mhb_coAtt.py:153-217), pinned since round 4: the goldens come from the reference class compiled from its own
+    text with the two edits that make it executable (tests/golden/make_golden.py::load_mhb_class)."""
+    gold = load_golden("mhb_" + case["name"])
+    cfg, img, q, ql, soft = _mhb_inputs(case)
+    assert np.array_equal(ql.numpy(), gold["q_length"])
+    sd = recipe_sd(O.mhb_shapes(cfg), case["salt"], requires_grad=True)
+    t = O.mhb_forward(sd, cfg, img, q, ql, return_all=True)
+    assert rel_err(t["out"].detach().numpy(), gold["out"]) <= OUT_TOL
+    loss = O.kldiv_loss(t["out"], soft)
+    assert abs(loss.item() - float(gold["loss"])) <= 1e-4 * max(1e-3, abs(float(gold["loss"])))
+    check_tensor_digest("lstm_out", t["last"], gold, OUT_TOL)
+    check_tensor_digest("i_mean_pooled", t["i_mean"], gold, OUT_TOL)
+    check_tensor_digest("mhb_12", t["y"], gold, OUT_TOL)
+    loss.backward()
+    check_grads({k: v.grad for k, v in sd.items()}, gold, GRAD_TOL)
+
+
+@pytest.mark.parametrize("case", _fast(MHB_CASES))
+def test_mhb_oracle_fp64_matches_reference_fp64(case):
+    gold = load_golden("mhb_" + case["name"])
+    cfg, img, q, ql, soft = _mhb_inputs(case)
+    sd = {k: v.double().requires_grad_(True) for k, v in recipe_sd(O.mhb_shapes(cfg), case["salt"]).items()}
+    out = O.mhb_forward(sd, cfg, img.double(), q, ql)
+    assert rel_err(out.detach().numpy(), gold["out64"]) <= 1e-9
+    loss = O.kldiv_loss(out, soft.double())
+    assert abs(loss.item() - float(gold["loss64"])) <= 1e-10 * max(1.0, abs(float(gold["loss64"])))
+    loss.backward()
+    check_grads64({k: v.grad for k, v in sd.items()}, gold)
 
 
 def test_mhbcoatt_recurs_over_the_batch_axis():
