@@ -184,6 +184,19 @@ int vqf_group_reduce_f32(const float* in, int G, int J, int W, float* out, void*
 int vqf_relu_bwd_f32(const float* dX, const float* Y, int M, int C, float* dXpre,
                      float* dbias, void* ws, size_t ws_bytes, void* stream);
 
+/* Backward of Y = dropout(relu(pre)) (hieCoAtten.py:25-26) whose output is also pooled by an attention head (:41): the head's
+ * gradient into Y is the rank-1 term wts[m] * dpooled[m / L, :], added here instead of being materialised:
+ *   dXpre[m,c] = (dX[m,c] + wts[m] * dpooled[m / L, c]) * (Y[m,c] > 0 ? scale : 0),  scale = 1 / (1 - p)
+ * (Y > 0 <=> pre > 0 and the element was kept); wts == NULL: no rank-1 term; dbias / ws as vqf_relu_bwd_f32; in place
+ * (dXpre == dX) allowed; C % 4 == 0. */
+int vqf_relu_bwd_rank1_f32(const float* dX, const float* Y, const float* wts, const float* dpooled, int L, float scale, int M,
+                           int C, float* dXpre, float* dbias, void* ws, size_t ws_bytes, void* stream);
+/* out[k][i] = a[k][i] + b[k][i], i < n[k], for count <= 4 segments in ONE launch; dst[k][i] = src[k][i] for count <= 8
+ * segments in one launch (HOST arrays of device pointers): packing the weights of layers that share an input into one GEMM
+ * operand and summing the gradient halves back. */
+int vqf_multi_add_f32(const float* const* a, const float* const* b, float* const* out, const long long* n, int count, void* stream);
+int vqf_multi_copy_f32(const float* const* src, float* const* dst, const long long* n, int count, void* stream);
+
 /* --------------------------------------------------------------------------
  * Attention heads: hidden -> 2 glimpse logits, softmax, glimpse-weighted sum.
  * Question side (S = T):  mfb.py:81-89   / mhb_coAtt.py:83-91
@@ -334,6 +347,14 @@ int vqf_tanh_dropout_fwd(const float* a, const float* b, const uint8_t* keep, ui
 /* dx = dy * keep/(1-p) * (1 - tanh^2), tanh recovered from the saved output y */
 int vqf_tanh_dropout_bwd(const float* dy, const float* y, const uint8_t* keep, uint64_t seed,
                          float p_drop, long long n, float* dx, void* stream);
+/* The tanh stages over 2-D operands with row strides lda / ldb / ldy (column blocks of wider buffers: HieCoAtten applies fc_Wbv
+ * and fc_Wv to the same input, hieCoAtten.py:30,35, as ONE product with the concatenated weights; its halves are consumed in
+ * place).  The dropout index of element (r, c) is r * W + c -- the bits of the flat call on the contiguous (R, W) tensor.
+ * W and every stride % 4 == 0. */
+int vqf_tanh_dropout_fwd2d(const float* a, int lda, const float* b, int ldb, const uint8_t* keep, uint64_t seed, float p_drop,
+                           int R, int W, float* y, int ldy, void* stream);
+int vqf_tanh_dropout_bwd2d(const float* dy, int lddy, const float* y, int ldy, const uint8_t* keep, uint64_t seed, float p_drop,
+                           int R, int W, float* dx, int lddx, void* stream);
 /* softmax over the last axis of (R,W) and its backward   modules.py:91-92 */
 int vqf_softmax_rows_fwd(const float* x, int R, int W, float* y, void* stream);
 int vqf_softmax_rows_bwd(const float* dy, const float* y, int R, int W, float* dx, void* stream);

@@ -152,7 +152,9 @@ def grad_parity(gpu_grads, g32, g64, k=8.0, floor=5e-4, label=""):
             if noise / n64 > max_noise_rel[0]:
                 max_noise_rel = (noise / n64, name)
         if err / bound > worst:
-            worst, worst_name, worst_rel = err / bound, name, (err / max(n64, 1e-300), noise / max(n64, 1e-300))
+            tiny = n64 <= 1e-6 * gmax              # a numerically-zero gradient: its relative errors say nothing
+            worst, worst_name = err / bound, name
+            worst_rel = (float("nan"), float("nan")) if tiny else (err / n64, noise / n64)
     _report_parity(label, worst, worst_name,
                    "  err/|g64| %.2e noise/|g64| %.2e there; max over tensors: err/|g64| %.2e (%s), noise/|g64| %.2e (%s)"
                    % (worst_rel[0], worst_rel[1], max_err_rel[0], max_err_rel[1], max_noise_rel[0], max_noise_rel[1]))

@@ -46,6 +46,8 @@ enum VqfKernelId {
   KID_EMBED_BWD,
   KID_HBM_COPY,
   KID_HBM_READ,
+  KID_MULTI_ADD,
+  KID_MULTI_COPY,
   KID_COUNT
 };
 

@@ -57,6 +57,40 @@ __global__ void ew_kernel(const float* __restrict__ a, const float* __restrict__
   }
 }
 
+// The same three modes over 2-D operands with ROW STRIDES (column blocks of wider buffers: HieCoAtten's [Cv | img_] product
+// of the concatenated fc_Wbv / fc_Wv weights and its gradient buffer).  The dropout index of element (r, c) is r * W + c, i.e.
+// that of the contiguous logical (R, W) tensor: a strided call gives the bits of the flat one.
+template <int MODE>
+__global__ void ew2d_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb,
+                            const uint8_t* __restrict__ keep, uint64_t seed, uint32_t thr, float inv_keep, int R, int W4,
+                            float* __restrict__ out, int ldo) {
+  const unsigned n4 = (unsigned)R * (unsigned)W4;
+  const unsigned stride = gridDim.x * blockDim.x;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const unsigned r = i / (unsigned)W4, c4 = i - r * (unsigned)W4;
+    float sc[4];
+    keep4(keep, seed, thr, inv_keep, (long long)i, sc);
+    f32x4 x = *reinterpret_cast<const f32x4*>(a + (long long)r * lda + 4 * c4);
+    f32x4 y;
+    if (MODE == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) y[j] = x[j] * sc[j];
+    } else if (MODE == 1) {
+      if (b) x += *reinterpret_cast<const f32x4*>(b + (long long)r * ldb + 4 * c4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) y[j] = tanhf(x[j]) * sc[j];
+    } else {
+      const f32x4 yy = *reinterpret_cast<const f32x4*>(b + (long long)r * ldb + 4 * c4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float t = sc[j] > 0.f ? yy[j] / sc[j] : 0.f;
+        y[j] = x[j] * sc[j] * (1.0f - t * t);
+      }
+    }
+    *reinterpret_cast<f32x4*>(out + (long long)r * ldo + 4 * c4) = y;
+  }
+}
+
 // one wave per row
 __global__ void softmax_rows_fwd_kernel(const float* __restrict__ x, int R, int W, float* __restrict__ y) {
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -139,9 +173,36 @@ int ew_launch(int kid, const float* a, const float* b, const uint8_t* keep, uint
   return vqf_last_error();
 }
 
+template <int MODE>
+int ew2d_launch(int kid, const float* a, int lda, const float* b, int ldb, const uint8_t* keep, uint64_t seed, float p, int R,
+                int W, float* out, int ldo, void* stream) {
+  if (!a || !out || R <= 0 || W <= 0 || p < 0.f || p >= 1.f) return VQF_E_BADARG;
+  if ((W % 4) || (lda % 4) || (ldo % 4) || (b && (ldb % 4)) || (long long)R * (W / 4) >= (1LL << 31)) return VQF_E_UNSUPPORTED;
+  if (lda < W || ldo < W || (b && ldb < W)) return VQF_E_BADARG;
+  if (!aligned16(a) || !aligned16(out) || (b && !aligned16(b)) || (keep && (((uintptr_t)keep) & 3))) return VQF_E_ALIGN;
+  const uint32_t thr = (keep || p == 0.f) ? 0u : drop_threshold_host(p);
+  const float inv_keep = (keep || p > 0.f) ? 1.0f / (1.0f - p) : 1.0f;
+  long long blocks = ((long long)R * (W / 4) + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  VQF_LAUNCH(kid, ew2d_kernel<MODE>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb, keep, seed, thr,
+             inv_keep, R, W / 4, out, ldo);
+  return vqf_last_error();
+}
+
 }  // namespace
 
 extern "C" {
+
+int vqf_tanh_dropout_fwd2d(const float* a, int lda, const float* b, int ldb, const uint8_t* keep, uint64_t seed, float p_drop,
+                           int R, int W, float* y, int ldy, void* stream) {
+  return ew2d_launch<1>(KID_TANH_DROP_FWD, a, lda, b, ldb, keep, seed, p_drop, R, W, y, ldy, stream);
+}
+
+int vqf_tanh_dropout_bwd2d(const float* dy, int lddy, const float* y, int ldy, const uint8_t* keep, uint64_t seed, float p_drop,
+                           int R, int W, float* dx, int lddx, void* stream) {
+  if (!y) return VQF_E_BADARG;
+  return ew2d_launch<2>(KID_TANH_DROP_BWD, dy, lddy, y, ldy, keep, seed, p_drop, R, W, dx, lddx, stream);
+}
 
 int vqf_dropout_f32(const float* x, const uint8_t* keep, uint64_t seed, float p_drop, long long n,
                     float* y, void* stream) {

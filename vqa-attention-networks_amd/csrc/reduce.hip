@@ -63,6 +63,47 @@ __global__ void relu_bwd_kernel(const float* __restrict__ dX, const float* __res
     dXpre[i] = Y[i] > 0.f ? dX[i] : 0.f;
 }
 
+// dXpre[m, c] = (dX[m, c] + wts[m] * dpooled[m / L, c]) * (Y[m, c] > 0 ? scale : 0): backward of Y = dropout(relu(pre)) whose
+// output is ALSO pooled by an attention head (the rank-1 term is that head's gradient: never materialised); in place allowed
+__global__ void relu_bwd_rank1_kernel(const float* __restrict__ dX, const float* __restrict__ Y, const float* __restrict__ wts,
+                                      const float* __restrict__ dpooled, int L, float scale, int M, int C4,
+                                      float* __restrict__ dXpre) {
+  const unsigned n4 = (unsigned)M * (unsigned)C4;
+  const unsigned stride = gridDim.x * blockDim.x;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const unsigned m = i / (unsigned)C4, c4 = i - m * (unsigned)C4;
+    f32x4 d = *reinterpret_cast<const f32x4*>(dX + 4ll * i);
+    const f32x4 y = *reinterpret_cast<const f32x4*>(Y + 4ll * i);
+    if (wts) {
+      const float w = wts[m];
+      const f32x4 dp = *reinterpret_cast<const f32x4*>(dpooled + ((long long)(m / (unsigned)L) * C4 + c4) * 4);
+      d += dp * w;
+    }
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = y[j] > 0.f ? d[j] * scale : 0.f;
+    *reinterpret_cast<f32x4*>(dXpre + 4ll * i) = o;
+  }
+}
+
+// out[i] = a[i] + b[i] for up to 4 (a, b, out, n) segments in one launch (gradient halves of concatenated weights)
+struct AddSegs { const float* a[4]; const float* b[4]; float* out[4]; long long n[4]; int count; };
+__global__ void multi_add_kernel(const AddSegs sg) {
+  const int k = blockIdx.y;
+  if (k >= sg.count) return;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < sg.n[k]; i += stride) sg.out[k][i] = sg.a[k][i] + sg.b[k][i];
+}
+
+// dst[k][0 .. n[k]) = src[k][0 .. n[k]) for up to 8 segments in one launch (packing weights of layers that share an input)
+struct CopySegs { const float* src[8]; float* dst[8]; long long n[8]; int count; };
+__global__ void multi_copy_kernel(const CopySegs sg) {
+  const int k = blockIdx.y;
+  if (k >= sg.count) return;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < sg.n[k]; i += stride) sg.dst[k][i] = sg.src[k][i];
+}
+
 // one wave per row: Y[m,:] = R[m,:] * inv[m / L]
 __global__ void scale_rows_kernel(const float* __restrict__ R, const float* __restrict__ inv,
                                   int M, int L, int W, float* __restrict__ Y) {
@@ -214,6 +255,52 @@ int vqf_relu_bwd_f32(const float* dX, const float* Y, int M, int C, float* dXpre
   int rc = vqf_last_error();
   if (rc || !dbias) return rc;
   return vqf_colsum_f32(dXpre, M, C, C, dbias, ws, ws_bytes, stream);
+}
+
+int vqf_relu_bwd_rank1_f32(const float* dX, const float* Y, const float* wts, const float* dpooled, int L, float scale, int M,
+                           int C, float* dXpre, float* dbias, void* ws, size_t ws_bytes, void* stream) {
+  if (!dX || !Y || !dXpre || M <= 0 || C <= 0 || (wts && (!dpooled || L <= 0))) return VQF_E_BADARG;
+  if ((C % 4) || (long long)M * (C / 4) >= (1LL << 31)) return VQF_E_UNSUPPORTED;
+  if (!aligned16(dX) || !aligned16(Y) || !aligned16(dXpre) || (dpooled && !aligned16(dpooled))) return VQF_E_ALIGN;
+  long long blocks = ((long long)M * (C / 4) + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  VQF_LAUNCH(KID_RELU_BWD, relu_bwd_rank1_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dX, Y, wts, dpooled,
+             L > 0 ? L : 1, scale, M, C / 4, dXpre);
+  int rc = vqf_last_error();
+  if (rc || !dbias) return rc;
+  return vqf_colsum_f32(dXpre, M, C, C, dbias, ws, ws_bytes, stream);
+}
+
+int vqf_multi_add_f32(const float* const* a, const float* const* b, float* const* out, const long long* n, int count, void* stream) {
+  if (!a || !b || !out || !n || count <= 0 || count > 4) return VQF_E_BADARG;
+  AddSegs sg;
+  long long nmax = 0;
+  for (int k = 0; k < count; ++k) {
+    if (!a[k] || !b[k] || !out[k] || n[k] <= 0) return VQF_E_BADARG;
+    sg.a[k] = a[k]; sg.b[k] = b[k]; sg.out[k] = out[k]; sg.n[k] = n[k];
+    nmax = n[k] > nmax ? n[k] : nmax;
+  }
+  sg.count = count;
+  long long blocks = (nmax + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  VQF_LAUNCH(KID_MULTI_ADD, multi_add_kernel, dim3((unsigned)blocks, count), dim3(256), 0, (hipStream_t)stream, sg);
+  return vqf_last_error();
+}
+
+int vqf_multi_copy_f32(const float* const* src, float* const* dst, const long long* n, int count, void* stream) {
+  if (!src || !dst || !n || count <= 0 || count > 8) return VQF_E_BADARG;
+  CopySegs sg;
+  long long nmax = 0;
+  for (int k = 0; k < count; ++k) {
+    if (!src[k] || !dst[k] || n[k] <= 0) return VQF_E_BADARG;
+    sg.src[k] = src[k]; sg.dst[k] = dst[k]; sg.n[k] = n[k];
+    nmax = n[k] > nmax ? n[k] : nmax;
+  }
+  sg.count = count;
+  long long blocks = (nmax + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  VQF_LAUNCH(KID_MULTI_COPY, multi_copy_kernel, dim3((unsigned)blocks, count), dim3(256), 0, (hipStream_t)stream, sg);
+  return vqf_last_error();
 }
 
 int vqf_scale_rows(const float* R, const float* inv, int M, int L, int W, float* Y, void* stream) {

@@ -567,6 +567,112 @@ class AttPoolFn(torch.autograd.Function):
         return (dx if ctx.needs_input_grad[0] else None), dfeat, dw.view_as(w), db
 
 
+class HieCoreFn(torch.autograd.Function):
+    """HieCoAtten's ladder from the raw inputs to cat((v, q), 0).view(N, -1) (hieCoAtten.py:25-53) as ONE autograd node with a
+    hand-ordered backward, so that
+      * fc_Wbv and fc_Wv, both applied to `img` (:30,35), are ONE product with the concatenated (2E, E) weight -- [Cv | img_] =
+        img [Wbv; Wv]^T, a (N*L, 2E) buffer whose halves the later stages consume in place (row-strided operands) -- and the
+        question side likewise ([Cq | que_] = que [Wbv; Wq]^T: :31 applies fc_Wbv to the question too);
+      * their input gradients are ONE product with K = 2E over the gradient buffer [dCv | dimg_], which the batched products
+        and the tanh backward fill in place (VQF_GEMM_ACCUM where two consumers meet): no gradient-accumulation adds of the
+        (N*L, E) tensors, one weight-gradient product per side;
+      * the attention pool's gradient into `img` -- the rank-1 term av[n,l] * dv[n,:] -- is never materialised: the backward of
+        dropout(relu(img_emb(.))) adds it on the fly (vqf_relu_bwd_rank1_f32);
+      * v and q land in the two halves of one (2N, E) buffer: the reference's cat is a view.
+    drops: {tag: (keep mask | None, seed, p)} for 'img', 'que', 'C', 'Hv', 'Hq' (the always-on functional dropouts).
+    Returns (x (N, 2E), av (N,1,L), aq (N,1,T)), all differentiable."""
+
+    @staticmethod
+    def forward(ctx, imgf, ids, w_emb, b_emb, w_que, wbv, bbv, wv, bv, wq, bq, whv, bhv, whq, bhq, drops):
+        imgf, ids = _c(imgf), ids.contiguous()
+        N, L, D = imgf.shape
+        T = ids.shape[1]
+        E = w_emb.shape[0]
+        M, MT = N * L, N * T
+        dev = imgf.device
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        # :25-26  img = dropout(relu(img_emb(img_features)))   (ReLU in the GEMM epilogue, the dropout in place)
+        img = ops.gemm(imgf.view(M, D), _c(w_emb), bias=b_emb, relu=True)
+        ops.dropout(img, *drops["img"], out=img)
+        # :27-28  que = dropout(que_emb(que_features))
+        que = ops.embed_tanh_fwd(_c(w_que), ids, False).view(MT, E)
+        ops.dropout(que, *drops["que"], out=que)
+        # :30-31,35-36  the four E x E layers as two products with concatenated weights
+        Wi, bi, Wq2, bq2 = new(2 * E, E), new(2 * E), new(2 * E, E), new(2 * E)
+        ops.multi_copy([(_c(wbv), Wi[:E]), (_c(wv), Wi[E:]), (bbv, bi[:E]), (bv, bi[E:]),
+                        (_c(wbv), Wq2[:E]), (_c(wq), Wq2[E:]), (bbv, bq2[:E]), (bq, bq2[E:])])
+        CI = ops.gemm(img, Wi, bias=bi)                       # (M, 2E)  = [Cv | img_]
+        CQ = ops.gemm(que, Wq2, bias=bq2)                     # (MT, 2E) = [Cq | que_]
+        Cv3, img_3 = CI[:, :E].view(N, L, E), CI[:, E:].view(N, L, E)
+        Cq3, que_3 = CQ[:, :E].view(N, T, E), CQ[:, E:].view(N, T, E)
+        # :32-33  C = dropout(tanh(Cq Cv^T))   (N,T,L)
+        C3 = ops.bgemm(Cq3, Cv3)
+        ops.tanh_dropout_fwd(C3.view(MT, L), None, *drops["C"], out=C3.view(MT, L))
+        # :38-42  Hv = dropout(tanh(img_ + C^T que_)), av = softmax_L(Whv Hv), v = av^T img
+        tq = ops.bgemm(C3, que_3, ta=True, tb=True).view(M, E)
+        Hv = ops.tanh_dropout_fwd2d(CI[:, E:], tq, *drops["Hv"], out=tq)
+        xcat = new(2 * N, E)
+        av, _ = ops.glimpse_pool_fwd(img.view(N, L, E), ops.att_logits_fwd(Hv, _w2d(whv), bhv), False, pooled_out=xcat[:N])
+        # :45-49  Hq = dropout(tanh(que_ + C img_)), aq = softmax_T(Whq Hq), q = aq^T que
+        ti = ops.bgemm(C3, img_3, ta=False, tb=True).view(MT, E)
+        Hq = ops.tanh_dropout_fwd2d(CQ[:, E:], ti, *drops["Hq"], out=ti)
+        aq, _ = ops.glimpse_pool_fwd(que.view(N, T, E), ops.att_logits_fwd(Hq, _w2d(whq), bhq), False, pooled_out=xcat[N:])
+        ctx.save_for_backward(imgf, ids, img, que, Wi, Wq2, CI, CQ, C3, Hv, Hq, av, aq, whv, whq)
+        ctx.drops, ctx.dims, ctx.V = drops, (N, L, T, D, E), w_que.shape[0]
+        return xcat.view(N, 2 * E), av, aq                    # :52-53: cat((v, q), 0).view(N, -1) is a view of xcat
+
+    @staticmethod
+    def backward(ctx, dx, dav, daq):
+        imgf, ids, img, que, Wi, Wq2, CI, CQ, C3, Hv, Hq, av, aq, whv, whq = ctx.saved_tensors
+        N, L, T, D, E = ctx.dims
+        M, MT = N * L, N * T
+        drops = ctx.drops
+        dev = imgf.device
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        dxcat = _c(dx).view(2 * N, E)
+        dv, dq = dxcat[:N], dxcat[N:]
+        Cv3, img_3 = CI[:, :E].view(N, L, E), CI[:, E:].view(N, L, E)
+        Cq3, que_3 = CQ[:, :E].view(N, T, E), CQ[:, E:].view(N, T, E)
+        dCI, dCQ = new(M, 2 * E), new(MT, 2 * E)              # [dCv | dimg_], [dCq | dque_]
+        # question-side head: q = aq^T que, aq = softmax(Whq Hq), Hq = dropout(tanh(que_ + ti))
+        dlq, dque = ops.glimpse_pool_bwd(dq, que.view(N, T, E), aq, False, True, dwts=None if daq is None else _c(daq))
+        dHq, dwhq, dbhq, _ = ops.att_logits_bwd(dlq, Hq, _w2d(whq), relu_mask=False)
+        ops.tanh_dropout_bwd2d(dHq, Hq, *drops["Hq"], out=dCQ[:, E:])          # d(que_ + ti): first term of dque_ ...
+        dti = ops.tanh_dropout_bwd2d(dHq, Hq, *drops["Hq"], out=dHq)           # ... and, untouched by the sums below, dti (7 MB)
+        # image-side head
+        dlv, _ = ops.glimpse_pool_bwd(dv, img.view(N, L, E), av, False, False, dwts=None if dav is None else _c(dav))
+        dHv, dwhv, dbhv, _ = ops.att_logits_bwd(dlv, Hv, _w2d(whv), relu_mask=False)
+        dtq = ops.tanh_dropout_bwd2d(dHv, Hv, *drops["Hv"], out=dCI[:, E:])    # d(img_ + tq), first term of dimg_
+        del dHv
+        dti3, dtq3 = dti.view(N, T, E), dCI[:, E:].view(N, L, E)
+        # tq = C^T que_, ti = C img_:  dC = dti img_^T + que_ dtq^T;  dque_ += C dtq;  dimg_ += C^T dti
+        dC3 = ops.bgemm(dti3, img_3)
+        ops.bgemm(que_3, dtq3, out=dC3, accumulate=True)
+        ops.bgemm(C3, dtq3, ta=False, tb=True, out=dCQ[:, E:].view(N, T, E), accumulate=True)
+        ops.bgemm(C3, dti3, ta=True, tb=True, out=dtq3, accumulate=True)       # (dtq's own uses are above this line)
+        # C = dropout(tanh(Cq Cv^T)):  dCq = daff Cv,  dCv = daff^T Cq
+        ops.tanh_dropout_bwd(dC3.view(MT, L), C3.view(MT, L), *drops["C"], out=dC3.view(MT, L))
+        ops.bgemm(dC3, Cv3, ta=False, tb=True, out=dCQ[:, :E].view(N, T, E))
+        ops.bgemm(dC3, Cq3, ta=True, tb=True, out=dCI[:, :E].view(N, L, E))
+        # the concatenated layers: one input-gradient product (K = 2E), one weight-gradient product and one column sum per side
+        dimg = ops.gemm(dCI, Wi, tb=True)                                      # (M, E); the pool's rank-1 term is added below
+        ops.gemm(dCQ, Wq2, tb=True, out=dque.view(MT, E), accumulate=True)     # on top of the pool's gradient into que
+        dWi, dWq2 = ops.gemm(dCI, img, ta=True, tb=True), ops.gemm(dCQ, que, ta=True, tb=True)
+        dbi, dbq2 = ops.colsum(dCI), ops.colsum(dCQ)
+        dwbv, dbbv = new(E, E), new(E)
+        ops.multi_add([(dWi[:E], dWq2[:E], dwbv), (dbi[:E], dbq2[:E], dbbv)])  # fc_Wbv serves both sides (:30-31)
+        # img = dropout(relu(img_emb(.))): mask, 1 / (1 - p) and the pool's av[n,l] * dv[n,:] in one pass, in place
+        keep_i, _, p_i = drops["img"]
+        scale = 1.0 / (1.0 - p_i) if (keep_i is not None or p_i > 0.0) else 1.0
+        dpre, db_emb = ops.relu_bwd_rank1(dimg, img, av.view(M), dv, L, scale, want_bias=True, out=dimg)
+        dw_emb = ops.gemm(dpre, imgf.view(M, D), ta=True, tb=True)
+        dque2 = dque.view(MT, E)
+        ops.dropout(dque2, *drops["que"], out=dque2)
+        dw_que = ops.embed_tanh_bwd(dque2, None, ids, ctx.V)
+        return (None, None, dw_emb, db_emb, dw_que, dwbv, dbbv, dWi[E:], dbi[E:], dWq2[E:], dbq2[E:],
+                dwhv.view_as(whv), dbhv, dwhq.view_as(whq), dbhq, None)
+
+
 class SoftmaxRowsFn(torch.autograd.Function):
     """softmax over the last axis of a 2-D tensor (modules.py:91-92)."""
 

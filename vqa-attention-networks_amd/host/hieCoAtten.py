@@ -10,7 +10,7 @@ state_dict keys.  Reference behaviour kept on purpose:
 import torch
 import torch.nn as nn
 
-from .functions import LinearFn, DropoutFn, TanhDropFn, BmmFn, AttPoolFn, embed
+from .functions import LinearFn, DropoutFn, TanhDropFn, BmmFn, AttPoolFn, HieCoreFn, embed, _plain_embedding
 from .mfb import _DropSeeds
 
 
@@ -28,6 +28,9 @@ class HieCoAtten(nn.Module):
         self.fc_Whq = nn.Linear(embed_size, 1)
         self.fc = nn.Linear(2 * embed_size, output_size)
         self.drop_p = 0.5
+        # True (default): the whole ladder :25-53 is ONE autograd node with concatenated fc_Wbv / fc_Wv (and fc_Wbv / fc_Wq)
+        # products and a hand-ordered backward (functions.HieCoreFn); False: one node per stage, as rounds 1-3 ran it
+        self.fused = True
         self._seeds = _DropSeeds()
 
     def set_keep_masks(self, **masks):
@@ -43,6 +46,16 @@ class HieCoAtten(nn.Module):
         N, L, D = img_features.shape
         T = que_features.shape[1]
         lin = lambda x, m, relu=False: LinearFn.apply(x, m.weight, m.bias, relu)
+        E = self.img_emb.out_features
+        if (self.fused and img_features.is_cuda and img_features.dtype == torch.float32 and _plain_embedding(self.que_emb, que_features)
+                and E % 4 == 0 and L % 4 == 0 and not img_features.requires_grad):
+            drops = {tag: self._drop_args(tag) for tag in ("img", "que", "C", "Hv", "Hq")}      # the draw order of the staged form
+            x, av, aq = HieCoreFn.apply(img_features, que_features, self.img_emb.weight, self.img_emb.bias, self.que_emb.weight,
+                                        self.fc_Wbv.weight, self.fc_Wbv.bias, self.fc_Wv.weight, self.fc_Wv.bias,
+                                        self.fc_Wq.weight, self.fc_Wq.bias, self.fc_Whv.weight, self.fc_Whv.bias,
+                                        self.fc_Whq.weight, self.fc_Whq.bias, drops)
+            x = lin(x, self.fc)                                                     # :54
+            return x, torch.squeeze(av.view(N, L, 1)), torch.squeeze(aq.view(N, T, 1))   # :43,50,55
         img = lin(img_features.reshape(N * L, D), self.img_emb, True)          # :25-26 (relu fused)
         img = DropoutFn.apply(img, *self._drop_args('img'))
         E = img.shape[1]

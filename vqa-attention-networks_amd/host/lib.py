@@ -63,6 +63,11 @@ SIGNATURES = {
     "vqf_dropout_f32": (c_i, [c_f, c_p, c_u64, ctypes.c_float, ctypes.c_longlong, c_f, c_p]),
     "vqf_tanh_dropout_fwd": (c_i, [c_f, c_f, c_p, c_u64, ctypes.c_float, ctypes.c_longlong, c_f, c_p]),
     "vqf_tanh_dropout_bwd": (c_i, [c_f, c_f, c_p, c_u64, ctypes.c_float, ctypes.c_longlong, c_f, c_p]),
+    "vqf_tanh_dropout_fwd2d": (c_i, [c_f, c_i, c_f, c_i, c_p, c_u64, ctypes.c_float, c_i, c_i, c_f, c_i, c_p]),
+    "vqf_tanh_dropout_bwd2d": (c_i, [c_f, c_i, c_f, c_i, c_p, c_u64, ctypes.c_float, c_i, c_i, c_f, c_i, c_p]),
+    "vqf_relu_bwd_rank1_f32": (c_i, [c_f, c_f, c_f, c_f, c_i, ctypes.c_float, c_i, c_i, c_f, c_f, c_p, c_sz, c_p]),
+    "vqf_multi_add_f32": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p]),
+    "vqf_multi_copy_f32": (c_i, [c_p, c_p, c_p, c_i, c_p]),
     "vqf_softmax_rows_fwd": (c_i, [c_f, c_i, c_i, c_f, c_p]),
     "vqf_softmax_rows_bwd": (c_i, [c_f, c_f, c_i, c_i, c_f, c_p]),
     "vqf_log_softmax_rows_fwd": (c_i, [c_f, c_i, c_i, c_f, c_p]),

@@ -232,9 +232,19 @@ def gemm_bf16_rowscale(a, b, rowscale, rows_per_scale, bias=None, relu=False, K=
     return out
 
 
+def _chk3(*ts):
+    """3-D fp32 GPU operands of the batched GEMM: innermost dimension contiguous, row and batch strides free (column blocks
+    of wider 2-D buffers viewed as (B, rows, cols))"""
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 3 or t.stride(2) != 1:
+            raise _l.VqfError("bgemm: 3-D fp32 GPU tensors with a contiguous innermost dimension expected")
+
+
 def bgemm(a, b, ta=False, tb=False, out=None, accumulate=False):
     """Batched: a (B,M,K)|(B,K,M), b (B,N,K)|(B,K,N) -> (B,M,N)."""
-    _chk(a, b, out)
+    _chk3(a, b, out)
     Bn = a.shape[0]
     M = a.shape[2] if ta else a.shape[1]
     K = a.shape[1] if ta else a.shape[2]
@@ -313,8 +323,8 @@ def att_logits_bwd(dlogits, hid, w2, relu_mask=True, rowscale=None, rows_per_sca
     return dpre, dw2, db2, db1
 
 
-def glimpse_pool_fwd(feat, logits, unit_softmax):
-    """feat (N,S,C) fp32 | bf16, logits (N*S,G) -> wts (N,G,S), pooled (N,G*C) (fp32)."""
+def glimpse_pool_fwd(feat, logits, unit_softmax, pooled_out=None):
+    """feat (N,S,C) fp32 | bf16, logits (N*S,G) -> wts (N,G,S), pooled (N,G*C) (fp32; pooled_out: written there)."""
     bf = feat.dtype == torch.bfloat16
     (_chk_bf16 if bf else _chk)(feat)
     if not feat.is_contiguous():
@@ -323,7 +333,13 @@ def glimpse_pool_fwd(feat, logits, unit_softmax):
     N, S, C = feat.shape
     G = logits.shape[1]
     wts = torch.empty((N, G, S), dtype=torch.float32, device=feat.device)
-    pooled = torch.empty((N, G * C), dtype=torch.float32, device=feat.device)
+    if pooled_out is not None:
+        _chk(pooled_out)
+        if tuple(pooled_out.shape) != (N, G * C):
+            raise _l.VqfError("glimpse_pool_fwd: pooled_out must be (N, G*C)")
+        pooled = pooled_out
+    else:
+        pooled = torch.empty((N, G * C), dtype=torch.float32, device=feat.device)
     fn = _lib().vqf_glimpse_pool_fwd_bf16 if bf else _lib().vqf_glimpse_pool_fwd
     _l.check(fn(_ptr(feat), _ptr(logits), N, S, C, G, int(bool(unit_softmax)), _ptr(wts), _ptr(pooled), _stream()),
              "vqf_glimpse_pool_fwd")
@@ -351,28 +367,98 @@ def glimpse_pool_bwd(dpooled, feat, wts, unit_softmax, want_dfeat, dwts=None):
     return dlogits, dfeat
 
 
-def dropout(x, keep=None, seed=0, p_drop=0.5):
-    _chk(x)
-    y = torch.empty_like(x)
+def dropout(x, keep=None, seed=0, p_drop=0.5, out=None):
+    _chk(x, out)
+    y = torch.empty_like(x) if out is None else out          # in place (out is x) allowed
     _l.check(_lib().vqf_dropout_f32(_ptr(x), _keep_ptr(keep), int(seed), float(p_drop), x.numel(), _ptr(y),
                                     _stream()), "vqf_dropout_f32")
     return y
 
 
-def tanh_dropout_fwd(a, b=None, keep=None, seed=0, p_drop=0.5):
-    _chk(a, b)
-    y = torch.empty_like(a)
+def tanh_dropout_fwd(a, b=None, keep=None, seed=0, p_drop=0.5, out=None):
+    _chk(a, b, out)
+    y = torch.empty_like(a) if out is None else out           # in place (out is a) allowed
     _l.check(_lib().vqf_tanh_dropout_fwd(_ptr(a), _ptr(b), _keep_ptr(keep), int(seed), float(p_drop),
                                          a.numel(), _ptr(y), _stream()), "vqf_tanh_dropout_fwd")
     return y
 
 
-def tanh_dropout_bwd(dy, y, keep=None, seed=0, p_drop=0.5):
-    _chk(dy, y)
-    dx = torch.empty_like(y)
+def tanh_dropout_bwd(dy, y, keep=None, seed=0, p_drop=0.5, out=None):
+    _chk(dy, y, out)
+    dx = torch.empty_like(y) if out is None else out          # in place (out is dy) allowed
     _l.check(_lib().vqf_tanh_dropout_bwd(_ptr(dy), _ptr(y), _keep_ptr(keep), int(seed), float(p_drop),
                                          y.numel(), _ptr(dx), _stream()), "vqf_tanh_dropout_bwd")
     return dx
+
+
+def _chk2s(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1:
+            raise _l.VqfError("2-D fp32 GPU tensor with contiguous rows expected")
+
+
+def tanh_dropout_fwd2d(a, b=None, keep=None, seed=0, p_drop=0.5, out=None):
+    """y = dropout(tanh(a + b)) over 2-D operands whose rows may be strided (column blocks of wider buffers); out may be b."""
+    _chk2s(a, b, out)
+    R, W = a.shape
+    if out is None:
+        out = torch.empty((R, W), dtype=torch.float32, device=a.device)
+    _l.check(_lib().vqf_tanh_dropout_fwd2d(_ptr(a), a.stride(0), _ptr(b), b.stride(0) if b is not None else 0, _keep_ptr(keep),
+                                           int(seed), float(p_drop), R, W, _ptr(out), out.stride(0), _stream()),
+             "vqf_tanh_dropout_fwd2d")
+    return out
+
+
+def tanh_dropout_bwd2d(dy, y, keep=None, seed=0, p_drop=0.5, out=None):
+    """dx = dy * keep / (1 - p) * (1 - tanh^2), 2-D operands with strided rows; out may be dy."""
+    _chk2s(dy, y, out)
+    R, W = y.shape
+    if out is None:
+        out = torch.empty((R, W), dtype=torch.float32, device=y.device)
+    _l.check(_lib().vqf_tanh_dropout_bwd2d(_ptr(dy), dy.stride(0), _ptr(y), y.stride(0), _keep_ptr(keep), int(seed),
+                                           float(p_drop), R, W, _ptr(out), out.stride(0), _stream()), "vqf_tanh_dropout_bwd2d")
+    return out
+
+
+def relu_bwd_rank1(dx, y, wts, dpooled, L, scale, want_bias=True, out=None):
+    """dXpre = (dx + wts[m] * dpooled[m // L]) * (y > 0 ? scale : 0) (+ its column sums): include/vqa_fusion.h
+    vqf_relu_bwd_rank1_f32.  out may be dx (in place)."""
+    _chk(dx, y, wts, dpooled, out)
+    M, C = y.shape
+    dpre = torch.empty_like(y) if out is None else out
+    db = torch.empty(C, dtype=torch.float32, device=y.device) if want_bias else None
+    ws = workspace(y.device, _lib().vqf_colsum_ws_bytes(M, C))
+    _l.check(_lib().vqf_relu_bwd_rank1_f32(_ptr(dx), _ptr(y), _ptr(wts), _ptr(dpooled), int(L), float(scale), M, C, _ptr(dpre),
+                                           _ptr(db), _ptr(ws), ws.numel(), _stream()), "vqf_relu_bwd_rank1_f32")
+    return dpre, db
+
+
+def _ptr_array(ts):
+    return (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+
+
+def multi_copy(pairs):
+    """[(src, dst), ...] (<= 8 contiguous fp32 GPU tensors of equal size per pair): dst = src, ONE launch"""
+    for a, b in pairs:
+        _chk(a, b)
+        if a.numel() != b.numel():
+            raise _l.VqfError("multi_copy: sizes differ")
+    n = (ctypes.c_longlong * len(pairs))(*[a.numel() for a, _ in pairs])
+    _l.check(_lib().vqf_multi_copy_f32(_ptr_array([a for a, _ in pairs]), _ptr_array([b for _, b in pairs]), n, len(pairs),
+                                       _stream()), "vqf_multi_copy_f32")
+
+
+def multi_add(triples):
+    """[(a, b, out), ...] (<= 4): out = a + b, ONE launch"""
+    for a, b, o in triples:
+        _chk(a, b, o)
+        if not (a.numel() == b.numel() == o.numel()):
+            raise _l.VqfError("multi_add: sizes differ")
+    n = (ctypes.c_longlong * len(triples))(*[a.numel() for a, _, _ in triples])
+    _l.check(_lib().vqf_multi_add_f32(_ptr_array([t[0] for t in triples]), _ptr_array([t[1] for t in triples]),
+                                      _ptr_array([t[2] for t in triples]), n, len(triples), _stream()), "vqf_multi_add_f32")
 
 
 def softmax_rows_fwd(x):
