@@ -355,6 +355,33 @@ int vqf_tanh_dropout_fwd2d(const float* a, int lda, const float* b, int ldb, con
                            int R, int W, float* y, int ldy, void* stream);
 int vqf_tanh_dropout_bwd2d(const float* dy, int lddy, const float* y, int ldy, const uint8_t* keep, uint64_t seed, float p_drop,
                            int R, int W, float* dx, int lddx, void* stream);
+/* --------------------------------------------------------------------------
+ * HieCoAtten's co-attention ladder (hieCoAtten.py:32-49): the stages with a tiny inner / outer extent T (words per question)
+ * as single streaming passes over the rows of the (N*L, E) tensors (csrc/hie.hip), neighbouring element-wise stage fused in.
+ * Rows m = n*L + l of a / z / out may be strided (lda / ldz / ldo; column blocks of the concatenated-weight products);
+ * C, U: (N, T, L) contiguous; V: rows n*T + t, stride ldv.  part: (S, N*T, E) partial sums over the S = vqf_hie_chunks(N, L)
+ * row chunks of a sample -- add them up with vqf_hie_slab_sum (fixed order, no atomics).  Supported (vqf_hie_stream_supported):
+ * T <= 16, E % 4 == 0, E / 4 divides 256, T * E small enough for LDS; else VQF_E_UNSUPPORTED (the caller uses the batched GEMMs).
+ *   vqf_hie_hv_fwd     out = dropout(tanh(a + C^T V)) (:38-39, Hv; a = img_, V = que_);  part[t] += C[t,l] a[l]  (:45, ti = C img_)
+ *   vqf_hie_head_bwd   out = dl[l] w sc (1 - (hv/sc)^2): gradient of :38-40 w.r.t. img_ + tq from the logit gradient dl (N*L) of
+ *                      fc_Whv (weight w (E)), dHv never materialised;  part[t] += C[t,l] out[l]  (-> dque_);  wpart (S*N, E+4):
+ *                      partial rows [sum_l dl[l] hv[l,:] | sum_l dl[l] | 0 0 0]  (column sums -> d fc_Whv.weight, d fc_Whv.bias)
+ *   vqf_hie_rank_add   out = a + U^T V                 (dimg_ += C^T dti; in place allowed)
+ *   vqf_hie_rank_left  out = U^T V;  part[t] += U[t,l] z[l]      (dCv = daff^T Cq;  dCq = daff Cv)
+ *   vqf_hie_slab_sum   out[r,:] = (add ? add[r,:] : 0) + sum_s part[s][r][:],  r < R, W columns */
+int vqf_hie_stream_supported(int N, int L, int E, int T);
+int vqf_hie_chunks(int N, int L);
+int vqf_hie_hv_fwd(const float* a, int lda, const float* C, const float* V, int ldv, const uint8_t* keep, uint64_t seed,
+                   float p_drop, int N, int L, int E, int T, float* out, int ldo, float* part, void* stream);
+int vqf_hie_head_bwd(const float* hv, int ldh, const float* dl, const float* w, const float* C, const uint8_t* keep,
+                     uint64_t seed, float p_drop, int N, int L, int E, int T, float* out, int ldo, float* part, float* wpart,
+                     void* stream);
+int vqf_hie_rank_add(const float* a, int lda, const float* U, const float* V, int ldv, int N, int L, int E, int T, float* out,
+                     int ldo, void* stream);
+int vqf_hie_rank_left(const float* U, const float* V, int ldv, const float* z, int ldz, int N, int L, int E, int T, float* out,
+                      int ldo, float* part, void* stream);
+int vqf_hie_slab_sum(const float* part, int S, int R, int W, const float* add, int lda, float* out, int ldo, void* stream);
+
 /* softmax over the last axis of (R,W) and its backward   modules.py:91-92 */
 int vqf_softmax_rows_fwd(const float* x, int R, int W, float* y, void* stream);
 int vqf_softmax_rows_bwd(const float* dy, const float* y, int R, int W, float* dx, void* stream);

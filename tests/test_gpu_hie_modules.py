@@ -138,12 +138,24 @@ def _hie_oracle_pair(case, img, q, ans, drop=None):
     return res[0][0], res[0][1], res[1][1]
 
 
+@pytest.fixture(params=["stream", "bgemm", "staged"])
+def hie_form(request):
+    """The three executions of the ladder: one node with the tiny-T stages as streaming passes (default; csrc/hie.hip), one
+    node with batched GEMMs + element-wise kernels (what unsupported shapes get: T > 16 ...), one node per stage (rounds 1-3)."""
+    vqa = _vqa()
+    old = vqa.functions.HieCoreFn.STREAM
+    vqa.functions.HieCoreFn.STREAM = request.param == "stream"
+    yield request.param
+    vqa.functions.HieCoreFn.STREAM = old
+
+
 @pytest.mark.parametrize("case", [pytest.param(c, id=c["name"]) for c in HIE_CASES])
-def test_hiecoatten_matches_reference_golden(case):
+def test_hiecoatten_matches_reference_golden(case, hie_form):
     vqa = _vqa()
     gold = load_golden("hie_" + case["name"])
     model = _load(vqa.HieCoAtten(block_num=case["L"], word_num=case["T"], img_size=case["img_size"],
                                  vocab_size=case["V"], embed_size=case["E"], output_size=case["A"]), case["salt"])
+    model.fused = hie_form != "staged"
     model.drop_p = 0.0            # goldens were captured with the functional dropout patched to identity
     img, q, ans = _hie_inputs(case)
     N = case["N"]
@@ -160,12 +172,14 @@ def test_hiecoatten_matches_reference_golden(case):
     assert model.fc_Wbq.weight.grad is None            # hieCoAtten.py:31: never used
 
 
-def test_hiecoatten_always_on_dropout_with_explicit_masks():
+@pytest.mark.parametrize("ci", [2, 0])
+def test_hiecoatten_always_on_dropout_with_explicit_masks(ci, hie_form):
     vqa = _vqa()
-    case = HIE_CASES[2]
+    case = HIE_CASES[ci]                  # [2]: T = 22 (batched-GEMM form even when "stream" is asked for), [0]: T = 7
     N, L, T, E = case["N"], case["L"], case["T"], case["E"]
     model = _load(vqa.HieCoAtten(block_num=L, word_num=T, img_size=case["img_size"], vocab_size=case["V"],
                                  embed_size=E, output_size=case["A"]), case["salt"]).eval()   # eval: still drops
+    model.fused = hie_form != "staged"
     img, q, ans = _hie_inputs(case)
     shapes = dict(img=(N * L, E), que=(N * T, E), C=(N * T, L), Hv=(N * L, E), Hq=(N * T, E))
     masks = {k: torch.from_numpy(recipe.keep_mask(s, 0.5, "hie_" + k)) for k, s in shapes.items()}
@@ -186,11 +200,12 @@ def test_hiecoatten_always_on_dropout_with_explicit_masks():
     assert not torch.equal(a, b)
 
 
-def test_hiecoatten_attention_outputs_are_differentiable():
+def test_hiecoatten_attention_outputs_are_differentiable(hie_form):
     vqa = _vqa()
     case = HIE_CASES[1]
     model = _load(vqa.HieCoAtten(block_num=case["L"], word_num=case["T"], img_size=case["img_size"],
                                  vocab_size=case["V"], embed_size=case["E"], output_size=case["A"]), case["salt"])
+    model.fused = hie_form != "staged"
     model.drop_p = 0.0
     img, q, ans = _hie_inputs(case)
     x, av, aq = model.forward(img, q)
@@ -319,6 +334,33 @@ def test_config4_hiecoatten_full_batch_256_row_pairing():
         ox, oav, _ = O.hiecoatten_forward(sd, img[2 * i:2 * i + 2], q[2 * i:2 * i + 2])
         assert rel_err(x[i].detach().cpu().numpy(), ox[0].numpy()) <= OUT_TOL
         assert rel_err(av[2 * i:2 * i + 2].detach().cpu().numpy(), oav.numpy()) <= OUT_TOL
+
+
+def test_hiecoatten_philox_masks_are_the_same_in_every_form():
+    """The in-kernel Philox masks are indexed by the element's position in the logical tensor, so the three executions of the
+    ladder draw the SAME masks from the same seeds: outputs and gradients agree to rounding (re-association only)."""
+    vqa = _vqa()
+    case = HIE_CASES[0]
+    img, q, ans = _hie_inputs(case)
+    res = {}
+    for form in ("stream", "bgemm", "staged"):
+        model = _load(vqa.HieCoAtten(block_num=case["L"], word_num=case["T"], img_size=case["img_size"], vocab_size=case["V"],
+                                     embed_size=case["E"], output_size=case["A"]), case["salt"])
+        model.fused = form != "staged"
+        vqa.functions.HieCoreFn.STREAM = form == "stream"
+        try:
+            torch.manual_seed(77)                      # the seeds of the five masks come from torch's CPU generator
+            x, av, aq = model.forward(img, q)
+            torch.nn.CrossEntropyLoss()(x, ans).backward()
+        finally:
+            vqa.functions.HieCoreFn.STREAM = True
+        res[form] = (x.detach().clone(), {k: v.clone() for k, v in _grads(model).items() if v is not None})
+    assert float(res["staged"][0].abs().max()) > 0
+    for form in ("stream", "bgemm"):
+        assert rel_err(res[form][0].cpu().numpy(), res["staged"][0].cpu().numpy()) <= 1e-5, form
+        for k, g in res["staged"][1].items():
+            d = float((res[form][1][k] - g).norm())
+            assert d <= 1e-4 * float(g.norm()) + 1e-9, (form, k, d, float(g.norm()))
 
 
 def test_config4_hiecoatten_full_batch_256_gradients_vs_oracle():

@@ -64,13 +64,33 @@ def wrap(name, real):
     return f
 
 
-ops.gemm, ops.gemm_bf16 = wrap("f32", ops.gemm), wrap("bf16", ops.gemm_bf16)
+def wrap_b(real):
+    def f(a_, b_, ta=False, tb=False, **kw):
+        Bn = a_.shape[0]
+        M = a_.shape[2] if ta else a_.shape[1]
+        K = a_.shape[1] if ta else a_.shape[2]
+        N = b_.shape[2] if tb else b_.shape[1]
+        torch.cuda.synchronize()
+        ops.prof_reset(); ops.prof_enable(True)
+        out = real(a_, b_, ta=ta, tb=tb, **kw)
+        torch.cuda.synchronize()
+        ops.prof_enable(False)
+        ms = sum(v[1] for v in ops.prof_report().values())
+        key = ("b%d" % Bn, int(bool(ta)), int(bool(tb)), M, N, K, bool(kw.get("accumulate")))
+        r = rec.setdefault(key, [0, 0.0, 0, 0.0])
+        r[0] += 1; r[1] += ms
+        return out
+    return f
+
+
+ops.gemm, ops.gemm_bf16, ops.bgemm = wrap("f32", ops.gemm), wrap("bf16", ops.gemm_bf16), wrap_b(ops.bgemm)
 step()
 torch.cuda.synchronize()
 tot = 0.0
 print("%-5s %-5s %7s %6s %7s %4s %6s %9s %8s %7s %9s" % ("type", "ta,tb", "M", "N", "K", "acc", "calls", "ms/call", "TF", "reduces", "red ms"))
 for (name, ta, tb, M, N, K, acc), (n, ms, nr, rms) in sorted(rec.items(), key=lambda kv: -(kv[1][1] + kv[1][3])):
+    nb = int(name[1:]) if name.startswith("b") and name[1:].isdigit() else 1
     print("%-5s (%d,%d) %7d %6d %7d %4s %6d %9.4f %8.1f %7d %9.4f" % (name, ta, tb, M, N, K, "acc" if acc else "", n, ms / n,
-                                                                     2.0 * M * N * K * n / ms / 1e9, nr, rms))
+                                                                     2.0 * nb * M * N * K * n / ms / 1e9, nr, rms))
     tot += ms + rms
 print("total GEMM + reduce time per step: %.3f ms" % tot)

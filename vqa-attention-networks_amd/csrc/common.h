@@ -48,6 +48,11 @@ enum VqfKernelId {
   KID_HBM_READ,
   KID_MULTI_ADD,
   KID_MULTI_COPY,
+  KID_HIE_FWD,
+  KID_HIE_HEAD,
+  KID_HIE_ADD,
+  KID_HIE_LEFT,
+  KID_HIE_SLABSUM,
   KID_COUNT
 };
 

@@ -48,7 +48,7 @@ const char* const kNames[KID_COUNT] = {
     "gemm_bf16", "cast_f32_bf16",
     "lstm_seq_fwd(all steps)", "lstm_seq_bwd(all steps)",
     "ce_loss", "kldiv_loss", "adam_step", "feat_transpose",
-    "lstm_cell_fwd", "lstm_cell_bwd", "embed_tanh_fwd", "embed_tanh_bwd", "hbm_copy", "hbm_read_sweep", "multi_add", "multi_copy"};
+    "lstm_cell_fwd", "lstm_cell_bwd", "embed_tanh_fwd", "embed_tanh_bwd", "hbm_copy", "hbm_read_sweep", "multi_add", "multi_copy", "hie_hv_fwd", "hie_head_bwd", "hie_rank_add", "hie_rank_left", "hie_slab_sum"};
 
 hipEvent_t get_event() {
   std::lock_guard<std::mutex> lk(g_mu);

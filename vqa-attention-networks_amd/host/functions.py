@@ -582,6 +582,8 @@ class HieCoreFn(torch.autograd.Function):
     drops: {tag: (keep mask | None, seed, p)} for 'img', 'que', 'C', 'Hv', 'Hq' (the always-on functional dropouts).
     Returns (x (N, 2E), av (N,1,L), aq (N,1,T)), all differentiable."""
 
+    STREAM = True      # the tiny-T stages as streaming passes (csrc/hie.hip) where supported; False: batched GEMMs + element-wise (A/B)
+
     @staticmethod
     def forward(ctx, imgf, ids, w_emb, b_emb, w_que, wbv, bbv, wv, bv, wq, bq, whv, bhv, whq, bhq, drops):
         imgf, ids = _c(imgf), ids.contiguous()
@@ -608,17 +610,24 @@ class HieCoreFn(torch.autograd.Function):
         # :32-33  C = dropout(tanh(Cq Cv^T))   (N,T,L)
         C3 = ops.bgemm(Cq3, Cv3)
         ops.tanh_dropout_fwd(C3.view(MT, L), None, *drops["C"], out=C3.view(MT, L))
-        # :38-42  Hv = dropout(tanh(img_ + C^T que_)), av = softmax_L(Whv Hv), v = av^T img
-        tq = ops.bgemm(C3, que_3, ta=True, tb=True).view(M, E)
-        Hv = ops.tanh_dropout_fwd2d(CI[:, E:], tq, *drops["Hv"], out=tq)
+        # :38-42  Hv = dropout(tanh(img_ + C^T que_)), av = softmax_L(Whv Hv), v = av^T img;  :45  ti = C img_
+        stream = HieCoreFn.STREAM and ops.hie_stream_supported(N, L, E, T)
+        if stream:
+            # ONE pass over img_: the rank-T update, tanh, dropout, and the T-row sums of ti in registers (csrc/hie.hip)
+            part = new(ops.hie_chunks(N, L), MT, E)
+            Hv = ops.hie_hv_fwd(CI[:, E:], C3, CQ[:, E:], drops["Hv"], N, L, T, new(M, E), part)
+            ti = ops.hie_slab_sum(part, new(MT, E))
+        else:
+            tq = ops.bgemm(C3, que_3, ta=True, tb=True).view(M, E)
+            Hv = ops.tanh_dropout_fwd2d(CI[:, E:], tq, *drops["Hv"], out=tq)
+            ti = ops.bgemm(C3, img_3, ta=False, tb=True).view(MT, E)
         xcat = new(2 * N, E)
         av, _ = ops.glimpse_pool_fwd(img.view(N, L, E), ops.att_logits_fwd(Hv, _w2d(whv), bhv), False, pooled_out=xcat[:N])
         # :45-49  Hq = dropout(tanh(que_ + C img_)), aq = softmax_T(Whq Hq), q = aq^T que
-        ti = ops.bgemm(C3, img_3, ta=False, tb=True).view(MT, E)
         Hq = ops.tanh_dropout_fwd2d(CQ[:, E:], ti, *drops["Hq"], out=ti)
         aq, _ = ops.glimpse_pool_fwd(que.view(N, T, E), ops.att_logits_fwd(Hq, _w2d(whq), bhq), False, pooled_out=xcat[N:])
         ctx.save_for_backward(imgf, ids, img, que, Wi, Wq2, CI, CQ, C3, Hv, Hq, av, aq, whv, whq)
-        ctx.drops, ctx.dims, ctx.V = drops, (N, L, T, D, E), w_que.shape[0]
+        ctx.drops, ctx.dims, ctx.V, ctx.stream = drops, (N, L, T, D, E), w_que.shape[0], stream
         return xcat.view(N, 2 * E), av, aq                    # :52-53: cat((v, q), 0).view(N, -1) is a view of xcat
 
     @staticmethod
@@ -637,23 +646,40 @@ class HieCoreFn(torch.autograd.Function):
         # question-side head: q = aq^T que, aq = softmax(Whq Hq), Hq = dropout(tanh(que_ + ti))
         dlq, dque = ops.glimpse_pool_bwd(dq, que.view(N, T, E), aq, False, True, dwts=None if daq is None else _c(daq))
         dHq, dwhq, dbhq, _ = ops.att_logits_bwd(dlq, Hq, _w2d(whq), relu_mask=False)
-        ops.tanh_dropout_bwd2d(dHq, Hq, *drops["Hq"], out=dCQ[:, E:])          # d(que_ + ti): first term of dque_ ...
+        if not ctx.stream:
+            ops.tanh_dropout_bwd2d(dHq, Hq, *drops["Hq"], out=dCQ[:, E:])      # d(que_ + ti): first term of dque_ ...
         dti = ops.tanh_dropout_bwd2d(dHq, Hq, *drops["Hq"], out=dHq)           # ... and, untouched by the sums below, dti (7 MB)
         # image-side head
         dlv, _ = ops.glimpse_pool_bwd(dv, img.view(N, L, E), av, False, False, dwts=None if dav is None else _c(dav))
-        dHv, dwhv, dbhv, _ = ops.att_logits_bwd(dlv, Hv, _w2d(whv), relu_mask=False)
-        dtq = ops.tanh_dropout_bwd2d(dHv, Hv, *drops["Hv"], out=dCI[:, E:])    # d(img_ + tq), first term of dimg_
-        del dHv
         dti3, dtq3 = dti.view(N, T, E), dCI[:, E:].view(N, L, E)
-        # tq = C^T que_, ti = C img_:  dC = dti img_^T + que_ dtq^T;  dque_ += C dtq;  dimg_ += C^T dti
-        dC3 = ops.bgemm(dti3, img_3)
-        ops.bgemm(que_3, dtq3, out=dC3, accumulate=True)
-        ops.bgemm(C3, dtq3, ta=False, tb=True, out=dCQ[:, E:].view(N, T, E), accumulate=True)
-        ops.bgemm(C3, dti3, ta=True, tb=True, out=dtq3, accumulate=True)       # (dtq's own uses are above this line)
-        # C = dropout(tanh(Cq Cv^T)):  dCq = daff Cv,  dCv = daff^T Cq
-        ops.tanh_dropout_bwd(dC3.view(MT, L), C3.view(MT, L), *drops["C"], out=dC3.view(MT, L))
-        ops.bgemm(dC3, Cv3, ta=False, tb=True, out=dCQ[:, :E].view(N, T, E))
-        ops.bgemm(dC3, Cq3, ta=True, tb=True, out=dCI[:, :E].view(N, L, E))
+        if ctx.stream:
+            # dtq = d(img_ + tq) straight from the logit gradient (dHv = dlv (x) whv is never written), C dtq and dlv^T Hv on the way
+            S = ops.hie_chunks(N, L)
+            part, wpart = new(S, MT, E), new(S * N, E + 4)
+            ops.hie_head_bwd(Hv, dlv.view(M), whv.view(E), C3, drops["Hv"], N, L, T, dCI[:, E:], part, wpart)
+            wsum = ops.colsum(wpart)
+            dwhv, dbhv = wsum[:E], wsum[E:E + 1]
+            dC3 = ops.bgemm(dti3, img_3)                                           # dC = dti img_^T + que_ dtq^T
+            ops.bgemm(que_3, dtq3, out=dC3, accumulate=True)
+            ops.hie_slab_sum(part, dCQ[:, E:], add=dti)                            # dque_ = dti + C dtq
+            ops.hie_rank_add(dCI[:, E:], C3, dti, N, L, T, dCI[:, E:])             # dimg_ = dtq + C^T dti (dtq's own uses are above)
+            # C = dropout(tanh(Cq Cv^T)):  dCv = daff^T Cq,  dCq = daff Cv   (one pass over Cv)
+            ops.tanh_dropout_bwd(dC3.view(MT, L), C3.view(MT, L), *drops["C"], out=dC3.view(MT, L))
+            ops.hie_rank_left(dC3, CQ[:, :E], CI[:, :E], N, L, T, dCI[:, :E], part)
+            ops.hie_slab_sum(part, dCQ[:, :E])
+        else:
+            dHv, dwhv, dbhv, _ = ops.att_logits_bwd(dlv, Hv, _w2d(whv), relu_mask=False)
+            ops.tanh_dropout_bwd2d(dHv, Hv, *drops["Hv"], out=dCI[:, E:])          # d(img_ + tq), first term of dimg_
+            del dHv
+            # tq = C^T que_, ti = C img_:  dC = dti img_^T + que_ dtq^T;  dque_ += C dtq;  dimg_ += C^T dti
+            dC3 = ops.bgemm(dti3, img_3)
+            ops.bgemm(que_3, dtq3, out=dC3, accumulate=True)
+            ops.bgemm(C3, dtq3, ta=False, tb=True, out=dCQ[:, E:].view(N, T, E), accumulate=True)
+            ops.bgemm(C3, dti3, ta=True, tb=True, out=dtq3, accumulate=True)       # (dtq's own uses are above this line)
+            # C = dropout(tanh(Cq Cv^T)):  dCq = daff Cv,  dCv = daff^T Cq
+            ops.tanh_dropout_bwd(dC3.view(MT, L), C3.view(MT, L), *drops["C"], out=dC3.view(MT, L))
+            ops.bgemm(dC3, Cv3, ta=False, tb=True, out=dCQ[:, :E].view(N, T, E))
+            ops.bgemm(dC3, Cq3, ta=True, tb=True, out=dCI[:, :E].view(N, L, E))
         # the concatenated layers: one input-gradient product (K = 2E), one weight-gradient product and one column sum per side
         dimg = ops.gemm(dCI, Wi, tb=True)                                      # (M, E); the pool's rank-1 term is added below
         ops.gemm(dCQ, Wq2, tb=True, out=dque.view(MT, E), accumulate=True)     # on top of the pool's gradient into que

@@ -461,6 +461,72 @@ def multi_add(triples):
                                       _ptr_array([t[2] for t in triples]), n, len(triples), _stream()), "vqf_multi_add_f32")
 
 
+# ---------------------------------------------------------------------------
+# HieCoAtten's ladder as streaming passes (csrc/hie.hip; include/vqa_fusion.h vqf_hie_*)
+def hie_stream_supported(N, L, E, T):
+    return bool(_lib().vqf_hie_stream_supported(int(N), int(L), int(E), int(T)))
+
+
+def hie_chunks(N, L):
+    return int(_lib().vqf_hie_chunks(int(N), int(L)))
+
+
+def _chk_ntl(u, N, T, L):
+    _chk(u)
+    if u.numel() != N * T * L:
+        raise _l.VqfError("hie: the (N, T, L) coefficient tensor has the wrong size")
+
+
+def hie_hv_fwd(a, C, V, drop, N, L, T, out, part):
+    """out = dropout(tanh(a + C^T V)); part (S, N*T, E) = per-chunk sums of C[t,l] a[l,:]"""
+    _chk2s(a, V, out)
+    _chk(part)
+    _chk_ntl(C, N, T, L)
+    E = a.shape[1]
+    keep, seed, p = drop
+    _l.check(_lib().vqf_hie_hv_fwd(_ptr(a), a.stride(0), _ptr(C), _ptr(V), V.stride(0), _keep_ptr(keep), int(seed), float(p),
+                                   N, L, E, T, _ptr(out), out.stride(0), _ptr(part), _stream()), "vqf_hie_hv_fwd")
+    return out
+
+
+def hie_head_bwd(hv, dl, w, C, drop, N, L, T, out, part, wpart):
+    _chk2s(hv, out)
+    _chk(dl, w, part, wpart)
+    _chk_ntl(C, N, T, L)
+    E = hv.shape[1]
+    keep, seed, p = drop
+    _l.check(_lib().vqf_hie_head_bwd(_ptr(hv), hv.stride(0), _ptr(dl), _ptr(w), _ptr(C), _keep_ptr(keep), int(seed), float(p),
+                                     N, L, E, T, _ptr(out), out.stride(0), _ptr(part), _ptr(wpart), _stream()), "vqf_hie_head_bwd")
+    return out
+
+
+def hie_rank_add(a, U, V, N, L, T, out):
+    _chk2s(a, V, out)
+    _chk_ntl(U, N, T, L)
+    _l.check(_lib().vqf_hie_rank_add(_ptr(a), a.stride(0), _ptr(U), _ptr(V), V.stride(0), N, L, a.shape[1], T, _ptr(out),
+                                     out.stride(0), _stream()), "vqf_hie_rank_add")
+    return out
+
+
+def hie_rank_left(U, V, z, N, L, T, out, part):
+    _chk2s(V, z, out)
+    _chk(part)
+    _chk_ntl(U, N, T, L)
+    _l.check(_lib().vqf_hie_rank_left(_ptr(U), _ptr(V), V.stride(0), _ptr(z), z.stride(0), N, L, z.shape[1], T, _ptr(out),
+                                      out.stride(0), _ptr(part), _stream()), "vqf_hie_rank_left")
+    return out
+
+
+def hie_slab_sum(part, out, add=None):
+    """out[r,:] = (add[r,:] if add is given) + sum_s part[s, r, :]; part (S, R, W) contiguous, add / out 2-D, rows may be strided"""
+    _chk(part)
+    _chk2s(add, out)
+    S, R, W = part.shape
+    _l.check(_lib().vqf_hie_slab_sum(_ptr(part), S, R, W, _ptr(add), add.stride(0) if add is not None else 0, _ptr(out),
+                                     out.stride(0), _stream()), "vqf_hie_slab_sum")
+    return out
+
+
 def softmax_rows_fwd(x):
     _chk(x)
     R, W = x.shape
