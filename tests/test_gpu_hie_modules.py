@@ -356,11 +356,12 @@ def test_hiecoatten_philox_masks_are_the_same_in_every_form():
             vqa.functions.HieCoreFn.STREAM = True
         res[form] = (x.detach().clone(), {k: v.clone() for k, v in _grads(model).items() if v is not None})
     assert float(res["staged"][0].abs().max()) > 0
+    gmax = max(float(g.norm()) for g in res["staged"][1].values())
     for form in ("stream", "bgemm"):
         assert rel_err(res[form][0].cpu().numpy(), res["staged"][0].cpu().numpy()) <= 1e-5, form
         for k, g in res["staged"][1].items():
-            d = float((res[form][1][k] - g).norm())
-            assert d <= 1e-4 * float(g.norm()) + 1e-9, (form, k, d, float(g.norm()))
+            d = float((res[form][1][k] - g).norm())      # (the softmax biases carry a mathematically-zero gradient: gmax floor)
+            assert d <= 1e-4 * float(g.norm()) + 1e-6 * gmax, (form, k, d, float(g.norm()))
 
 
 def test_config4_hiecoatten_full_batch_256_gradients_vs_oracle():

@@ -24,6 +24,40 @@ __global__ void colsum_partial_kernel(const float* __restrict__ in, int M, int N
   partial[(long long)blockIdx.y * N + c] = (a0 + a1) + (a2 + a3);
 }
 
+// The same with 16-byte loads: thread = 4 consecutive columns x one of RS row slots (RS = 256 / (columns / 4) per column tile of
+// <= 1024 columns), eight rows in flight per thread, the slots folded through LDS in a fixed order.  N % 4 == 0, ld % 4 == 0.
+__global__ void __launch_bounds__(256) colsum_partial_vec_kernel(const float* __restrict__ in, int M, int N, int ld,
+                                                                 float* __restrict__ partial) {
+  __shared__ f32x4 red[256];
+  const int tile_c4 = min(256, (N >> 2) - blockIdx.x * 256);      // float4 columns of this column tile
+  int CT = 1;
+  while (CT < tile_c4) CT <<= 1;                                  // threads per row: a power of two >= the tile's float4 columns
+  const int RS = 256 / CT;
+  const int tid = threadIdx.x, c4 = tid % CT, rs = tid / CT;
+  const bool live = c4 < tile_c4;
+  const int r0 = blockIdx.y * CS_ROWS, r1 = min(M, r0 + CS_ROWS);
+  const float* p = in + 4ll * (blockIdx.x * 256 + c4);
+  f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  if (live) {
+    int r = r0 + rs;
+    for (; r + 7 * RS < r1; r += 8 * RS) {
+      f32x4 v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const f32x4*>(p + (long long)(r + q * RS) * ld);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc[q & 3] += v[q];
+    }
+    for (; r < r1; r += RS) acc[0] += *reinterpret_cast<const f32x4*>(p + (long long)r * ld);
+  }
+  red[tid] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  __syncthreads();
+  if (rs == 0 && live) {
+    f32x4 sum = red[c4];
+    for (int q = 1; q < RS; ++q) sum += red[q * CT + c4];
+    *reinterpret_cast<f32x4*>(partial + (long long)blockIdx.y * N + 4ll * (blockIdx.x * 256 + c4)) = sum;
+  }
+}
+
 // out[g, c] = sum_{j<J} in[(g*J + j), c]
 __global__ void group_reduce_kernel(const float* __restrict__ in, int G, int J, int W,
                                     float* __restrict__ out) {
@@ -64,25 +98,56 @@ __global__ void relu_bwd_kernel(const float* __restrict__ dX, const float* __res
 }
 
 // dXpre[m, c] = (dX[m, c] + wts[m] * dpooled[m / L, c]) * (Y[m, c] > 0 ? scale : 0): backward of Y = dropout(relu(pre)) whose
-// output is ALSO pooled by an attention head (the rank-1 term is that head's gradient: never materialised); in place allowed
-__global__ void relu_bwd_rank1_kernel(const float* __restrict__ dX, const float* __restrict__ Y, const float* __restrict__ wts,
-                                      const float* __restrict__ dpooled, int L, float scale, int M, int C4,
-                                      float* __restrict__ dXpre) {
-  const unsigned n4 = (unsigned)M * (unsigned)C4;
-  const unsigned stride = gridDim.x * blockDim.x;
-  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    const unsigned m = i / (unsigned)C4, c4 = i - m * (unsigned)C4;
-    f32x4 d = *reinterpret_cast<const f32x4*>(dX + 4ll * i);
-    const f32x4 y = *reinterpret_cast<const f32x4*>(Y + 4ll * i);
-    if (wts) {
-      const float w = wts[m];
-      const f32x4 dp = *reinterpret_cast<const f32x4*>(dpooled + ((long long)(m / (unsigned)L) * C4 + c4) * 4);
-      d += dp * w;
-    }
-    f32x4 o;
+// output is ALSO pooled by an attention head (the rank-1 term is that head's gradient: never materialised); in place allowed.
+// Workgroup = CS_ROWS rows x a column tile of <= 1024 columns, thread = 4 columns x a row slot (as colsum_partial_vec_kernel);
+// partial != nullptr: the column sums of the workgroup's rows go to partial[blockIdx.y][:] (the bias gradient, no second pass).
+__global__ void __launch_bounds__(256) relu_bwd_rank1_kernel(const float* __restrict__ dX, const float* __restrict__ Y,
+                                                             const float* __restrict__ wts, const float* __restrict__ dpooled,
+                                                             int L, float scale, int M, int C, float* __restrict__ dXpre,
+                                                             float* __restrict__ partial) {
+  __shared__ f32x4 red[256];
+  const int tile_c4 = min(256, (C >> 2) - blockIdx.x * 256);
+  int CT = 1;
+  while (CT < tile_c4) CT <<= 1;
+  const int RS = 256 / CT;
+  const int tid = threadIdx.x, c4 = tid % CT, rs = tid / CT;
+  const bool live = c4 < tile_c4;
+  const int r0 = blockIdx.y * CS_ROWS, r1 = min(M, r0 + CS_ROWS);
+  const long long col = 4ll * (blockIdx.x * 256 + c4);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (live) {
+    for (int r = r0 + rs; r < r1; r += 2 * RS) {
+      const int rb = min(r + RS, r1 - 1);                  // second row of the trip (a tail trip re-reads row r: not stored)
+      const bool hasB = r + RS < r1;
+      f32x4 dA = *reinterpret_cast<const f32x4*>(dX + (long long)r * C + col);
+      f32x4 dB = *reinterpret_cast<const f32x4*>(dX + (long long)rb * C + col);
+      const f32x4 yA = *reinterpret_cast<const f32x4*>(Y + (long long)r * C + col);
+      const f32x4 yB = *reinterpret_cast<const f32x4*>(Y + (long long)rb * C + col);
+      if (wts) {
+        dA += *reinterpret_cast<const f32x4*>(dpooled + (long long)(r / L) * C + col) * wts[r];
+        dB += *reinterpret_cast<const f32x4*>(dpooled + (long long)(rb / L) * C + col) * wts[rb];
+      }
+      f32x4 oA, oB;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = y[j] > 0.f ? d[j] * scale : 0.f;
-    *reinterpret_cast<f32x4*>(dXpre + 4ll * i) = o;
+      for (int j = 0; j < 4; ++j) {
+        oA[j] = yA[j] > 0.f ? dA[j] * scale : 0.f;
+        oB[j] = yB[j] > 0.f ? dB[j] * scale : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(dXpre + (long long)r * C + col) = oA;
+      acc += oA;
+      if (hasB) {
+        *reinterpret_cast<f32x4*>(dXpre + (long long)rb * C + col) = oB;
+        acc += oB;
+      }
+    }
+  }
+  if (!partial) return;
+  red[tid] = acc;
+  __syncthreads();
+  if (rs == 0 && live) {
+    f32x4 sum = red[c4];
+    for (int q = 1; q < RS; ++q) sum += red[q * CT + c4];
+    *reinterpret_cast<f32x4*>(partial + (long long)blockIdx.y * C + col) = sum;
   }
 }
 
@@ -230,7 +295,11 @@ int vqf_colsum_f32(const float* dY, int M, int N, int ldy, float* db, void* ws, 
     return vqf_last_error();
   }
   if (!ws || ws_bytes < vqf_colsum_ws_bytes(M, N)) return VQF_E_WORKSPACE;
-  VQF_LAUNCH(KID_COLSUM, colsum_partial_kernel, grid, dim3(256), 0, s, dY, M, N, ldy, (float*)ws);
+  if ((N % 4) == 0 && (ldy % 4) == 0 && aligned16(dY) && aligned16(ws)) {      // 16-byte loads, eight rows in flight per thread
+    VQF_LAUNCH(KID_COLSUM, colsum_partial_vec_kernel, dim3((N / 4 + 255) / 256, nb), dim3(256), 0, s, dY, M, N, ldy, (float*)ws);
+  } else {
+    VQF_LAUNCH(KID_COLSUM, colsum_partial_kernel, grid, dim3(256), 0, s, dY, M, N, ldy, (float*)ws);
+  }
   int rc = vqf_last_error();
   if (rc) return rc;
   return vqf_colreduce_2stage((const float*)ws, nb, N, db, (float*)ws + (size_t)nb * N, s);
@@ -260,15 +329,23 @@ int vqf_relu_bwd_f32(const float* dX, const float* Y, int M, int C, float* dXpre
 int vqf_relu_bwd_rank1_f32(const float* dX, const float* Y, const float* wts, const float* dpooled, int L, float scale, int M,
                            int C, float* dXpre, float* dbias, void* ws, size_t ws_bytes, void* stream) {
   if (!dX || !Y || !dXpre || M <= 0 || C <= 0 || (wts && (!dpooled || L <= 0))) return VQF_E_BADARG;
-  if ((C % 4) || (long long)M * (C / 4) >= (1LL << 31)) return VQF_E_UNSUPPORTED;
+  if (C % 4) return VQF_E_UNSUPPORTED;
   if (!aligned16(dX) || !aligned16(Y) || !aligned16(dXpre) || (dpooled && !aligned16(dpooled))) return VQF_E_ALIGN;
-  long long blocks = ((long long)M * (C / 4) + 255) / 256;
-  if (blocks > 16384) blocks = 16384;
-  VQF_LAUNCH(KID_RELU_BWD, relu_bwd_rank1_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dX, Y, wts, dpooled,
-             L > 0 ? L : 1, scale, M, C / 4, dXpre);
+  hipStream_t s = (hipStream_t)stream;
+  const int nb = (M + CS_ROWS - 1) / CS_ROWS;
+  float* partial = nullptr;
+  if (dbias) {
+    if (nb == 1) partial = dbias;
+    else {
+      if (!ws || !aligned16(ws) || ws_bytes < vqf_colsum_ws_bytes(M, C)) return VQF_E_WORKSPACE;
+      partial = (float*)ws;
+    }
+  }
+  VQF_LAUNCH(KID_RELU_BWD, relu_bwd_rank1_kernel, dim3((C / 4 + 255) / 256, nb), dim3(256), 0, s, dX, Y, wts, dpooled,
+             L > 0 ? L : 1, scale, M, C, dXpre, partial);
   int rc = vqf_last_error();
-  if (rc || !dbias) return rc;
-  return vqf_colsum_f32(dXpre, M, C, C, dbias, ws, ws_bytes, stream);
+  if (rc || !dbias || nb == 1) return rc;
+  return vqf_colreduce_2stage(partial, nb, C, dbias, partial + (size_t)nb * C, s);
 }
 
 int vqf_multi_add_f32(const float* const* a, const float* const* b, float* const* out, const long long* n, int count, void* stream) {
