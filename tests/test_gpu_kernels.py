@@ -68,6 +68,66 @@ def test_gemm_relu_accumulate_and_splitk(ops):
     assert _rel(out2, torch.relu(ref + C0)) <= 1e-5
 
 
+@pytest.mark.parametrize("ta,tb,M,N,K,extras", [
+    (0, 0, 512, 5000, 2048, "bias"),            # ques_proj1 (mfb.py:92): 160 tiles, split-K
+    (0, 1, 512, 2048, 5000, ""),                # its dgrad
+    (1, 1, 640, 512, 8192, "accum+relu"),       # deep-K weight-gradient layout, accumulate + ReLU in the combine
+    (0, 0, 300, 77, 4100, "bias+relu"),         # nothing aligned: the element-wise combine path, ragged tiles
+    (0, 0, 256, 1000, 1024, "bias"),            # HieCoAtten's fc (hieCoAtten.py:54)
+    (1, 1, 1000, 1024, 3584, ""),
+])
+def test_splitk_combined_in_the_launch_has_the_bits_of_the_two_launch_form(ops, ta, tb, M, N, K, extras):
+    """Split-K products combine their K slices INSIDE the GEMM launch (each tile's last-arriving workgroup sums the slabs in
+    split order): bit-identical to the slabs + vqf_splitk_reduce form of rounds 1-3 (option gemm_splitk_fused = 0), run to run
+    (the arrival counters are left at zero), on two streams at once, and no reduce launch is left."""
+    A = _rand((K, M) if ta else (M, K), 51).float().cuda()
+    B = _rand((K, N) if tb else (N, K), 52).float().cuda()
+    bias = _rand((N,), 53).float().cuda() if "bias" in extras else None
+    C0 = _rand((M, N), 54).float().cuda()
+    kw = dict(ta=bool(ta), tb=bool(tb), bias=bias, relu="relu" in extras)
+
+    def run():
+        if "accum" in extras:
+            out = C0.clone()
+            return ops.gemm(A, B, out=out, accumulate=True, **kw)
+        return ops.gemm(A, B, **kw)
+    with ops.options(gemm_splitk_fused=0):
+        ops.prof_reset(); ops.prof_enable(True)
+        two = run()
+        torch.cuda.synchronize()
+        ops.prof_enable(False)
+        assert ops.prof_report().get("splitk_reduce", (0, 0))[0] == 1, "this shape does not split K: pick another one"
+    ops.prof_reset(); ops.prof_enable(True)
+    one = run()
+    torch.cuda.synchronize()
+    ops.prof_enable(False)
+    rep = ops.prof_report()
+    ops.prof_reset()
+    assert "splitk_reduce" not in rep and sum(n for n, _ in rep.values()) == 1
+    assert torch.equal(one, two)
+    for _ in range(3):                                  # counters back at zero: the same bits again and again
+        assert torch.equal(run(), two)
+    side = torch.cuda.Stream()                          # two launches in flight: disjoint counter words of the ring
+    side.wait_stream(torch.cuda.current_stream())
+    outs = []
+    for _ in range(4):
+        with torch.cuda.stream(side):
+            outs.append(run())
+        outs.append(run())
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    assert all(torch.equal(o, two) for o in outs)
+    Ad, Bd = A.double().cpu(), B.double().cpu()
+    ref = (Ad.t() if ta else Ad) @ (Bd if tb else Bd.t())
+    if bias is not None:
+        ref = ref + bias.double().cpu()
+    if "accum" in extras:
+        ref = ref + C0.double().cpu()
+    if "relu" in extras:
+        ref = torch.relu(ref)
+    assert _rel(one, ref) <= 2e-6 * max(1.0, np.sqrt(K) / 8)
+
+
 def test_gemm_unaligned_views(ops):
     """odd leading dimensions / offsets force the scalar-load path."""
     M, N, K = 70, 50, 45

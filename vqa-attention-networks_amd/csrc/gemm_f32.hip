@@ -27,6 +27,7 @@
 //   * split-K (grid.y) with a deterministic slab reduction for the wgrad
 //     shapes (few output tiles, K = N*196).
 #include "common.h"
+#include <atomic>
 
 namespace {
 
@@ -73,6 +74,7 @@ struct GemmArgs {
   const float* rowscale;   // epilogue: C = rowscale[(row0 + row) / rps] * acc + bias (vqf_gemm_f32_rowscale), or nullptr
   int rps;
   int row0;                // rows of the product that another launch computed (the large-tile kernel's whole-rounds block)
+  int* cnt;                // split-K combined IN the launch: one arrival counter per output tile (zero before and after), or nullptr
 };
 
 // Thread -> (row, k) of its i-th float4 in the K-contiguous ("RK") tile image.  A ds_write_b128
@@ -378,6 +380,95 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& g, float* smem, co
   }
 }
 
+// Split-K combined inside the GEMM launch (cdna_hip_programming.md, "In-launch split-K reduction"): every K-slice workgroup
+// has written its partial tile to its slab with plain stores; it drains them, the workgroup meets at a barrier, ONE lane
+// releases at agent scope (the slabs of a tile may come from different XCDs, whose L2s are not coherent) and draws a ticket
+// from the tile's counter.  The LAST arriver acquires and sums the tile's slabs z = 0 .. splits-1 IN THAT ORDER -- whoever
+// arrived when -- then bias / accumulate / ReLU exactly as splitk_reduce_kernel does: the result has the bits of the two-launch
+// form.  Nobody waits for anybody (no spin, every wave reaches its exit); the last arriver leaves the counter at zero.
+// Returns true in the workgroup that has just written the tile.  `scratch`: 4 bytes of the kernel's ONE LDS array.
+__device__ __forceinline__ bool splitk_combine_tile(const GemmArgs& g, int tile, int splits, int m0, int n0, int tid,
+                                                    float* scratch) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int ticket = __hip_atomic_fetch_add(g.cnt + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *reinterpret_cast<volatile int*>(scratch) = ticket;
+  }
+  __syncthreads();
+  const int ticket = *reinterpret_cast<volatile int*>(scratch);
+  if (ticket != splits - 1) return false;
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(g.cnt + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+  }
+  __syncthreads();
+  const long long total = (long long)g.M * g.N;
+  const bool relu = g.flags & VQF_GEMM_RELU, accum = g.flags & VQF_GEMM_ACCUM;
+  const int c4 = tid & 31, r8 = tid >> 5;
+  const int col = n0 + 4 * c4;
+  if ((g.N & 3) == 0 && (g.ldc & 3) == 0 && aligned16_dev(g.C) && aligned16_dev(g.slab) && (!g.bias || aligned16_dev(g.bias))) {
+    if (col >= g.N) return true;
+    const f32x4 bv = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < BM / 8; k += 2) {
+      const int rowA = m0 + r8 + 8 * k, rowB = rowA + 8;
+      if (rowA >= g.M) break;
+      const bool hasB = rowB < g.M;
+      const float* pA = g.slab + (long long)rowA * g.N + col;
+      const float* pB = g.slab + (long long)(hasB ? rowB : rowA) * g.N + col;
+      f32x4 vA = {0.f, 0.f, 0.f, 0.f}, vB = vA;
+      int z = 0;
+      for (; z + 3 < splits; z += 4) {
+        f32x4 a[4], b[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          a[q] = *reinterpret_cast<const f32x4*>(pA + (z + q) * total);
+          b[q] = *reinterpret_cast<const f32x4*>(pB + (z + q) * total);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { vA += a[q]; vB += b[q]; }
+      }
+      for (; z < splits; ++z) {
+        vA += *reinterpret_cast<const f32x4*>(pA + z * total);
+        vB += *reinterpret_cast<const f32x4*>(pB + z * total);
+      }
+      vA += bv; vB += bv;
+      float* cA = g.C + (long long)rowA * g.ldc + col;
+      float* cB = g.C + (long long)rowB * g.ldc + col;
+      if (accum) {
+        vA += *reinterpret_cast<const f32x4*>(cA);
+        if (hasB) vB += *reinterpret_cast<const f32x4*>(cB);
+      }
+      if (relu) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { vA[j] = fmaxf(vA[j], 0.f); vB[j] = fmaxf(vB[j], 0.f); }
+      }
+      *reinterpret_cast<f32x4*>(cA) = vA;
+      if (hasB) *reinterpret_cast<f32x4*>(cB) = vB;
+    }
+    return true;
+  }
+  for (int k = 0; k < BM / 8; ++k) {                       // unaligned shapes: element by element
+    const int row = m0 + r8 + 8 * k;
+    if (row >= g.M) break;
+    for (int j = 0; j < 4; ++j) {
+      if (col + j >= g.N) break;
+      const long long i = (long long)row * g.N + col + j;
+      float v = 0.f;
+      for (int z = 0; z < splits; ++z) v += g.slab[z * total + i];
+      if (g.bias) v += g.bias[col + j];
+      float* pc = g.C + (long long)row * g.ldc + col + j;
+      if (accum) v += *pc;
+      if (relu) v = fmaxf(v, 0.f);
+      *pc = v;
+    }
+  }
+  return true;
+}
+
 template <bool TA, bool TB, bool FAST>
 __global__ void __launch_bounds__(NTHREADS, VQF_GEMM_WAVES_PER_SIMD) gemm_f32_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -448,6 +539,7 @@ __global__ void __launch_bounds__(NTHREADS, VQF_GEMM_WAVES_PER_SIMD) gemm_f32_ke
       }
     }
   }
+  if (to_slab && g.cnt) splitk_combine_tile(g, bid, (int)gridDim.y, m0, n0, tid, smem);
 }
 
 // C = sum_z slab[z] + bias (+C) (relu);  float4 over flattened (M,N) when possible
@@ -487,6 +579,30 @@ int launch_gemm(const GemmArgs& g, dim3 grid, hipStream_t s, int kid) {
 }
 
 }  // namespace
+
+// Arrival counters of the in-launch split-K combine: a ring of zero words in device memory (one copy per device: a module
+// global).  A launch takes `tiles` consecutive words; its last arrivers leave them at zero, so the ring needs no clearing
+// between launches, and concurrent launches (two streams) hold different words as long as fewer than VQF_SPLITK_RING tiles are
+// in flight.  nullptr: no counters (the caller runs the two-launch form).
+constexpr int VQF_SPLITK_RING = 1 << 16;
+__device__ int vqf_splitk_ring[VQF_SPLITK_RING];      // zero-initialised when the code object is loaded
+int* vqf_splitk_counters(int tiles) {
+  static int* base[64] = {};
+  static std::atomic<unsigned> next{0};
+  if (tiles <= 0 || tiles > VQF_SPLITK_RING / 4) return nullptr;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (!base[dev]) {
+    void* q = nullptr;
+    if (hipGetSymbolAddress(&q, HIP_SYMBOL(vqf_splitk_ring)) != hipSuccess) return nullptr;
+    base[dev] = (int*)q;
+  }
+  unsigned cur = next.load(std::memory_order_relaxed), start;
+  do {
+    start = (cur % VQF_SPLITK_RING) + (unsigned)tiles <= (unsigned)VQF_SPLITK_RING ? cur % VQF_SPLITK_RING : 0u;   // contiguous
+  } while (!next.compare_exchange_weak(cur, start + (unsigned)tiles, std::memory_order_relaxed));
+  return base[dev] + start;
+}
 
 // shared with gemm_bf16.hip
 int vqf_splitk_reduce(const float* slab, int splits, int M, int N, float* C, int ldc,
@@ -560,7 +676,7 @@ static int gemm_tile128(int ta, int tb, int M, int N, int K, const float* A, int
   g.A = A; g.B = B; g.C = C; g.bias = bias; g.slab = nullptr;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.flags = flags;
   g.sA = g.sB = g.sC = 0;
-  g.rowscale = rowscale; g.rps = rps; g.row0 = row0;
+  g.rowscale = rowscale; g.rps = rps; g.row0 = row0; g.cnt = nullptr;
   g.tiles_m = (M + BM - 1) / BM;
   g.tiles_n = (N + BN - 1) / BN;
   g.vecA = aligned16(A) && (lda % 4 == 0);
@@ -589,7 +705,11 @@ static int gemm_tile128(int ta, int tb, int M, int N, int K, const float* A, int
   int kt_per = (ktiles + splits - 1) / splits;
   g.kchunk = kt_per * BK;
   splits = (K + g.kchunk - 1) / g.kchunk;
-  if (splits > 1) g.slab = (float*)ws;
+  if (splits > 1) {
+    g.slab = (float*)ws;
+    // combined inside this launch by each tile's last-arriving workgroup (option gemm_splitk_fused = 0: a second launch)
+    if (vqf_opt(VQF_OPT_GEMM_SPLITK_FUSED, 1) != 0) g.cnt = vqf_splitk_counters((int)tiles);
+  }
 
   dim3 grid((unsigned)tiles, (unsigned)splits);
   const int kid = KID_GEMM_A0B0 + 2 * (ta ? 1 : 0) + (tb ? 1 : 0);
@@ -601,7 +721,7 @@ static int gemm_tile128(int ta, int tb, int M, int N, int K, const float* A, int
   else if (ta && !tb) rc = launch_gemm<true, false>(g, grid, s, kid);
   else rc = launch_gemm<true, true>(g, grid, s, kid);
   if (rc != VQF_OK) return rc;
-  if (splits > 1) rc = vqf_splitk_reduce((const float*)ws, splits, M, N, C, ldc, bias, flags, s);
+  if (splits > 1 && !g.cnt) rc = vqf_splitk_reduce((const float*)ws, splits, M, N, C, ldc, bias, flags, s);
   return rc;
 }
 
@@ -618,7 +738,7 @@ extern "C" int vqf_gemm_f32_batched(int ta, int tb, int batch, int M, int N, int
   g.A = A; g.B = B; g.C = C; g.bias = nullptr; g.slab = nullptr;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.flags = flags;
   g.sA = strideA; g.sB = strideB; g.sC = strideC;
-  g.rowscale = nullptr; g.rps = 1; g.row0 = 0;
+  g.rowscale = nullptr; g.rps = 1; g.row0 = 0; g.cnt = nullptr;
   g.tiles_m = (M + BM - 1) / BM;
   g.tiles_n = (N + BN - 1) / BN;
   g.vecA = aligned16(A) && (lda % 4 == 0) && (strideA % 4 == 0);

@@ -4,7 +4,10 @@
 
 namespace {
 
-constexpr int CS_ROWS = 256;   // rows folded by one colsum block
+constexpr int CS_ROWS = 256;   // rows folded by one colsum block ...
+// ... of the scalar kernel; the 16-byte kernels fold fewer rows per workgroup on tall tensors, so that a (50176, 512) tensor is
+// 784 workgroups, not 196 (one column tile wide: fewer workgroups than CUs)
+static inline int cs_rows_vec(int M) { return M > 16384 ? 64 : CS_ROWS; }
 
 // partial[b, c] = sum over rows [b*CS_ROWS, ...) of in[r, c];  thread = column
 __global__ void colsum_partial_kernel(const float* __restrict__ in, int M, int N, int ld,
@@ -26,7 +29,7 @@ __global__ void colsum_partial_kernel(const float* __restrict__ in, int M, int N
 
 // The same with 16-byte loads: thread = 4 consecutive columns x one of RS row slots (RS = 256 / (columns / 4) per column tile of
 // <= 1024 columns), eight rows in flight per thread, the slots folded through LDS in a fixed order.  N % 4 == 0, ld % 4 == 0.
-__global__ void __launch_bounds__(256) colsum_partial_vec_kernel(const float* __restrict__ in, int M, int N, int ld,
+__global__ void __launch_bounds__(256) colsum_partial_vec_kernel(const float* __restrict__ in, int M, int N, int ld, int rpb,
                                                                  float* __restrict__ partial) {
   __shared__ f32x4 red[256];
   const int tile_c4 = min(256, (N >> 2) - blockIdx.x * 256);      // float4 columns of this column tile
@@ -35,7 +38,7 @@ __global__ void __launch_bounds__(256) colsum_partial_vec_kernel(const float* __
   const int RS = 256 / CT;
   const int tid = threadIdx.x, c4 = tid % CT, rs = tid / CT;
   const bool live = c4 < tile_c4;
-  const int r0 = blockIdx.y * CS_ROWS, r1 = min(M, r0 + CS_ROWS);
+  const int r0 = blockIdx.y * rpb, r1 = min(M, r0 + rpb);
   const float* p = in + 4ll * (blockIdx.x * 256 + c4);
   f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
   if (live) {
@@ -103,8 +106,8 @@ __global__ void relu_bwd_kernel(const float* __restrict__ dX, const float* __res
 // partial != nullptr: the column sums of the workgroup's rows go to partial[blockIdx.y][:] (the bias gradient, no second pass).
 __global__ void __launch_bounds__(256) relu_bwd_rank1_kernel(const float* __restrict__ dX, const float* __restrict__ Y,
                                                              const float* __restrict__ wts, const float* __restrict__ dpooled,
-                                                             int L, float scale, int M, int C, float* __restrict__ dXpre,
-                                                             float* __restrict__ partial) {
+                                                             int L, float scale, int M, int C, int rpb,
+                                                             float* __restrict__ dXpre, float* __restrict__ partial) {
   __shared__ f32x4 red[256];
   const int tile_c4 = min(256, (C >> 2) - blockIdx.x * 256);
   int CT = 1;
@@ -112,7 +115,7 @@ __global__ void __launch_bounds__(256) relu_bwd_rank1_kernel(const float* __rest
   const int RS = 256 / CT;
   const int tid = threadIdx.x, c4 = tid % CT, rs = tid / CT;
   const bool live = c4 < tile_c4;
-  const int r0 = blockIdx.y * CS_ROWS, r1 = min(M, r0 + CS_ROWS);
+  const int r0 = blockIdx.y * rpb, r1 = min(M, r0 + rpb);
   const long long col = 4ll * (blockIdx.x * 256 + c4);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   if (live) {
@@ -281,7 +284,8 @@ extern "C" {
 
 size_t vqf_colsum_ws_bytes(int M, int N) {
   if (M <= 0 || N <= 0) return 0;
-  return (size_t)((M + CS_ROWS - 1) / CS_ROWS + VQF_REDUCE_SPLITS) * (size_t)N * sizeof(float);
+  const int rpb = cs_rows_vec(M);
+  return (size_t)((M + rpb - 1) / rpb + VQF_REDUCE_SPLITS) * (size_t)N * sizeof(float);
 }
 
 int vqf_colsum_f32(const float* dY, int M, int N, int ldy, float* db, void* ws, size_t ws_bytes,
@@ -295,14 +299,18 @@ int vqf_colsum_f32(const float* dY, int M, int N, int ldy, float* db, void* ws, 
     return vqf_last_error();
   }
   if (!ws || ws_bytes < vqf_colsum_ws_bytes(M, N)) return VQF_E_WORKSPACE;
+  int nbv = nb;
   if ((N % 4) == 0 && (ldy % 4) == 0 && aligned16(dY) && aligned16(ws)) {      // 16-byte loads, eight rows in flight per thread
-    VQF_LAUNCH(KID_COLSUM, colsum_partial_vec_kernel, dim3((N / 4 + 255) / 256, nb), dim3(256), 0, s, dY, M, N, ldy, (float*)ws);
+    const int rpb = cs_rows_vec(M);
+    nbv = (M + rpb - 1) / rpb;
+    VQF_LAUNCH(KID_COLSUM, colsum_partial_vec_kernel, dim3((N / 4 + 255) / 256, nbv), dim3(256), 0, s, dY, M, N, ldy, rpb,
+               (float*)ws);
   } else {
     VQF_LAUNCH(KID_COLSUM, colsum_partial_kernel, grid, dim3(256), 0, s, dY, M, N, ldy, (float*)ws);
   }
   int rc = vqf_last_error();
   if (rc) return rc;
-  return vqf_colreduce_2stage((const float*)ws, nb, N, db, (float*)ws + (size_t)nb * N, s);
+  return vqf_colreduce_2stage((const float*)ws, nbv, N, db, (float*)ws + (size_t)nbv * N, s);
 }
 
 int vqf_group_reduce_f32(const float* in, int G, int J, int W, float* out, void* stream) {
@@ -332,7 +340,8 @@ int vqf_relu_bwd_rank1_f32(const float* dX, const float* Y, const float* wts, co
   if (C % 4) return VQF_E_UNSUPPORTED;
   if (!aligned16(dX) || !aligned16(Y) || !aligned16(dXpre) || (dpooled && !aligned16(dpooled))) return VQF_E_ALIGN;
   hipStream_t s = (hipStream_t)stream;
-  const int nb = (M + CS_ROWS - 1) / CS_ROWS;
+  const int rpb = cs_rows_vec(M);
+  const int nb = (M + rpb - 1) / rpb;
   float* partial = nullptr;
   if (dbias) {
     if (nb == 1) partial = dbias;
@@ -342,7 +351,7 @@ int vqf_relu_bwd_rank1_f32(const float* dX, const float* Y, const float* wts, co
     }
   }
   VQF_LAUNCH(KID_RELU_BWD, relu_bwd_rank1_kernel, dim3((C / 4 + 255) / 256, nb), dim3(256), 0, s, dX, Y, wts, dpooled,
-             L > 0 ? L : 1, scale, M, C, dXpre, partial);
+             L > 0 ? L : 1, scale, M, C, rpb, dXpre, partial);
   int rc = vqf_last_error();
   if (rc || !dbias || nb == 1) return rc;
   return vqf_colreduce_2stage(partial, nb, C, dbias, partial + (size_t)nb * C, s);
