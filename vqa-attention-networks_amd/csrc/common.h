@@ -148,6 +148,101 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Split-K combined inside the GEMM launch (cdna_hip_programming.md, "In-launch split-K reduction"): every K-slice workgroup
+// has written its partial tile to its slab with plain stores; it drains them, the workgroup meets at a barrier, ONE lane
+// releases at agent scope (the slabs of a tile may come from different XCDs, whose L2s are not coherent) and draws a ticket
+// from the tile's counter.  The LAST arriver acquires and sums the tile's slabs z = 0 .. splits-1 IN THAT ORDER -- whoever
+// arrived when -- then bias / accumulate / ReLU exactly as splitk_reduce_kernel (gemm_f32.hip) does: the result has the bits of
+// the two-launch form.  Nobody waits for anybody (no spin: every wave reaches its exit); the last arriver leaves the counter at
+// zero.  slab: [splits][M][N] fp32.  Returns true in the workgroup that wrote the tile.  `scratch`: 4 bytes of the kernel's ONE
+// LDS array (free at this point).  TILE_N / 4 must divide NT.
+struct VqfSplitkTile { int* cnt; const float* slab; float* C; const float* bias; int M, N, ldc, flags; };
+template <int TILE_M, int TILE_N, int NT>
+__device__ __forceinline__ bool vqf_splitk_combine(const VqfSplitkTile& g, int tile, int splits, int m0, int n0, int tid,
+                                                   float* scratch) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int ticket = __hip_atomic_fetch_add(g.cnt + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *reinterpret_cast<volatile int*>(scratch) = ticket;
+  }
+  __syncthreads();
+  const int ticket = *reinterpret_cast<volatile int*>(scratch);
+  __syncthreads();                                          // (scratch may be reused by the caller's next tile)
+  if (ticket != splits - 1) return false;
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(g.cnt + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+  }
+  __syncthreads();
+  constexpr int CT = TILE_N / 4, RSTEP = NT / CT;
+  static_assert(NT % CT == 0, "TILE_N / 4 must divide the workgroup size");
+  const long long total = (long long)g.M * g.N;
+  const bool relu = g.flags & VQF_GEMM_RELU, accum = g.flags & VQF_GEMM_ACCUM;
+  const int c4 = tid % CT, r0 = tid / CT;
+  const int col = n0 + 4 * c4;
+  if ((g.N & 3) == 0 && (g.ldc & 3) == 0 && aligned16_dev(g.C) && aligned16_dev(g.slab) && (!g.bias || aligned16_dev(g.bias))) {
+    if (col >= g.N) return true;
+    const f32x4 bv = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < TILE_M / RSTEP; k += 2) {
+      const int rowA = m0 + r0 + RSTEP * k, rowB = rowA + RSTEP;
+      if (rowA >= g.M) break;
+      const bool hasB = rowB < g.M && k + 1 < TILE_M / RSTEP;
+      const float* pA = g.slab + (long long)rowA * g.N + col;
+      const float* pB = g.slab + (long long)(hasB ? rowB : rowA) * g.N + col;
+      f32x4 vA = {0.f, 0.f, 0.f, 0.f}, vB = vA;
+      int z = 0;
+      for (; z + 3 < splits; z += 4) {
+        f32x4 a[4], b[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          a[q] = *reinterpret_cast<const f32x4*>(pA + (z + q) * total);
+          b[q] = *reinterpret_cast<const f32x4*>(pB + (z + q) * total);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { vA += a[q]; vB += b[q]; }
+      }
+      for (; z < splits; ++z) {
+        vA += *reinterpret_cast<const f32x4*>(pA + z * total);
+        vB += *reinterpret_cast<const f32x4*>(pB + z * total);
+      }
+      vA += bv; vB += bv;
+      float* cA = g.C + (long long)rowA * g.ldc + col;
+      float* cB = g.C + (long long)rowB * g.ldc + col;
+      if (accum) {
+        vA += *reinterpret_cast<const f32x4*>(cA);
+        if (hasB) vB += *reinterpret_cast<const f32x4*>(cB);
+      }
+      if (relu) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { vA[j] = fmaxf(vA[j], 0.f); vB[j] = fmaxf(vB[j], 0.f); }
+      }
+      *reinterpret_cast<f32x4*>(cA) = vA;
+      if (hasB) *reinterpret_cast<f32x4*>(cB) = vB;
+    }
+    return true;
+  }
+  for (int k = 0; k < TILE_M / RSTEP; ++k) {               // unaligned shapes: element by element
+    const int row = m0 + r0 + RSTEP * k;
+    if (row >= g.M) break;
+    for (int j = 0; j < 4; ++j) {
+      if (col + j >= g.N) break;
+      const long long i = (long long)row * g.N + col + j;
+      float v = 0.f;
+      for (int z = 0; z < splits; ++z) v += g.slab[z * total + i];
+      if (g.bias) v += g.bias[col + j];
+      float* pc = g.C + (long long)row * g.ldc + col + j;
+      if (accum) v += *pc;
+      if (relu) v = fmaxf(v, 0.f);
+      *pc = v;
+    }
+  }
+  return true;
+}
+
 // Philox4x32-10 (Salmon et al.), counter = (ctr_lo, ctr_hi, 0, 0), key = seed.
 __device__ __forceinline__ uint4 philox4x32_10(uint64_t ctr, uint64_t seed) {
   uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0u, c3 = 0u;

@@ -48,6 +48,7 @@ struct GemmArgs {
   int tiles_m, tiles_n;
   const float* rowscale;   // epilogue: C = rowscale[row / rps] * acc + bias (vqf_gemm_bf16_rowscale), or nullptr
   int rps;
+  int* cnt;                // split-K combined in the launch: arrival counters, one per tile (common.h), or nullptr
 };
 
 // thread -> (row, k) of its i-th 16-byte chunk
@@ -245,6 +246,10 @@ __global__ void __launch_bounds__(NTHREADS, 4) gemm_bf16_kernel(GemmArgs g) {
       }
     }
   }
+  if (to_slab && g.cnt) {      // split-K combined in this launch by the tile's last arriver (common.h)
+    const VqfSplitkTile st = {g.cnt, g.slab, g.C, g.bias, g.M, g.N, g.ldc, g.flags};
+    vqf_splitk_combine<BM, BN, NTHREADS>(st, bid, (int)gridDim.y, m0, n0, tid, reinterpret_cast<float*>(smem_bf));
+  }
 }
 
 template <bool TA, bool TB>
@@ -319,7 +324,7 @@ static int gemm_bf16_impl(int ta, int tb, int M, int N, int K, const void* A, in
   GemmArgs g;
   g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C; g.bias = bias; g.slab = nullptr;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.flags = flags;
-  g.rowscale = rowscale; g.rps = rps;
+  g.rowscale = rowscale; g.rps = rps; g.cnt = nullptr;
   g.tiles_m = (M + BM - 1) / BM;
   g.tiles_n = (N + BN - 1) / BN;
   const long long tiles = (long long)g.tiles_m * g.tiles_n;
@@ -340,7 +345,10 @@ static int gemm_bf16_impl(int ta, int tb, int M, int N, int K, const void* A, in
   const int kt_per = (ktiles + splits - 1) / splits;
   g.kchunk = kt_per * BK;
   splits = (K + g.kchunk - 1) / g.kchunk;
-  if (splits > 1) g.slab = (float*)ws;
+  if (splits > 1) {
+    g.slab = (float*)ws;
+    if (vqf_opt(VQF_OPT_GEMM_SPLITK_FUSED, 1) != 0) g.cnt = vqf_splitk_counters((int)tiles);
+  }
   if (g_vqf_prof_on) vqf_prof_dims(M, N, K);
   vqf_stat_bump(VQF_STAT_GEMM_BF16_TILE128);
   dim3 grid((unsigned)tiles, (unsigned)splits);
@@ -350,7 +358,7 @@ static int gemm_bf16_impl(int ta, int tb, int M, int N, int K, const void* A, in
   else if (ta && !tb) rc = launch<true, false>(g, grid, s);
   else rc = launch<true, true>(g, grid, s);
   if (rc != VQF_OK) return rc;
-  if (splits > 1) rc = vqf_splitk_reduce((const float*)ws, splits, M, N, C, ldc, bias, flags, s);
+  if (splits > 1 && !g.cnt) rc = vqf_splitk_reduce((const float*)ws, splits, M, N, C, ldc, bias, flags, s);
   return rc;
 }
 

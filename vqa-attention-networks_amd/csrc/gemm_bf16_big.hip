@@ -72,6 +72,11 @@ struct BigArgs {
   int M, N, K, lda, ldb, ldc, flags;
   int tiles_m, tiles_n, kchunk, splits;
   int group_m;           // row tiles per group of the tile order (pick_group_m)
+  // split-K combined in the launch (common.h vqf_splitk_combine): arrival counters (one per output tile) and the real
+  // destination -- C / ldc above then describe the slabs; cnt == nullptr: the caller runs vqf_splitk_reduce
+  int* cnt;
+  float* Cfinal;
+  int ldc_final;
 #ifdef VQF_PP_STAMPS
   unsigned long long* dbg;   // diagnostic build only (tools/pp_stamps.py): per workgroup and wave, 8 cycle sums
 #endif
@@ -278,6 +283,10 @@ __global__ void __launch_bounds__(NT, 2) gemm_bf16_big_kernel(const BigArgs g) {
     if (m0 + TM <= g.M) store_tile<false>(g, C, acc, bv, row_base, n0 + wc * 64 + r, relu);
     else                store_tile<true>(g, C, acc, bv, row_base, n0 + wc * 64 + r, relu);
   }
+  if (split && g.cnt) {      // the tile's K slices are combined in this launch by its last arriver (ring idle: see gemm_f32_big.hip)
+    const VqfSplitkTile st = {g.cnt, g.C, g.Cfinal, g.bias, g.M, g.N, g.ldc_final, g.flags};
+    vqf_splitk_combine<TM, TN, NT>(st, (m0 / TM) * g.tiles_n + n0 / TN, g.splits, m0, n0, threadIdx.x, reinterpret_cast<float*>(smem));
+  }
 }
 
 
@@ -447,6 +456,10 @@ __global__ void __launch_bounds__(NT, 2) gemm_bf16_pp_kernel(const BigArgs g) {
   } else {
     if (m0 + TM <= g.M) store_tile<false>(g, C, acc, bv, row_base, n0 + wc * 64 + r, relu);
     else                store_tile<true>(g, C, acc, bv, row_base, n0 + wc * 64 + r, relu);
+  }
+  if (split && g.cnt) {      // the tile's K slices are combined in this launch by its last arriver (ring idle: see gemm_f32_big.hip)
+    const VqfSplitkTile st = {g.cnt, g.C, g.Cfinal, g.bias, g.M, g.N, g.ldc_final, g.flags};
+    vqf_splitk_combine<TM, TN, NT>(st, (m0 / TM) * g.tiles_n + n0 / TN, g.splits, m0, n0, threadIdx.x, reinterpret_cast<float*>(smem));
   }
   w += gridDim.x;
   if (w >= total) break;
@@ -649,6 +662,10 @@ __global__ void __launch_bounds__(NT, 2) gemm_bf16_pp16_kernel(const BigArgs g) 
                else      store_tile16<true, true>(g, C, acc, row0, col0, lane, relu, use_bias); }
     else     { store_tile16<true, false>(g, C, acc, row0, col0, lane, relu, use_bias); }
   }
+  if (split && g.cnt) {      // the tile's K slices are combined in this launch by its last arriver (ring idle: see gemm_f32_big.hip)
+    const VqfSplitkTile st = {g.cnt, g.C, g.Cfinal, g.bias, g.M, g.N, g.ldc_final, g.flags};
+    vqf_splitk_combine<TM, TN, NT>(st, (m0 / TM) * g.tiles_n + n0 / TN, g.splits, m0, n0, threadIdx.x, reinterpret_cast<float*>(smem));
+  }
   w += gridDim.x;
   if (w >= total) break;
   begin_tile();
@@ -762,7 +779,11 @@ int vqf_gemm_bf16_big_try(int ta, int tb, int M, int N, int K, const void* A, in
   g.kchunk = per * TK;
   splits = (K + g.kchunk - 1) / g.kchunk;
   g.splits = splits;
-  if (splits > 1) { g.C = (float*)ws; g.ldc = N; }
+  g.cnt = nullptr; g.Cfinal = C; g.ldc_final = ldc;
+  if (splits > 1) {
+    g.C = (float*)ws; g.ldc = N;
+    if (tiles >= 64 && vqf_opt(VQF_OPT_GEMM_SPLITK_FUSED, 1) != 0) g.cnt = vqf_splitk_counters(tiles);   // (as gemm_f32_big.hip)
+  }
   g.group_m = pick_group_m(g.tiles_m, g.tiles_n, splits);
 #ifdef VQF_PP_STAMPS
   g.dbg = (splits == 1 && ws && ws_bytes >= (size_t)tiles * 8 * 8 * 8) ? (unsigned long long*)ws : nullptr;
@@ -771,6 +792,6 @@ int vqf_gemm_bf16_big_try(int ta, int tb, int M, int N, int K, const void* A, in
   vqf_stat_bump(VQF_STAT_GEMM_BF16_BIG);
   if (ta) *rc = tb ? launch<true, true>(g, s) : launch<true, false>(g, s);
   else    *rc = tb ? launch<false, true>(g, s) : launch<false, false>(g, s);
-  if (*rc == VQF_OK && splits > 1) *rc = vqf_splitk_reduce((const float*)ws, splits, M, N, C, ldc, bias, flags, s);
+  if (*rc == VQF_OK && splits > 1 && !g.cnt) *rc = vqf_splitk_reduce((const float*)ws, splits, M, N, C, ldc, bias, flags, s);
   return 1;
 }

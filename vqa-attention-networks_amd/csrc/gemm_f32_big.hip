@@ -75,6 +75,11 @@ struct BigArgs {
   const float* rowscale;   // epilogue: C = rowscale[row / rps] * acc + bias (vqf_gemm_f32_rowscale), or nullptr
   int rps;
   const float* zeros;      // 16 bytes of zeros in device memory: source of the copies past K in the last slab when K % 16 != 0
+  // split-K combined in the launch (common.h vqf_splitk_combine): arrival counters (one per output tile) and the real
+  // destination -- C / ldc above then describe the slabs; cnt == nullptr: the caller runs vqf_splitk_reduce
+  int* cnt;
+  float* Cfinal;
+  int ldc_final;
 #ifdef VQF_F32BIG_CLOCK
   unsigned long long* dbg;   // diagnostic build only (tools/f32_clock.py): per workgroup and wave half, s_memtime / s_memrealtime stamps
 #endif
@@ -563,6 +568,13 @@ __global__ void __launch_bounds__(NT, 2) gemm_f32_big_kernel(const BigArgs g) {
   } else if (nj > 0) {
     store_tile_blocked<TA>(g, C, acc, row0, col0, lane, relu, use_bias, nj);
   }
+  if (split && g.cnt) {
+    // The K slices of a tile are combined in this launch by the tile's last arriver.  Every wave has left the K loop when the
+    // combine's first barrier releases (each wave runs the same number of barriers per item in every loop form), the ring is
+    // idle until next_item() below issues the next item's slabs: its first bytes serve as the ticket's broadcast word.
+    const VqfSplitkTile st = {g.cnt, g.C, g.Cfinal, g.bias, g.M, g.N, g.ldc_final, g.flags};
+    vqf_splitk_combine<TM, TN, NT>(st, (m0 / TM) * g.tiles_n + n0 / TN, g.splits, m0, n0, tid, reinterpret_cast<float*>(smem));
+  }
 #ifdef VQF_F32BIG_CLOCK
   if (g.dbg && lane == 0 && (wave & 3) == 0) {         // one record per wave half: [entry, loop start, loop end, stores issued] cycles,
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // [entry, loop end] 100 MHz ticks, slabs; stores landed at the last stamp
@@ -772,7 +784,13 @@ int vqf_gemm_f32_big_try(int ta, int tb, int M, int N, int K, const float* A, in
   g.kchunk = per * TK;
   splits = (K + g.kchunk - 1) / g.kchunk;
   g.splits = splits;
-  if (splits > 1) { g.C = (float*)ws; g.ldc = N; }
+  g.cnt = nullptr; g.Cfinal = C; g.ldc_final = ldc;
+  if (splits > 1) {
+    g.C = (float*)ws; g.ldc = N;
+    // combined in the launch when there are enough tiles for the last arrivers to read their slabs side by side (each reads
+    // splits x 256 KB at one CU's rate: 16 tiles x 16 splits would take longer than the chip-wide reduce launch it replaces)
+    if (tiles >= 64 && vqf_opt(VQF_OPT_GEMM_SPLITK_FUSED, 1) != 0) g.cnt = vqf_splitk_counters(tiles);
+  }
   // a SHORT last column tile of a K-contiguous B (N = 5000: 136 of 256 columns) is split off into phase 2 of the work order:
   // its waves multiply only the column tiles that hold live columns (kernel header)
   const int rem = N % TN;
@@ -787,7 +805,7 @@ int vqf_gemm_f32_big_try(int ta, int tb, int M, int N, int K, const float* A, in
   vqf_stat_bump(VQF_STAT_GEMM_F32_BIG);
   if (ta) *rc = tb ? launch<true, true>(g, s) : launch<true, false>(g, s);
   else    *rc = tb ? launch<false, true>(g, s) : launch<false, false>(g, s);
-  if (*rc == VQF_OK && splits > 1) *rc = vqf_splitk_reduce((const float*)ws, splits, Mb, N, C, ldc, bias, flags, s);
+  if (*rc == VQF_OK && splits > 1 && !g.cnt) *rc = vqf_splitk_reduce((const float*)ws, splits, Mb, N, C, ldc, bias, flags, s);
   *rows_done = Mb;
   return 1;
 }
