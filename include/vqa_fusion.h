@@ -341,6 +341,13 @@ int vqf_mfb_fuse_bwd_pbf16(const float* dY, const float* Y, const float* inv, co
  * Its own backward: call it with x = dy and the same keep/seed. */
 int vqf_dropout_f32(const float* x, const uint8_t* keep, uint64_t seed, float p_drop,
                     long long n, float* y, void* stream);
+/* The LSTM-output dropout (mfb.py:70, mhb_coAtt.py:75) over a (B, T, H) tensor whose first two axes carry free ELEMENT strides on
+ * the input and on the output side (last axis contiguous): y[b,t,:] = x[b,t,:] * keep / (1-p).  One pass also re-lays the
+ * recursion's time-major states (T, B, H) out as the sample-major rows (B, T, H) the attention head reads; its backward is the
+ * same call with the strides swapped.  Dropout index of (b, t, h): (b*T + t)*H + h (one Philox call per 4 elements as above;
+ * keep: (B*T, H) uint8).  H and every stride % 4 == 0. */
+int vqf_dropout_bt(const float* x, long long sb_in, long long st_in, const uint8_t* keep, uint64_t seed, float p_drop, int B,
+                   int T, int H, float* y, long long sb_out, long long st_out, void* stream);
 /* y = dropout(tanh(a + b))  (b may be NULL)   hieCoAtten.py:32-33,38-39,45-46 */
 int vqf_tanh_dropout_fwd(const float* a, const float* b, const uint8_t* keep, uint64_t seed,
                          float p_drop, long long n, float* y, void* stream);

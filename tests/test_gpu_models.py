@@ -128,11 +128,14 @@ def test_train_mode_with_explicit_dropout_masks(mhb):
     cfg, img, q, glove, hard, soft = mfb_inputs(case, "cuda")
     N, T, L = case["N"], case["T"], cfg.img_feature_dim
     model = _load((vqa.MHBCoAtt if mhb else vqa.MFB)(cfg), case["salt"]).train()
-    model.dropout_l.p = 0.0                      # LSTM-output dropout is torch's; tested separately
+    # the LSTM-output dropout (mfb.py:70 / mhb_coAtt.py:75, p = 0.3) runs on the HIP path too (vqf_dropout_bt): its mask 'l' is
+    # indexed (sample, token, unit) there; the oracle applies it where the reference does -- for MHBCoAtt on the (T, N, H) tensor
+    H = cfg.hidden_dim
+    ml = torch.from_numpy(recipe.keep_mask((N, T, H), 0.3, "l"))
     m1 = torch.from_numpy(recipe.keep_mask((N * L, 5000), 0.1, "m1"))
     m2 = torch.from_numpy(recipe.keep_mask((N, 5000), 0.1, "m2"))
     m3 = torch.from_numpy(recipe.keep_mask((N, 5000), 0.1, "m3"))
-    masks = dict(m1=m1.cuda(), m2=m2.cuda())
+    masks = dict(m1=m1.cuda(), m2=m2.cuda(), l=ml.view(N * T, H).cuda())
     if mhb:
         masks["m3"] = m3.cuda()
     model.set_keep_masks(**masks)
@@ -140,7 +143,7 @@ def test_train_mode_with_explicit_dropout_masks(mhb):
     loss = torch.nn.KLDivLoss()(out, soft) if mhb else torch.nn.CrossEntropyLoss()(out, hard)
     loss.backward()
 
-    drop = dict(m1=m1.view(N, L, 5000), m2=m2, m3=m3)
+    drop = dict(m1=m1.view(N, L, 5000), m2=m2, m3=m3, l=ml.permute(1, 0, 2) if mhb else ml)
     o_out, g32, g64 = _oracle_pair(case, mhb, img, q, glove, soft if mhb else hard, drop=drop)
     assert rel_err(out.detach().cpu().numpy(), o_out.numpy()) <= OUT_TOL
     grad_parity(_named_grads(model), g32, g64)
@@ -384,8 +387,7 @@ def test_pruned_mode_is_bit_identical_to_faithful(multilayer):
     model = vqa_amd.MFB(cfg)
     model.load_state_dict({k: torch.from_numpy(recipe.weight_for(k, tuple(v.shape), case["salt"]))
                            for k, v in model.state_dict().items()})
-    model = model.cuda().train()
-    model.dropout_l.p = 0.0                     # torch's own dropout would draw differently placed randoms
+    model = model.cuda().train()                # every dropout active, the LSTM-output one (HIP, seeded like the others) included
     res = {}
     for pruned in (False, True):
         model.pruned = pruned

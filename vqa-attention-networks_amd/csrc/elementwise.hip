@@ -91,6 +91,28 @@ __global__ void ew2d_kernel(const float* __restrict__ a, int lda, const float* _
   }
 }
 
+// y[b, t, :] = x[b, t, :] * keep / (1 - p) over a (B, T, H) tensor whose first two axes carry free element strides on either
+// side (sb_*, st_*; the last axis contiguous): the LSTM-output dropout (mfb.py:70, mhb_coAtt.py:75) together with the
+// (T, B, H) -> (B, T, H) re-layout between the recursion's time-major states and the attention head's sample-major rows, and
+// its backward (the same call with the strides swapped).  The dropout index of (b, t, h) is (b * T + t) * H + h.
+__global__ void dropout_bt_kernel(const float* __restrict__ x, long long sb_in, long long st_in, const uint8_t* __restrict__ keep,
+                                  uint64_t seed, uint32_t thr, float inv_keep, int B, int T, int H4, float* __restrict__ y,
+                                  long long sb_out, long long st_out) {
+  const unsigned rows = (unsigned)B * (unsigned)T, n4 = rows * (unsigned)H4;
+  const unsigned stride = gridDim.x * blockDim.x;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const unsigned r = i / (unsigned)H4, c4 = i - r * (unsigned)H4;
+    const unsigned b = r / (unsigned)T, t = r - b * (unsigned)T;
+    float sc[4];
+    keep4(keep, seed, thr, inv_keep, (long long)i, sc);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + b * sb_in + t * st_in + 4 * c4);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = v[j] * sc[j];
+    *reinterpret_cast<f32x4*>(y + b * sb_out + t * st_out + 4 * c4) = o;
+  }
+}
+
 // one wave per row
 __global__ void softmax_rows_fwd_kernel(const float* __restrict__ x, int R, int W, float* __restrict__ y) {
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -192,6 +214,21 @@ int ew2d_launch(int kid, const float* a, int lda, const float* b, int ldb, const
 }  // namespace
 
 extern "C" {
+
+int vqf_dropout_bt(const float* x, long long sb_in, long long st_in, const uint8_t* keep, uint64_t seed, float p_drop, int B,
+                   int T, int H, float* y, long long sb_out, long long st_out, void* stream) {
+  if (!x || !y || B <= 0 || T <= 0 || H <= 0 || p_drop < 0.f || p_drop >= 1.f) return VQF_E_BADARG;
+  if ((H % 4) || (sb_in % 4) || (st_in % 4) || (sb_out % 4) || (st_out % 4) || (long long)B * T * (H / 4) >= (1LL << 31))
+    return VQF_E_UNSUPPORTED;
+  if (!aligned16(x) || !aligned16(y) || (keep && (((uintptr_t)keep) & 3))) return VQF_E_ALIGN;
+  const uint32_t thr = (keep || p_drop == 0.f) ? 0u : drop_threshold_host(p_drop);
+  const float inv_keep = (keep || p_drop > 0.f) ? 1.0f / (1.0f - p_drop) : 1.0f;
+  long long blocks = ((long long)B * T * (H / 4) + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  VQF_LAUNCH(KID_DROPOUT, dropout_bt_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, sb_in, st_in, keep, seed,
+             thr, inv_keep, B, T, H / 4, y, sb_out, st_out);
+  return vqf_last_error();
+}
 
 int vqf_tanh_dropout_fwd2d(const float* a, int lda, const float* b, int ldb, const uint8_t* keep, uint64_t seed, float p_drop,
                            int R, int W, float* y, int ldy, void* stream) {

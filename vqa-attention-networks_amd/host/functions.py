@@ -492,6 +492,45 @@ class DropoutFn(torch.autograd.Function):
         return ops.dropout(_c(dy), keep=ctx.keep, seed=ctx.seed, p_drop=ctx.p), None, None, None
 
 
+class DropoutBTFn(torch.autograd.Function):
+    """The LSTM-output dropout (mfb.py:70, mhb_coAtt.py:75): x (B, T, H), any strides on the first two axes (MFB hands in the
+    transposed view of its time-major LSTM states) -> CONTIGUOUS dropout(x); the gradient goes back in x's own layout, so the
+    (T, B, H) <-> (B, T, H) re-layouts of both directions ride in the two dropout passes instead of torch copy kernels."""
+
+    @staticmethod
+    def forward(ctx, x, keep, seed, p_drop):
+        ctx.keep, ctx.seed, ctx.p = keep, seed, p_drop
+        ctx.in_strides = (x.stride(0), x.stride(1))
+        return ops.dropout_bt(x, torch.empty(x.shape, dtype=torch.float32, device=x.device), keep, seed, p_drop)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, T, H = dy.shape
+        if dy.stride(2) != 1:
+            dy = dy.contiguous()
+        sb, st = ctx.in_strides
+        if st > sb and sb == H and st == B * H:                     # x was the transposed view of a contiguous (T, B, H) tensor
+            dx = torch.empty((T, B, H), dtype=torch.float32, device=dy.device).transpose(0, 1)
+        else:
+            dx = torch.empty((B, T, H), dtype=torch.float32, device=dy.device)
+        ops.dropout_bt(dy, dx, ctx.keep, ctx.seed, ctx.p)
+        return dx, None, None, None
+
+
+def lstm_out_dropout(module, x, seeds, tag="l"):
+    """dropout_l / lstm_dropout of the reference modules on the HIP path: rate = the nn.Dropout's p in train mode, 0 in eval
+    (then the pass only makes x contiguous); an explicit (B*T, H) keep-mask under `tag` replaces the in-kernel Philox draw."""
+    p = float(module.p) if module.training else 0.0
+    keep = seeds.keep.get(tag)
+    if x.dim() == 3 and x.is_cuda and x.dtype == torch.float32 and x.stride(2) == 1 and x.shape[2] % 4 == 0 \
+            and all(s % 4 == 0 for s in x.stride()[:2]):
+        if p <= 0.0 and keep is None and x.is_contiguous():
+            return x
+        seed, pp = seeds.next(module.training, p)
+        return DropoutBTFn.apply(x, keep, seed, p if keep is not None else pp)
+    return module(x).contiguous()
+
+
 class TanhDropFn(torch.autograd.Function):
     """y = dropout(tanh(a [+ b]))   (hieCoAtten.py:32-33,38-39,45-46)."""
 

@@ -61,6 +61,8 @@ SIGNATURES = {
     "vqf_glimpse_pool_fwd_bf16": (c_i, [c_p, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_p]),
     "vqf_glimpse_pool_bwd_bf16": (c_i, [c_f, c_f, c_p, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_p]),
     "vqf_dropout_f32": (c_i, [c_f, c_p, c_u64, ctypes.c_float, ctypes.c_longlong, c_f, c_p]),
+    "vqf_dropout_bt": (c_i, [c_f, ctypes.c_longlong, ctypes.c_longlong, c_p, c_u64, ctypes.c_float, c_i, c_i, c_i, c_f,
+                             ctypes.c_longlong, ctypes.c_longlong, c_p]),
     "vqf_tanh_dropout_fwd": (c_i, [c_f, c_f, c_p, c_u64, ctypes.c_float, ctypes.c_longlong, c_f, c_p]),
     "vqf_tanh_dropout_bwd": (c_i, [c_f, c_f, c_p, c_u64, ctypes.c_float, ctypes.c_longlong, c_f, c_p]),
     "vqf_tanh_dropout_fwd2d": (c_i, [c_f, c_i, c_f, c_i, c_p, c_u64, ctypes.c_float, c_i, c_i, c_f, c_i, c_p]),

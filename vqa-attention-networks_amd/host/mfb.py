@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from .functions import (LinearFn, AttHeadFn, ImgFuseFn, ImgProjFn, ImgProjLateFn, ImgProjDeferFn, MfbFuseFn, FinalMfbFn,
-                        LstmBatchFn, UnitPoolFn, DeadParamsFn, NormLink, img_project, embed_tanh)
+                        LstmBatchFn, UnitPoolFn, DeadParamsFn, NormLink, img_project, embed_tanh, lstm_out_dropout)
 
 
 def _image_is_data(img, gemm_dtype="fp32"):
@@ -243,7 +243,7 @@ class MFB(nn.Module):
         # a2: question encoder                                               mfb.py:68-70
         que_embedded = embed_tanh(self.word_embedding, questions)
         lstm_o = batch_first_lstm(self.lstm, que_embedded, self.use_hip_lstm, _lstm_bf16(self.gemm_dtype))
-        ques_feature = self.dropout_l(lstm_o).contiguous()                 # (N,T,H)
+        ques_feature = lstm_out_dropout(self.dropout_l, lstm_o, self._seeds)   # (N,T,H) contiguous; mfb.py:70
         N, T, H = ques_feature.shape
         L = img_features.shape[1]
         keep = self._seeds.keep

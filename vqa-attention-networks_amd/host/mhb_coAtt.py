@@ -9,7 +9,7 @@ import torch.nn as nn
 
 from . import ops
 from .functions import (LinearFn, AttHeadFn, ImgFuseFn, MfbFuseFn, FinalMfbFn, LstmSeqFn, LstmBatchFn, LogSoftmaxRowsFn,
-                        NormLink, embed_tanh, embed)
+                        NormLink, embed_tanh, embed, lstm_out_dropout)
 from .mfb import _DropSeeds, _image_is_data, _SideStream, _lstm_bf16, batch_first_lstm, warn_once
 
 
@@ -68,7 +68,7 @@ class MHBCoAtt(nn.Module):
             que_embedded = torch.cat((que_embedded, glove_matrix), dim=2)
         if self.fix_lstm_orientation:
             lstm_o = batch_first_lstm(self.lstm, que_embedded, self.use_hip_lstm, _lstm_bf16(self.gemm_dtype))   # (N,T,H)
-            ques_feature = self.dropout_l(lstm_o).contiguous()
+            ques_feature = lstm_out_dropout(self.dropout_l, lstm_o, self._seeds)
         elif (self.use_hip_lstm and self.lstm.num_layers == 1 and que_embedded.is_cuda
               and ops.lstm_seq_supported(que_embedded.shape[1], self.cfg.hidden_dim)):
             # batch_first LSTM fed (T,N,.): sequence axis = N, per-step batch = T  (mhb_coAtt.py:72-74).
@@ -77,7 +77,7 @@ class MHBCoAtt(nn.Module):
             hs = LstmSeqFn.apply(que_embedded, self.lstm.weight_ih_l0, self.lstm.weight_hh_l0,
                                  self.lstm.bias_ih_l0, self.lstm.bias_hh_l0,
                                  _lstm_bf16(self.gemm_dtype))     # bf16 modes: bf16 operands in the recurrent product
-            ques_feature = self.dropout_l(hs).contiguous()
+            ques_feature = lstm_out_dropout(self.dropout_l, hs, self._seeds)        # mhb_coAtt.py:75
         else:
             if self.use_hip_lstm:
                 warn_once("lstm_seq", "MHBCoAtt's batch-axis LSTM recursion runs on nn.LSTM (MIOpen: one tiny step per "
@@ -168,7 +168,7 @@ class MHB(nn.Module):
             lstm_outs, _ = self.LSTM(q_embedded)                             # (T,N,H)
         idx = (q_length.to(torch.long) - 1).to(lstm_outs.device)
         lstm_out = lstm_outs[idx, torch.arange(batch_size, device=lstm_outs.device)]   # :185-186
-        lstm_out = self.lstm_dropout(lstm_out)
+        lstm_out = lstm_out_dropout(self.lstm_dropout, lstm_out.unsqueeze(1), self._seeds).squeeze(1)      # :188
         pm = self.mfb_dropout.p
         seed, p = self._seeds.next(self.training, pm)
         k1 = keep.get('m1')

@@ -375,6 +375,20 @@ def dropout(x, keep=None, seed=0, p_drop=0.5, out=None):
     return y
 
 
+def dropout_bt(x, out, keep=None, seed=0, p_drop=0.0):
+    """out[b,t,:] = x[b,t,:] * keep / (1 - p) for 3-D fp32 tensors of the same (B, T, H) shape with ANY strides on the first two
+    axes (a transposed view in, a contiguous tensor out, or the other way round); the mask is indexed by (b, t, h)."""
+    for t_ in (x, out):
+        if not t_.is_cuda or t_.dtype != torch.float32 or t_.dim() != 3 or t_.stride(2) != 1:
+            raise _l.VqfError("dropout_bt: 3-D fp32 GPU tensors with a contiguous last axis expected")
+    if x.shape != out.shape:
+        raise _l.VqfError("dropout_bt: shapes differ")
+    B, T, H = x.shape
+    _l.check(_lib().vqf_dropout_bt(_ptr(x), x.stride(0), x.stride(1), _keep_ptr(keep), int(seed), float(p_drop), B, T, H,
+                                   _ptr(out), out.stride(0), out.stride(1), _stream()), "vqf_dropout_bt")
+    return out
+
+
 def tanh_dropout_fwd(a, b=None, keep=None, seed=0, p_drop=0.5, out=None):
     _chk(a, b, out)
     y = torch.empty_like(a) if out is None else out           # in place (out is a) allowed
