@@ -85,7 +85,7 @@ class MHBCoAtt(nn.Module):
                           "tokens per question <= 32 and hidden_dim in {256, 512, 768, 1024} (got T=%d, H=%d, layers=%d)"
                           % (que_embedded.shape[1], self.cfg.hidden_dim, self.lstm.num_layers))
             lstm_o, _ = self.lstm(que_embedded.permute(1, 0, 2))             # (T,N,H), recurs over N
-            ques_feature = self.dropout_l(lstm_o).permute(1, 0, 2).contiguous()   # (N,T,H)
+            ques_feature = lstm_out_dropout(self.dropout_l, lstm_o.permute(1, 0, 2), self._seeds)   # (N,T,H) contiguous
         T, H = ques_feature.shape[1], ques_feature.shape[2]
 
         qa = AttHeadFn.apply(ques_feature.view(N * T, H), ques_feature,
