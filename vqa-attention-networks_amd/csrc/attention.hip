@@ -41,7 +41,7 @@ __global__ void att_logits_fwd_kernel(const float* __restrict__ hid, const float
   for (int g = 0; g < G; ++g) { a[g] = 0.f; al[g] = 0.f; }
   if ((Hh & 3) == 0 && aligned16_dev(h) && aligned16_dev(w2) && (!LIN || aligned16_dev(b1))) {
     for (int c = lane * 4; c < Hh; c += 256) {
-      const f32x4 x = *reinterpret_cast<const f32x4*>(h + c);
+      const f32x4 x = vqf_ld_stream(reinterpret_cast<const f32x4*>(h + c));
       f32x4 xl = x;
       if (LIN) {
         const f32x4 bb = *reinterpret_cast<const f32x4*>(b1 + c);
@@ -116,7 +116,7 @@ __global__ void att_logits_bwd_kernel(const float* __restrict__ dl, const float*
         rs[q] = rowscale ? rowscale[r / rps] : 1.0f;
         const float* hp = hid + (long long)r * Hh + c;
         if (vec) {
-          const f32x4 xv = *reinterpret_cast<const f32x4*>(hp);
+          const f32x4 xv = vqf_ld_stream(reinterpret_cast<const f32x4*>(hp));
           x[q][0] = xv[0]; x[q][1] = xv[1]; x[q][2] = xv[2]; x[q][3] = xv[3];
         } else {
 #pragma unroll
@@ -139,7 +139,7 @@ __global__ void att_logits_bwd_kernel(const float* __restrict__ dl, const float*
         float* o = dhid_pre + (long long)r * Hh + c;
         if (vec) {
           f32x4 gv = {gp[0] * rs[q], gp[1] * rs[q], gp[2] * rs[q], gp[3] * rs[q]};
-          *reinterpret_cast<f32x4*>(o) = gv;
+          vqf_st_stream(reinterpret_cast<f32x4*>(o), gv);
         } else {
 #pragma unroll
           for (int j = 0; j < 4; ++j) if (j < nc) o[j] = gp[j] * rs[q];
@@ -172,7 +172,7 @@ __global__ void split_reduced_row_kernel(const float* __restrict__ red, int n0, 
 // feature element loaders: the pooled tensor is fp32 or (bf16 feature storage) bf16
 template <typename FT> __device__ __forceinline__ f32x4 load4(const FT* p);
 template <> __device__ __forceinline__ f32x4 load4<float>(const float* p) {
-  return *reinterpret_cast<const f32x4*>(p);
+  return vqf_ld_stream(reinterpret_cast<const f32x4*>(p));
 }
 template <> __device__ __forceinline__ f32x4 load4<__bf16>(const __bf16* p) {
   const uint2 r = *reinterpret_cast<const uint2*>(p);        // 4 bf16 = 8 bytes

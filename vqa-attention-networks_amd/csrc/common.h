@@ -6,6 +6,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // kernel ids for the profiler (keep in sync with prof.hip names[])
 enum VqfKernelId {
@@ -136,6 +137,19 @@ static inline int vqf_cu_count() {
 }
 
 // ---- device helpers -------------------------------------------------------
+// Loads / stores of ONCE-touched streams (the projection P and its gradient in the fusion kernels, the image grid in the glimpse
+// pools, the hidden layer in the attention-logit kernels): VQF_STREAM_NT = 1 issues them non-temporal, so that the streamed
+// bytes do not displace what the caches hold (tools/hbm_probe.hip: a 2 GB read sweep 6.8 TB/s nt vs 6.1 default policy).
+#ifndef VQF_STREAM_NT
+#define VQF_STREAM_NT 1
+#endif
+template <typename T> __device__ __forceinline__ T vqf_ld_stream(const T* p) {
+  return VQF_STREAM_NT ? __builtin_nontemporal_load(p) : *p;
+}
+template <typename T> __device__ __forceinline__ void vqf_st_stream(T* p, T v) {
+  if (VQF_STREAM_NT) __builtin_nontemporal_store(v, p); else *p = v;
+}
+
 __device__ __forceinline__ bool aligned16_dev(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

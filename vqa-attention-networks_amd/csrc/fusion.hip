@@ -78,14 +78,19 @@ __device__ __forceinline__ void raw_load(const float* __restrict__ rowp, int W5,
 #pragma unroll
   for (int k = 0; k < 5; ++k) {
     const int el = wave * WSPAN + (64 * k + lane) * 4;
-    r.v[k] = el < W5 ? *reinterpret_cast<const f32x4*>(rowp + el) : f32x4{0.f, 0.f, 0.f, 0.f};
+    r.v[k] = el < W5 ? vqf_ld_stream(reinterpret_cast<const f32x4*>(rowp + el)) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
 }
 __device__ __forceinline__ void raw_load(const __bf16* __restrict__ rowp, int W5, int wave, int lane, Raw<__bf16>& r) {
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const int pc = 64 * k + lane, el = wave * WSPAN + pc * 8;
-    r.v[k] = (pc < 160 && el < W5) ? *reinterpret_cast<const uint4*>(rowp + el) : make_uint4(0u, 0u, 0u, 0u);
+    if (pc < 160 && el < W5) {
+      const u32x4 t = vqf_ld_stream(reinterpret_cast<const u32x4*>(rowp + el));
+      r.v[k] = make_uint4(t[0], t[1], t[2], t[3]);
+    } else {
+      r.v[k] = make_uint4(0u, 0u, 0u, 0u);
+    }
   }
 }
 __device__ __forceinline__ void raw_to_own(const Raw<float>& r, char* wl, int lane, float (&p)[CPT]) {
@@ -123,7 +128,7 @@ __device__ __forceinline__ void own_store(float* __restrict__ rowp, int W5, int 
 #pragma unroll
   for (int k = 0; k < 5; ++k) {
     const int pc = 64 * k + lane, el = wave * WSPAN + pc * 4;
-    if (el < W5) *reinterpret_cast<f32x4*>(rowp + el) = *reinterpret_cast<const f32x4*>(wl + pc * 16);
+    if (el < W5) vqf_st_stream(reinterpret_cast<f32x4*>(rowp + el), *reinterpret_cast<const f32x4*>(wl + pc * 16));
   }
 }
 __device__ __forceinline__ void own_store(__bf16* __restrict__ rowp, int W5, int wave, int lane, char* wl,
