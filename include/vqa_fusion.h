@@ -268,7 +268,8 @@ int vqf_glimpse_pool_bwd_bf16(const float* dpooled, const float* dwts_extra, con
  *                   generated in-kernel from Philox4x32-10(seed, element index / 8), one 16-bit draw
  *                   per element (keep iff draw >= p * 65536), identically in forward and backward.
  *  R    (N*L, O)    signed sqrt of the pooled sums (un-normalised)
- *  rowssq (N*L)     per-row sum of R^2 (= sum |pooled|)
+ *  rowssq (N*L*4)   per-row sum of R^2 (= sum |pooled|) as FOUR partial sums per row (one per wave of the workgroup: no barrier
+ *                   in the row loop); vqf_l2_group_norm(rowssq, N, 4 * L, ...) adds them up
  *  zdrop (N*L,5*O) or NULL: the dropped-out product itself (only MHB needs it)
  *  O % 4 == 0 and O <= 1024 (mfb.py:42-43 hard-codes O = 1000); else VQF_E_UNSUPPORTED.
  */
@@ -487,8 +488,9 @@ int vqf_adam_step(const VqfAdamTensor* tensors, int count, double lr, double bet
 
 /* --------------------------------------------------------------------------
  * HBM yardsticks (measurement only; bench.py's `hbm_yardsticks`): what a plain streaming kernel of this library reaches,
- * in the units the HBM-bound stages above are priced in.  16 bytes per lane, grid-stride, 8 workgroups of 256 threads
- * per CU, four loads in flight per lane; nt != 0: non-temporal loads / stores.  nbytes % 16 == 0, 16-byte aligned.
+ * in the units the HBM-bound stages above are priced in.  16 bytes per lane, grid-stride, the launch shape that streams 2 GB
+ * buffers fastest (tools/hbm_probe.hip: 2 - 4 workgroups of 256 threads per CU; csrc/yardstick.hip); nt != 0: non-temporal
+ * loads / stores.  nbytes % 16 == 0, 16-byte aligned.
  *   vqf_hbm_copy        dst[0..nbytes) = src[0..nbytes)            (read : write = 1 : 1)
  *   vqf_hbm_read_sweep  block_sums[b] = sum of the fp32 values workgroup b read (b < vqf_hbm_read_sweep_blocks(nbytes)):
  *                       a pure read stream whose loads cannot be dropped. */

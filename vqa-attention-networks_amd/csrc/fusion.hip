@@ -67,6 +67,9 @@ __device__ __forceinline__ void store20(__bf16* __restrict__ p, const float (&v)
 // The exchange is between LANES of one wave, which the compiler's per-thread view does not see: without a fence hipcc
 // proves that a thread's own stores cannot alias its reads of other lanes' slots and hoists those reads out of the row
 // loop.  A wavefront-scope fence emits no instruction and pins the order.
+#ifndef VQF_FUSE_ROWBAR
+#define VQF_FUSE_ROWBAR 0      // 1: round 3's forward (the row's sum of squares folded over the four waves behind a barrier per row; A/B)
+#endif
 #define VQF_WAVE_FENCE() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
 constexpr int WSPAN = 64 * CPT;                        // elements of a row owned by one wave
 constexpr int WLDS = WSPAN * 4;                        // bytes of a wave's transpose buffer
@@ -203,7 +206,9 @@ mfb_fuse_fwd_kernel(const PT* __restrict__ P, const float* __restrict__ pbias,
                     const float* __restrict__ cascade, const uint8_t* __restrict__ keep,
                     uint64_t seed, uint32_t thr, float inv_keep, int L, int O, int LS,
                     float* __restrict__ R, float* __restrict__ rowssq, float* __restrict__ zdrop) {
+#if VQF_FUSE_ROWBAR
   __shared__ float red[2][4];
+#endif
   __shared__ __attribute__((aligned(16))) char tl[COAL ? 4 * WLDS : 16];
   const int n = blockIdx.x, ls = blockIdx.y;
   const int W5 = KP * O;
@@ -262,9 +267,18 @@ mfb_fuse_fwd_kernel(const PT* __restrict__ P, const float* __restrict__ pbias,
       *reinterpret_cast<f32x4*>(R + row * O + TPT * tid) = r;
     }
     ssq = wave_sum(ssq);
+#if VQF_FUSE_ROWBAR
     if ((tid & 63) == 0) red[it & 1][tid >> 6] = ssq;
     __syncthreads();                               // red[] is double-buffered: one barrier per row
-    if (tid == 0) rowssq[row] = (red[it & 1][0] + red[it & 1][1]) + (red[it & 1][2] + red[it & 1][3]);
+    if (tid == 0) {
+      rowssq[4 * row] = (red[it & 1][0] + red[it & 1][1]) + (red[it & 1][2] + red[it & 1][3]);
+      rowssq[4 * row + 1] = 0.f; rowssq[4 * row + 2] = 0.f; rowssq[4 * row + 3] = 0.f;
+    }
+#else
+    // every wave leaves the sum of ITS quarter of the row: no workgroup barrier in the row loop, the four waves of a block drift
+    // apart and cover each other's load latency; vqf_l2_group_norm adds the 4 L partials of a sample in a fixed order
+    if ((tid & 63) == 0) rowssq[4 * row + (tid >> 6)] = ssq;
+#endif
   }
 }
 

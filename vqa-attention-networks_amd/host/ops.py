@@ -590,7 +590,7 @@ def mfb_fuse_fwd(P, q, N, L, O, keep=None, seed=0, p_drop=0.0, cascade=None, wan
     _chk(q, cascade, pbias)
     dev = P.device
     R = torch.empty((N * L, O), dtype=torch.float32, device=dev)
-    rowssq = torch.empty(N * L, dtype=torch.float32, device=dev)
+    rowssq = torch.empty(N * L * 4, dtype=torch.float32, device=dev)       # four partial sums per row (one per wave)
     zdrop = torch.empty_like(P) if want_zdrop else None
     if P.dtype == torch.bfloat16:      # the projection itself stored in bf16 (bf16 mode of the image fusion)
         if cascade is not None or want_zdrop:
@@ -603,7 +603,7 @@ def mfb_fuse_fwd(P, q, N, L, O, keep=None, seed=0, p_drop=0.0, cascade=None, wan
                  "vqf_mfb_fuse_fwd")
     norm = torch.empty(N, dtype=torch.float32, device=dev)
     inv = torch.empty(N, dtype=torch.float32, device=dev)
-    _l.check(_lib().vqf_l2_group_norm(_ptr(rowssq), N, L, _ptr(norm), _ptr(inv), _stream()),
+    _l.check(_lib().vqf_l2_group_norm(_ptr(rowssq), N, 4 * L, _ptr(norm), _ptr(inv), _stream()),
              "vqf_l2_group_norm")
     if normalise:
         _l.check(_lib().vqf_scale_rows(_ptr(R), _ptr(inv), N * L, L, O, _ptr(R), _stream()), "vqf_scale_rows")
