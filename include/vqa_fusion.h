@@ -79,8 +79,9 @@ const char* vqf_build_info(void);
                                         of the chip to kernels of other streams); <= 0 or -1 = all */
 #define VQF_OPT_GEMM_F32_EDGE 11      /* 0 = the large-tile fp32 GEMM treats a short last column tile like a full one (A/B) */
 #define VQF_OPT_GEMM_F32_ROUNDS 12    /* 0 = mid-size fp32 GEMMs are NOT split at a whole number of rounds of the large-tile kernel (A/B; see vqf_gemm_f32_big_rows) */
-#define VQF_OPT_GEMM_SPLITK_FUSED 13  /* 0 = split-K products write slabs and run a separate vqf_splitk_reduce launch (r01-r03); default: the
-                                        last-arriving workgroup of an output tile sums the slabs in split order inside the GEMM launch */
+#define VQF_OPT_GEMM_SPLITK_FUSED 13  /* split-K combined INSIDE the GEMM launch (the last-arriving workgroup of an output tile sums the slabs in
+                                        split order; same bits as the slabs + vqf_splitk_reduce form): default = in the 256x256-tile kernels
+                                        with >= 64 output tiles only; 1 = in the 128x128-tile kernels too (measured slower there); 0 = never */
 #define VQF_OPT_COUNT 14
 int vqf_set_option(int option, int value, int* previous);
 int vqf_get_option(int option, int* value);

@@ -367,3 +367,49 @@ def test_persistent_gemms_confined_to_a_cu_subset_give_the_same_bits(ops, dtype)
         assert torch.equal(o, full)
     ref = _ref64(A, B, 0, 0, bias)
     assert _rel(full, ref) <= (2e-5 if dtype == "bf16" else 2e-6) * max(1.0, np.sqrt(K) / 8)
+
+
+@pytest.mark.parametrize("dtype,ta,tb,M,N,K,extras", [
+    ("f32", 1, 1, 5000, 2048, 25088, ""),            # the image projection's weight-gradient layout: 160 tiles x splits
+    ("f32", 1, 1, 2100, 2300, 16384, "bias+relu"),   # ragged tiles, bias and ReLU in the combine
+    ("bf16", 1, 1, 5000, 2048, 25088, ""),           # the same launch of the bf16 mode (gemm_bf16_pp_kernel)
+    ("bf16", 0, 0, 2104, 2200, 2048, "bias"),        # 81 tiles, split-K on the 16x16x32 kernel
+])
+@pytest.mark.parametrize("persist", [1, 0])
+def test_large_tile_splitk_combined_in_the_launch_bitwise(ops, dtype, ta, tb, M, N, K, extras, persist):
+    """The 256x256-tile kernels combine their split-K slices inside the launch when the product has >= 64 output tiles (each
+    tile's last-arriving workgroup sums the slabs in split order, csrc/common.h vqf_splitk_combine): the same bits as the
+    slabs + vqf_splitk_reduce form (option gemm_splitk_fused = 0), in both launch forms, run after run, no reduce launch."""
+    A = _u((K, M) if ta else (M, K), 71)
+    B = _u((K, N) if tb else (N, K), 72, 0.05)
+    bias = _u((N,), 73) if "bias" in extras else None
+    kw = dict(ta=bool(ta), tb=bool(tb), bias=bias, relu="relu" in extras)
+    if dtype == "bf16":
+        A, B = A.to(torch.bfloat16), B.to(torch.bfloat16)
+        run = lambda: ops.gemm_bf16(A, B, **kw)
+        fam, opt = "gemm_bf16_big", "gemm_bf16_persist"
+    else:
+        run = lambda: ops.gemm(A, B, **kw)
+        fam, opt = "gemm_f32_big", "gemm_f32_persist"
+    with ops.options(**{opt: persist}):
+        n0 = ops.stat(fam)
+        with ops.options(gemm_splitk_fused=0):
+            ops.prof_reset(); ops.prof_enable(True)
+            two = run()
+            torch.cuda.synchronize()
+            ops.prof_enable(False)
+            assert ops.prof_report().get("splitk_reduce", (0, 0))[0] == 1, "this shape does not split K"
+        assert ops.stat(fam) == n0 + 1, "not routed to the large-tile kernel"
+        ops.prof_reset(); ops.prof_enable(True)
+        one = run()
+        torch.cuda.synchronize()
+        ops.prof_enable(False)
+        assert "splitk_reduce" not in ops.prof_report()
+        ops.prof_reset()
+        assert torch.equal(one, two)
+        for _ in range(2):
+            assert torch.equal(run(), two)
+    ref = _ref64(A, B, ta, tb, bias)
+    if "relu" in extras:
+        ref = torch.relu(ref)
+    assert _rel(one, ref) <= (2e-5 * max(1.0, np.sqrt(K) / 16) if dtype == "bf16" else 2e-6 * max(1.0, np.sqrt(K) / 8))

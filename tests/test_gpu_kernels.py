@@ -77,9 +77,11 @@ def test_gemm_relu_accumulate_and_splitk(ops):
     (1, 1, 1000, 1024, 3584, ""),
 ])
 def test_splitk_combined_in_the_launch_has_the_bits_of_the_two_launch_form(ops, ta, tb, M, N, K, extras):
-    """Split-K products combine their K slices INSIDE the GEMM launch (each tile's last-arriving workgroup sums the slabs in
-    split order): bit-identical to the slabs + vqf_splitk_reduce form of rounds 1-3 (option gemm_splitk_fused = 0), run to run
-    (the arrival counters are left at zero), on two streams at once, and no reduce launch is left."""
+    """Option gemm_splitk_fused = 1: split-K products of the 128x128-tile kernel combine their K slices INSIDE the GEMM launch
+    (each tile's last-arriving workgroup sums the slabs in split order): bit-identical to the slabs + vqf_splitk_reduce form
+    (option 0, and this kernel's default: the in-launch combine measured 3-20 us slower per product), run to run (the arrival
+    counters are left at zero), on two streams at once, and no reduce launch is left.  The large-tile kernels use the same
+    combine by default (tests/test_gpu_gemm_big.py)."""
     A = _rand((K, M) if ta else (M, K), 51).float().cuda()
     B = _rand((K, N) if tb else (N, K), 52).float().cuda()
     bias = _rand((N,), 53).float().cuda() if "bias" in extras else None
@@ -97,26 +99,28 @@ def test_splitk_combined_in_the_launch_has_the_bits_of_the_two_launch_form(ops, 
         torch.cuda.synchronize()
         ops.prof_enable(False)
         assert ops.prof_report().get("splitk_reduce", (0, 0))[0] == 1, "this shape does not split K: pick another one"
-    ops.prof_reset(); ops.prof_enable(True)
-    one = run()
-    torch.cuda.synchronize()
-    ops.prof_enable(False)
-    rep = ops.prof_report()
-    ops.prof_reset()
-    assert "splitk_reduce" not in rep and sum(n for n, _ in rep.values()) == 1
-    assert torch.equal(one, two)
-    for _ in range(3):                                  # counters back at zero: the same bits again and again
-        assert torch.equal(run(), two)
-    side = torch.cuda.Stream()                          # two launches in flight: disjoint counter words of the ring
-    side.wait_stream(torch.cuda.current_stream())
-    outs = []
-    for _ in range(4):
-        with torch.cuda.stream(side):
+    assert torch.equal(run(), two)                      # the default of this kernel family is the two-launch form
+    with ops.options(gemm_splitk_fused=1):
+        ops.prof_reset(); ops.prof_enable(True)
+        one = run()
+        torch.cuda.synchronize()
+        ops.prof_enable(False)
+        rep = ops.prof_report()
+        ops.prof_reset()
+        assert "splitk_reduce" not in rep and sum(n for n, _ in rep.values()) == 1
+        assert torch.equal(one, two)
+        for _ in range(3):                                  # counters back at zero: the same bits again and again
+            assert torch.equal(run(), two)
+        side = torch.cuda.Stream()                          # two launches in flight: disjoint counter words of the ring
+        side.wait_stream(torch.cuda.current_stream())
+        outs = []
+        for _ in range(4):
+            with torch.cuda.stream(side):
+                outs.append(run())
             outs.append(run())
-        outs.append(run())
-    torch.cuda.current_stream().wait_stream(side)
-    torch.cuda.synchronize()
-    assert all(torch.equal(o, two) for o in outs)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        assert all(torch.equal(o, two) for o in outs)
     Ad, Bd = A.double().cpu(), B.double().cpu()
     ref = (Ad.t() if ta else Ad) @ (Bd if tb else Bd.t())
     if bias is not None:

@@ -171,14 +171,16 @@ __device__ __forceinline__ float wave_max(float v) {
 // zero.  slab: [splits][M][N] fp32.  Returns true in the workgroup that wrote the tile.  `scratch`: 4 bytes of the kernel's ONE
 // LDS array (free at this point).  TILE_N / 4 must divide NT.
 struct VqfSplitkTile { int* cnt; const float* slab; float* C; const float* bias; int M, N, ldc, flags; };
-template <int TILE_M, int TILE_N, int NT>
+template <int TILE_M, int TILE_N, int NT, bool WT = false>      // WT: the slabs were stored write-through (sc1): no release fence
 __device__ __forceinline__ bool vqf_splitk_combine(const VqfSplitkTile& g, int tile, int splits, int m0, int n0, int tid,
                                                    float* scratch) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!WT) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     const int ticket = __hip_atomic_fetch_add(g.cnt + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     *reinterpret_cast<volatile int*>(scratch) = ticket;
   }

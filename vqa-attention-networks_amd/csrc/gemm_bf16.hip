@@ -347,7 +347,7 @@ static int gemm_bf16_impl(int ta, int tb, int M, int N, int K, const void* A, in
   splits = (K + g.kchunk - 1) / g.kchunk;
   if (splits > 1) {
     g.slab = (float*)ws;
-    if (vqf_opt(VQF_OPT_GEMM_SPLITK_FUSED, 1) != 0) g.cnt = vqf_splitk_counters((int)tiles);
+    if (vqf_opt(VQF_OPT_GEMM_SPLITK_FUSED, 0) == 1) g.cnt = vqf_splitk_counters((int)tiles);
   }
   if (g_vqf_prof_on) vqf_prof_dims(M, N, K);
   vqf_stat_bump(VQF_STAT_GEMM_BF16_TILE128);

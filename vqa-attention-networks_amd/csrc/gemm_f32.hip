@@ -35,6 +35,9 @@ namespace {
 // 128.9 TF; BK=16 / 3 per CU 132.3 TF; BK=16 / 4 per CU 133.7 TF.  The shallower K-tile halves the
 // LDS footprint (40,960 B) so that four workgroups (4 waves per SIMD) share a CU and cover each
 // other's barrier / LDS-refill bubbles.
+#ifndef VQF_SPLITK_WT
+#define VQF_SPLITK_WT 0        // 1: write-through slab stores instead of a release fence in the in-launch split-K combine (A/B)
+#endif
 #ifndef VQF_GEMM_BK
 #define VQF_GEMM_BK 16
 #endif
@@ -445,6 +448,10 @@ __global__ void __launch_bounds__(NTHREADS, VQF_GEMM_WAVES_PER_SIMD) gemm_f32_ke
             if (g.flags & VQF_GEMM_ACCUM) v += *pc;
             if (g.flags & VQF_GEMM_RELU) v = fmaxf(v, 0.f);
           }
+#if VQF_SPLITK_WT
+          // slabs of an in-launch combine are stored WRITE-THROUGH (an agent-scope relaxed atomic store = sc1): no release fence
+          if (to_slab && g.cnt) __hip_atomic_store(pc, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else
+#endif
           *pc = v;
         }
       }
@@ -452,7 +459,7 @@ __global__ void __launch_bounds__(NTHREADS, VQF_GEMM_WAVES_PER_SIMD) gemm_f32_ke
   }
   if (to_slab && g.cnt) {      // split-K combined in this launch by the tile's last arriver (common.h)
     const VqfSplitkTile st = {g.cnt, g.slab, g.C, g.bias, g.M, g.N, g.ldc, g.flags};
-    vqf_splitk_combine<BM, BN, NTHREADS>(st, bid, (int)gridDim.y, m0, n0, tid, smem);
+    vqf_splitk_combine<BM, BN, NTHREADS, VQF_SPLITK_WT != 0>(st, bid, (int)gridDim.y, m0, n0, tid, smem);
   }
 }
 
@@ -621,8 +628,12 @@ static int gemm_tile128(int ta, int tb, int M, int N, int K, const float* A, int
   splits = (K + g.kchunk - 1) / g.kchunk;
   if (splits > 1) {
     g.slab = (float*)ws;
-    // combined inside this launch by each tile's last-arriving workgroup (option gemm_splitk_fused = 0: a second launch)
-    if (vqf_opt(VQF_OPT_GEMM_SPLITK_FUSED, 1) != 0) g.cnt = vqf_splitk_counters((int)tiles);
+    // option gemm_splitk_fused = 1: combined inside this launch by each tile's last-arriving workgroup.  NOT the default for
+    // this kernel: measured (tools/gemm_m512_probe.py, gpurun_out/m512_probe.log) the in-launch combine costs 3-20 us MORE per
+    // product than the slab-reduce launch it replaces (512x5000x2048: 139 vs 116 us; write-through slab stores instead of the
+    // release fence: 136) -- every slice's release + ticket and the last arrivers' serial slab reads (splits x 64 KB each) sit on
+    // the tail of a 100-us launch, the chip-wide reduce kernel takes ~8 us.  The large-tile kernels keep it (a wash there).
+    if (vqf_opt(VQF_OPT_GEMM_SPLITK_FUSED, 0) == 1) g.cnt = vqf_splitk_counters((int)tiles);
   }
 
   dim3 grid((unsigned)tiles, (unsigned)splits);
