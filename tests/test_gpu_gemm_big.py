@@ -371,7 +371,7 @@ def test_persistent_gemms_confined_to_a_cu_subset_give_the_same_bits(ops, dtype)
 
 @pytest.mark.parametrize("dtype,ta,tb,M,N,K,extras", [
     ("f32", 1, 1, 5000, 2048, 25088, ""),            # the image projection's weight-gradient layout: 160 tiles x splits
-    ("f32", 1, 1, 2100, 2300, 16384, "bias+relu"),   # ragged tiles, bias and ReLU in the combine
+    ("f32", 1, 1, 5000, 2100, 25088, "bias+relu"),   # ragged tiles in both directions, bias and ReLU in the combine
     ("bf16", 1, 1, 5000, 2048, 25088, ""),           # the same launch of the bf16 mode (gemm_bf16_pp_kernel)
     ("bf16", 0, 0, 2104, 2200, 2048, "bias"),        # 81 tiles, split-K on the 16x16x32 kernel
 ])

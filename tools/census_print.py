@@ -1,7 +1,10 @@
 """Print the per-kernel census table of the last bench.py run (gpurun_out/bench_census.json)."""
 import json
 import os
+import signal
 import sys
+
+signal.signal(signal.SIGPIPE, signal.SIG_DFL)
 
 path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "bench_census.json")
 d = json.load(open(path))
