@@ -431,6 +431,13 @@ int vqf_lstm_seq_bwd(const float* dhs, const float* gates, const float* cs, cons
  *   bwd: dh = dhs_t (+ dh_carry);  dG (B,4H) = pre-activation gradients;  dc_carry updated in place
  *        (first != 0 at the last time step: the carry is not read).  c_prev = NULL at t = 0. */
 int vqf_lstm_cell_fwd(float* gates, const float* c_prev, int B, int H, float* c_out, float* h_out, void* stream);
+/* One whole forward step in ONE launch: gates (B,4H) += h_prev (B,H) W_hh^T, then the cell stage above in the product's epilogue
+ * (the wave tile of csrc/gemm_f32_wave.hip holds 16 hidden units x 4 gates: W_hh's rows are gathered gate-interleaved by the
+ * LDS-DMA source addresses).  Bit-identical to vqf_gemm_f32(VQF_GEMM_ACCUM) + vqf_lstm_cell_fwd.  Supported
+ * (vqf_lstm_step_supported): B % 128 == 0, H % 16 == 0, H >= 256; else VQF_E_UNSUPPORTED. */
+int vqf_lstm_step_supported(int B, int H);
+int vqf_lstm_step_fwd(const float* h_prev, const float* w_hh, float* gates, const float* c_prev, int B, int H,
+                      float* c_out, float* h_out, void* stream);
 int vqf_lstm_cell_bwd(const float* dhs_t, const float* dh_carry, const float* gates, const float* c_t,
                       const float* c_prev, int first, int B, int H, float* dc_carry, float* dG, void* stream);
 

@@ -161,3 +161,39 @@ def test_mfb_hip_lstm_equals_miopen_lstm():
         if float(g.norm()) > 1e-6 * gmax:            # skip the mathematically-zero ones (biases in front of a softmax)
             tol = 2e-2 if k.startswith(loose) else 5e-3
             assert float((res[True][1][k] - g).norm()) <= tol * float(g.norm()) + 1e-9, k
+
+
+@pytest.mark.parametrize("B,H", [(512, 1024), (128, 256), (256, 768)])
+def test_fused_lstm_step_is_bit_identical_to_product_plus_cell(B, H):
+    """vqf_lstm_step_fwd (recurrent product with the cell in its epilogue, gate-interleaved W_hh rows) against
+    vqf_gemm_f32(VQF_GEMM_ACCUM) + vqf_lstm_cell_fwd on the same operands: activated gates, c and h BIT-identical, with and
+    without a previous cell state; then the module-level sequence (LstmBatchFn, T = 5) both ways incl. gradients."""
+    import vqa_amd
+    ops = vqa_amd.ops
+    assert ops.lstm_step_supported(B, H) and not ops.lstm_step_supported(B + 32, H) and not ops.lstm_step_supported(B, 64)
+    g = torch.Generator().manual_seed(B + H)
+    r = lambda *s: ((torch.rand(s, generator=g) * 2 - 1)).cuda()
+    h_prev, w_hh, pre, c_prev = r(B, H), r(4 * H, H) * 0.05, r(B, 4 * H) * 1.5, r(B, H)
+    for cp in (c_prev, None):
+        g1, c1, h1 = pre.clone(), torch.empty(B, H, device="cuda"), torch.empty(B, H, device="cuda")
+        ops.lstm_step_fwd(h_prev, w_hh, g1, cp, c1, h1)
+        g2, c2, h2 = pre.clone(), torch.empty(B, H, device="cuda"), torch.empty(B, H, device="cuda")
+        ops.gemm(h_prev, w_hh, out=g2, accumulate=True)
+        ops.lstm_cell_fwd(g2, cp, c2, h2)
+        assert torch.equal(g1, g2) and torch.equal(c1, c2) and torch.equal(h1, h2)
+    fn = vqa_amd.functions.LstmBatchFn
+    x = r(5, B, 40)
+    ps = [r(4 * H, 40) * 0.1, w_hh, r(4 * H) * 0.1, r(4 * H) * 0.1]
+    res = []
+    for fused in (True, False):
+        fn.FUSED_STEP = fused
+        try:
+            leaves = [p.clone().requires_grad_() for p in ps]
+            hs = fn.apply(x, *leaves)
+            (hs * torch.linspace(-1, 1, hs.numel(), device="cuda").view_as(hs)).sum().backward()
+            res.append((hs.detach(), [p.grad for p in leaves]))
+        finally:
+            fn.FUSED_STEP = True
+    assert torch.equal(res[0][0], res[1][0])
+    for a, b in zip(res[0][1], res[1][1]):
+        assert torch.equal(a, b)

@@ -42,6 +42,11 @@ struct WaveArgs {
   const float* bias;
   int M, N, K, lda, ldb, ldc, flags;
   int tiles_m, tiles_n, kpart;       // kpart: K range per wave (K for WK = 1, K / 4 for WK = 4)
+  // fused LSTM step (gemm_f32_lstm_fwd_kernel): C = the step's gate buffer (B, 4H), N = 4H
+  const float* c_prev;               // (B, H) or nullptr at the first step
+  float* c_out;
+  float* h_out;
+  int H;
 };
 
 __device__ __forceinline__ int swz(int r) { return (r >> 2) & 3; }
@@ -416,6 +421,142 @@ int launch_shb(const WaveArgs& g, int nwg, hipStream_t s) {
   return vqf_last_error();
 }
 
+// ---- one LSTM step of the question encoder in ONE launch (mfb.py:69; host/functions.py::LstmBatchFn) --------------------------
+//   gates_t (B, 4H) holds x_t W_ih^T + b on entry;  pre = gates_t + h_{t-1} W_hh^T;  i, f, o = sigmoid, g = tanh (PyTorch order
+//   i, f, g, o);  c_t = f c_{t-1} + i g;  h_t = o tanh(c_t);  gates_t leaves ACTIVATED (kept for the backward).
+// The shared-B kernel above with two changes.  (1) A wave's 64 output columns are 16 hidden units x 4 gates: the copy of the
+// W_hh slab takes its source rows per LDS row (the DMA's source address is per lane, nothing else moves): LDS row rho = 32 j +
+// cm holds W_hh row gate(j, cm) H + u0 + (cm & 15) with gate = 2 j + (cm >> 4) -- column tile 0 = (i | f), tile 1 = (g | o) of
+// the same 16 units.  (2) The epilogue IS the cell: a lane activates its two pre-activations, lanes cm and cm ^ 16 hold the
+// same unit and swap (f, o) for (i, g) with one cross-lane move each, lanes cm < 16 update c and h.  The old gate values, and
+// c_{t-1}, are fetched at kernel entry like the accumulating product's C.  Per element the same arithmetic in the same order as
+// vqf_gemm_f32(ACCUM) + vqf_lstm_cell_fwd: bit-identical, 14 launches and a 16 MB round trip per step fewer.
+__device__ __forceinline__ float sigm_f(float x) { return 1.0f / (1.0f + expf(-x)); }     // lstm_cell.hip's sigm
+
+__global__ void __launch_bounds__(NT, 1) gemm_f32_lstm_fwd_kernel(const WaveArgs g) {
+  constexpr int NSL = 6;
+  constexpr int SHB_A = NSL * A_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) char lds_char;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int t = 4 * wg + wave;                         // tiles_m % 4 == 0 (host): the 4 waves share the unit block
+  const int tm = t % g.tiles_m, tn = t / g.tiles_m;
+  const int m0 = tm * WTM, u0 = tn * 16, H = g.H;
+  const int S = g.kpart / TK;
+  char* myA = smem + wave * SHB_A;
+  char* shB = smem + 4 * SHB_A;
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+  gfloat* q[NGS];
+#pragma unroll
+  for (int i = 0; i < NGA; ++i) {
+    const int row = 16 * i + (lane >> 2);
+    const int chunk = (lane & 3) ^ swz(row);
+    q[i] = (gfloat*)(g.A + (long long)min(m0 + row, g.M - 1) * g.lda + chunk * 4);
+  }
+  {
+    const int rho = 16 * wave + (lane >> 2);           // my quarter of the workgroup's B slab: LDS rows 16 wave .. +15
+    const int chunk = (lane & 3) ^ swz(rho);
+    const int gate = 2 * (rho >> 5) + ((rho & 31) >> 4);
+    q[NGA] = (gfloat*)(g.B + (long long)(gate * H + u0 + (rho & 15)) * g.ldb + chunk * 4);
+  }
+  auto copy = [&](int i, int sl) {
+    lds_char* dst = (i < NGA) ? (lds_char*)(myA + sl * A_BYTES + i * 1024) : (lds_char*)(shB + sl * B_BYTES + wave * 1024);
+    __builtin_amdgcn_global_load_lds(q[i], dst, 16, 0, 0);
+    q[i] += TK;
+  };
+#pragma unroll
+  for (int p = 0; p < NSL - 1; ++p)
+    if (p < S) {
+#pragma unroll
+      for (int i = 0; i < NGS; ++i) copy(i, p);
+    }
+  // the lane's old gate values (x W_ih^T + b) and, for the lanes that update the state, c_{t-1}: in flight behind the copies
+  const int cm = lane & 31, hh = lane >> 5;
+  const int col0 = (cm >> 4) * H + u0 + (cm & 15);     // tile 0: gate cm >> 4 (i | f); tile 1: + 2 H (g | o)
+  float old0[16], old1[16], cpv[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int row = m0 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+    const float* pc = g.C + (long long)row * g.ldc + col0;
+    old0[e] = pc[0];
+    old1[e] = pc[2 * H];
+    cpv[e] = (g.c_prev && cm < 16) ? g.c_prev[(long long)row * H + u0 + cm] : 0.f;
+  }
+  FragS<false> fa[2], fb[2];
+  int slot = 0;
+  auto half = [&](int s, FragS<false> (&cur)[2], FragS<false> (&nxt)[2]) {
+    const bool more = s + 1 < S, refill = s + NSL - 1 < S;
+    const int nslot = (slot + 1 == NSL) ? 0 : slot + 1;
+    const int rslot = (slot == 0) ? NSL - 1 : slot - 1;
+#pragma unroll
+    for (int n = 0; n < 16; ++n) {
+      const int ks = n >> 3, e = (n >> 1) & 3, j = n & 1;
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[ks].a[e], cur[ks].b(j, e), acc[j], 0, 0, 0);
+      if (n < NGS && refill) copy(n, rslot);
+      if (n == 6 && more) {
+        wait_copies3(min(NSL - 2, S - 2 - s));
+        __builtin_amdgcn_s_barrier();
+      }
+      if (n == 7 && more) nxt[0].load(myA + nslot * A_BYTES, shB + nslot * B_BYTES, 0, lane);
+      if (n == 9 && more) nxt[1].load(myA + nslot * A_BYTES, shB + nslot * B_BYTES, 1, lane);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_sched_barrier(0);
+    slot = nslot;
+  };
+  if (S > 0) {
+    wait_copies3(min(NSL - 2, S - 1));
+    __builtin_amdgcn_s_barrier();
+    fa[0].load(myA, shB, 0, lane);
+    fa[1].load(myA, shB, 1, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  for (int s = 0; s < S; s += 2) {
+    half(s, fa, fb);
+    if (s + 1 < S) half(s + 1, fb, fa);
+  }
+  // ---- the cell.  Lane (cm, hh), register e: row (e & 3) + 8 (e >> 2) + 4 hh, unit u0 + (cm & 15);
+  //      tile 0 = gate i (cm < 16) | f (cm >= 16), tile 1 = gate g | o
+  const bool lo = cm < 16;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int row = m0 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+    const float a0 = sigm_f(acc[0][e] + old0[e]);                         // i | f
+    const float p1 = acc[1][e] + old1[e];
+    const float a1 = lo ? tanhf(p1) : sigm_f(p1);                         // g | o
+    float* pc = g.C + (long long)row * g.ldc + col0;
+    pc[0] = a0;
+    pc[2 * H] = a1;
+    const float f_act = __shfl_xor(a0, 16, 64), o_act = __shfl_xor(a1, 16, 64);
+    if (lo) {
+      const float c = f_act * cpv[e] + a0 * a1;
+      g.c_out[(long long)row * H + u0 + cm] = c;
+      g.h_out[(long long)row * H + u0 + cm] = o_act * tanhf(c);
+    }
+  }
+}
+
+int launch_lstm_fwd(const WaveArgs& g, int nwg, hipStream_t s) {
+  static VqfDynLdsFlags attr = {};
+  constexpr int SMEM_SHB = 6 * (4 * A_BYTES + B_BYTES);
+  if (int e = vqf_set_dyn_lds(reinterpret_cast<const void*>(&gemm_f32_lstm_fwd_kernel), SMEM_SHB, attr)) return e;
+  VQF_LAUNCH(KID_LSTM_CELL_FWD, gemm_f32_lstm_fwd_kernel, dim3(nwg), dim3(NT), SMEM_SHB, s, g);
+  return vqf_last_error();
+}
+
 template <bool TB, int WK>
 int launch(const WaveArgs& g, int nwg, hipStream_t s) {
   static VqfDynLdsFlags attr = {};
@@ -459,4 +600,28 @@ int vqf_gemm_f32_wave_try(int ta, int tb, int M, int N, int K, const float* A, i
   else if (wk == 1) *rc = tb ? launch<true, 1>(g, nwg1, s) : launch<false, 1>(g, nwg1, s);
   else         *rc = tb ? launch<true, 4>(g, nwg4, s) : launch<false, 4>(g, nwg4, s);
   return 1;
+}
+
+// One fused LSTM step (see gemm_f32_lstm_fwd_kernel).  Supported: B % 128 == 0, H % 16 == 0, H >= 256, 16-byte aligned rows;
+// else VQF_E_UNSUPPORTED and the caller runs vqf_gemm_f32(VQF_GEMM_ACCUM) + vqf_lstm_cell_fwd (the same bits).
+extern "C" int vqf_lstm_step_supported(int B, int H) {
+  return B > 0 && H >= 256 && (B % 128) == 0 && (H % 16) == 0 && vqf_opt(VQF_OPT_GEMM_F32_WAVE, 2) != 0;
+}
+extern "C" int vqf_lstm_step_fwd(const float* h_prev, const float* w_hh, float* gates, const float* c_prev, int B, int H,
+                                 float* c_out, float* h_out, void* stream) {
+  if (!h_prev || !w_hh || !gates || !c_out || !h_out || B <= 0 || H <= 0) return VQF_E_BADARG;
+  if (!vqf_lstm_step_supported(B, H)) return VQF_E_UNSUPPORTED;
+  if (!aligned16(h_prev) || !aligned16(w_hh) || !aligned16(gates) || !aligned16(c_out) || !aligned16(h_out) ||
+      (c_prev && !aligned16(c_prev)))
+    return VQF_E_ALIGN;
+  WaveArgs g = {};
+  g.A = h_prev; g.B = w_hh; g.C = gates; g.bias = nullptr;
+  g.M = B; g.N = 4 * H; g.K = H; g.lda = H; g.ldb = H; g.ldc = 4 * H; g.flags = VQF_GEMM_ACCUM;
+  g.tiles_m = B / WTM;
+  g.tiles_n = H / 16;
+  g.kpart = H;
+  g.c_prev = c_prev; g.c_out = c_out; g.h_out = h_out; g.H = H;
+  vqf_prof_dims(B, 4 * H, H);
+  vqf_stat_bump(VQF_STAT_GEMM_F32_WAVE);
+  return launch_lstm_fwd(g, g.tiles_m * g.tiles_n / 4, (hipStream_t)stream);
 }

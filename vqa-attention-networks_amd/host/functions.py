@@ -840,6 +840,8 @@ class LstmBatchFn(torch.autograd.Function):
     bf16=True (bf16 mode): the recurrent products take bf16 operands (W_hh cast once, h_t / dG_t per step),
     fp32 accumulation; gates, cell state and every stored tensor stay fp32."""
 
+    FUSED_STEP = True      # fp32: a step's recurrent product and its cell stage in one launch where supported (A/B switch)
+
     @staticmethod
     def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, bf16=False):
         x = _c(x)
@@ -853,7 +855,11 @@ class LstmBatchFn(torch.autograd.Function):
         gates = gates.view(T, B, 4 * H)                     # pre-activations -> activated in place
         hs = torch.empty((T, B, H), dtype=torch.float32, device=x.device)
         cs = torch.empty_like(hs)
+        fused = LstmBatchFn.FUSED_STEP and not ctx.bf16 and ops.lstm_step_supported(B, H)
         for t in range(T):
+            if t > 0 and fused:                 # product + cell in ONE launch (bit-identical to the two below; csrc/gemm_f32_wave.hip)
+                ops.lstm_step_fwd(hs[t - 1], whh, gates[t], cs[t - 1], cs[t], hs[t])
+                continue
             if t > 0:                                                               # += h_{t-1} W_hh^T
                 if ctx.bf16:
                     ops.gemm_bf16(ops.cast_bf16(hs[t - 1]), whh, out=gates[t], accumulate=True)

@@ -100,6 +100,8 @@ SIGNATURES = {
     "vqf_lstm_seq_fwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_i, c_p, c_sz, c_p]),
     "vqf_lstm_seq_bwd": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_i, c_p, c_sz, c_p]),
     "vqf_lstm_cell_fwd": (c_i, [c_f, c_f, c_i, c_i, c_f, c_f, c_p]),
+    "vqf_lstm_step_supported": (c_i, [c_i, c_i]),
+    "vqf_lstm_step_fwd": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_p]),
     "vqf_lstm_cell_bwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_p]),
     "vqf_embed_tanh_fwd": (c_i, [c_f, c_p, c_i, c_i, c_i, c_f, c_p]),
     "vqf_embed_tanh_bwd": (c_i, [c_f, c_f, c_p, c_i, c_i, c_i, c_f, c_p]),

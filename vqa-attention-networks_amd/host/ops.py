@@ -706,6 +706,18 @@ def lstm_cell_fwd(gates, c_prev, c_out, h_out):
              "vqf_lstm_cell_fwd")
 
 
+def lstm_step_supported(B, H):
+    return bool(_lib().vqf_lstm_step_supported(int(B), int(H)))
+
+
+def lstm_step_fwd(h_prev, w_hh, gates, c_prev, c_out, h_out):
+    """one LSTM step in one launch: gates (B,4H) += h_prev W_hh^T, then the cell in the product's epilogue (include/vqa_fusion.h)"""
+    _chk(h_prev, w_hh, gates, c_prev, c_out, h_out)
+    B, H4 = gates.shape
+    _l.check(_lib().vqf_lstm_step_fwd(_ptr(h_prev), _ptr(w_hh), _ptr(gates), _ptr(c_prev), B, H4 // 4, _ptr(c_out), _ptr(h_out),
+                                      _stream()), "vqf_lstm_step_fwd")
+
+
 def lstm_cell_bwd(dhs_t, dh_carry, gates, c_t, c_prev, first, dc_carry, dG):
     _chk(dhs_t, dh_carry, gates, c_t, c_prev, dc_carry, dG)
     B, H = dhs_t.shape
