@@ -413,3 +413,42 @@ def test_large_tile_splitk_combined_in_the_launch_bitwise(ops, dtype, ta, tb, M,
     if "relu" in extras:
         ref = torch.relu(ref)
     assert _rel(one, ref) <= (2e-5 * max(1.0, np.sqrt(K) / 16) if dtype == "bf16" else 2e-6 * max(1.0, np.sqrt(K) / 8))
+
+
+@pytest.mark.parametrize("ta,tb,M,N,K,extras", [
+    (0, 0, 50176, 512, 2048, "bias+relu"),     # HieCoAtten's img_emb (hieCoAtten.py:25): 392 tiles = 1.53 rounds of 256 CUs
+    (0, 1, 50176, 512, 1024, ""),              # the input gradient of its concatenated fc_Wbv / fc_Wv product (K = 2E)
+    (0, 0, 45000, 768, 520, "bias"),           # ragged M (176 row tiles x 3 = 528 tiles), K % 16 == 8: zero-filled last slab
+    (1, 1, 512 * 98, 512, 1536, ""),           # K-major operands
+])
+def test_stream_k_tail_of_the_large_tile_kernel(ops, ta, tb, M, N, K, extras):
+    """A mid-size product whose tiles are whole rounds of the CUs plus a substantial partial round runs that partial round
+    as a STREAM-K tail (gemm_f32_big.hip: the K slabs of the tail tiles shared out evenly over the CUs, 2-3 part images per
+    tail tile summed in part order by the tile's last-arriving fragment): against fp64; against the row-split form (option
+    gemm_f32_streamk = 0) to rounding; BIT-identical run to run and under a CU limit (the shares are those of 256 virtual
+    workers whatever the launch's grid); the whole product is ONE launch of the large-tile kernel."""
+    A = _u((K, M) if ta else (M, K), 81)
+    B = _u((K, N) if tb else (N, K), 82, 0.05)
+    bias = _u((N,), 83) if "bias" in extras else None
+    kw = dict(ta=bool(ta), tb=bool(tb), bias=bias, relu="relu" in extras)
+    assert ops.gemm_big_rows(ta, tb, M, N, K) == M
+    n0, t0 = ops.stat("gemm_f32_big"), ops.stat("gemm_f32_tile128")
+    out = ops.gemm(A, B, **kw)
+    assert ops.stat("gemm_f32_big") == n0 + 1 and ops.stat("gemm_f32_tile128") == t0
+    ref = _ref64(A, B, ta, tb, bias)
+    if "relu" in extras:
+        ref = torch.relu(ref)
+    assert _rel(out, ref) <= 2e-6 * max(1.0, np.sqrt(K) / 8)
+    for _ in range(2):
+        assert torch.equal(ops.gemm(A, B, **kw), out)
+    with ops.options(gemm_cu_limit=128):
+        assert torch.equal(ops.gemm(A, B, **kw), out)
+    with ops.options(gemm_cu_limit=200):
+        assert torch.equal(ops.gemm(A, B, **kw), out)
+    with ops.options(gemm_f32_streamk=0):
+        assert ops.gemm_big_rows(ta, tb, M, N, K) < M
+        old = ops.gemm(A, B, **kw)
+    assert _rel(old, ref) <= 2e-6 * max(1.0, np.sqrt(K) / 8)
+    d = (out - old).abs().max().item()
+    assert d <= 4e-6 * float(ref.abs().max())       # whole tiles are bit-equal, tail tiles re-associate 2-3 partial sums
+    assert not torch.equal(out, old)

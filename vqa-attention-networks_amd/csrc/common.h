@@ -170,7 +170,9 @@ __device__ __forceinline__ float wave_max(float v) {
 // the two-launch form.  Nobody waits for anybody (no spin: every wave reaches its exit); the last arriver leaves the counter at
 // zero.  slab: [splits][M][N] fp32.  Returns true in the workgroup that wrote the tile.  `scratch`: 4 bytes of the kernel's ONE
 // LDS array (free at this point).  TILE_N / 4 must divide NT.
-struct VqfSplitkTile { int* cnt; const float* slab; float* C; const float* bias; int M, N, ldc, flags; };
+// pstride != 0: TILE-LOCAL slabs (the stream-K tail of gemm_f32_big.hip): part z of this tile at slab + z * pstride, a
+// TILE_M x TILE_N image with row pitch sld -- `slab` then points at the tile's own parts; 0: [splits][M][N] as above.
+struct VqfSplitkTile { int* cnt; const float* slab; float* C; const float* bias; int M, N, ldc, flags; long long pstride; int sld; };
 template <int TILE_M, int TILE_N, int NT, bool WT = false>      // WT: the slabs were stored write-through (sc1): no release fence
 __device__ __forceinline__ bool vqf_splitk_combine(const VqfSplitkTile& g, int tile, int splits, int m0, int n0, int tid,
                                                    float* scratch) {
@@ -196,19 +198,23 @@ __device__ __forceinline__ bool vqf_splitk_combine(const VqfSplitkTile& g, int t
   __syncthreads();
   constexpr int CT = TILE_N / 4, RSTEP = NT / CT;
   static_assert(NT % CT == 0, "TILE_N / 4 must divide the workgroup size");
-  const long long total = (long long)g.M * g.N;
+  const bool local = g.pstride != 0;
+  const long long total = local ? g.pstride : (long long)g.M * g.N;       // distance between the parts of a tile
+  const int sld = local ? g.sld : g.N;                                     // row pitch of a part
+  const int srow0 = local ? m0 : 0, scol0 = local ? n0 : 0;
   const bool relu = g.flags & VQF_GEMM_RELU, accum = g.flags & VQF_GEMM_ACCUM;
   const int c4 = tid % CT, r0 = tid / CT;
   const int col = n0 + 4 * c4;
-  if ((g.N & 3) == 0 && (g.ldc & 3) == 0 && aligned16_dev(g.C) && aligned16_dev(g.slab) && (!g.bias || aligned16_dev(g.bias))) {
+  if ((g.N & 3) == 0 && (sld & 3) == 0 && (g.ldc & 3) == 0 && aligned16_dev(g.C) && aligned16_dev(g.slab) &&
+      (!g.bias || aligned16_dev(g.bias))) {
     if (col >= g.N) return true;
     const f32x4 bv = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
     for (int k = 0; k < TILE_M / RSTEP; k += 2) {
       const int rowA = m0 + r0 + RSTEP * k, rowB = rowA + RSTEP;
       if (rowA >= g.M) break;
       const bool hasB = rowB < g.M && k + 1 < TILE_M / RSTEP;
-      const float* pA = g.slab + (long long)rowA * g.N + col;
-      const float* pB = g.slab + (long long)(hasB ? rowB : rowA) * g.N + col;
+      const float* pA = g.slab + (long long)(rowA - srow0) * sld + (col - scol0);
+      const float* pB = g.slab + (long long)((hasB ? rowB : rowA) - srow0) * sld + (col - scol0);
       f32x4 vA = {0.f, 0.f, 0.f, 0.f}, vB = vA;
       int z = 0;
       for (; z + 3 < splits; z += 4) {
@@ -246,7 +252,7 @@ __device__ __forceinline__ bool vqf_splitk_combine(const VqfSplitkTile& g, int t
     if (row >= g.M) break;
     for (int j = 0; j < 4; ++j) {
       if (col + j >= g.N) break;
-      const long long i = (long long)row * g.N + col + j;
+      const long long i = (long long)(row - srow0) * sld + (col + j - scol0);
       float v = 0.f;
       for (int z = 0; z < splits; ++z) v += g.slab[z * total + i];
       if (g.bias) v += g.bias[col + j];

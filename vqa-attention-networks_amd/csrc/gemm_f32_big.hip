@@ -80,6 +80,14 @@ struct BigArgs {
   int* cnt;
   float* Cfinal;
   int ldc_final;
+  // STREAM-K TAIL (splits == 1, no edge phase): the first sk_fw tiles (whole rounds of sk_V virtual workers) are whole work
+  // items as ever; the K slabs of the remaining sk_tail tiles -- fewer than sk_V: the partial round that would leave most
+  // CUs idle -- form ONE sequence of sk_tail x S slabs that the virtual workers share out evenly (sk_q consecutive slabs each,
+  // at most two tiles touched).  A fragment's accumulators go to its tile's own slab image (sk_slab + (tile x 3 + part) x 256
+  // x 256 floats) and the tile's LAST-arriving fragment sums the 2-3 parts in part order (vqf_splitk_combine, tile-local
+  // form).  Workgroup b plays the virtual workers b, b + gridDim.x, ...: the result does not depend on the launch's CU limit.
+  int sk_tail, sk_fw, sk_V, sk_q;
+  float* sk_slab;
 #ifdef VQF_F32BIG_CLOCK
   unsigned long long* dbg;   // diagnostic build only (tools/f32_clock.py): per workgroup and wave half, s_memtime / s_memrealtime stamps
 #endif
@@ -457,7 +465,7 @@ __global__ void __launch_bounds__(NT, 2) gemm_f32_big_kernel(const BigArgs g) {
   // the longest workgroup).
   const int G = gridDim.x;
   const int ntiles1 = g.tiles_m * g.tiles_n_full;
-  const int F = ntiles1 * g.splits;                    // phase-1 items
+  const int F = g.sk_tail > 0 ? g.sk_fw : ntiles1 * g.splits;     // phase-1 items (stream-K: the whole rounds only)
   const int E = g.tiles_m * (g.tiles_n - g.tiles_n_full);   // phase-2 items
   int cur_w = blockIdx.x, cur_e;
   {
@@ -466,6 +474,11 @@ __global__ void __launch_bounds__(NT, 2) gemm_f32_big_kernel(const BigArgs g) {
     cur_e = r < g.edge_wn ? r : E;
   }
   int z = 0, m0 = 0, n0 = 0, kbeg = 0, S = 0, kt = TK, nj = 4;  // current work item (uniform over the workgroup); nj: this wave's live column tiles
+  // stream-K tail state: next virtual worker of this workgroup, its remaining slab range, and the current item's fragment
+  // descriptor (frag_parts == 0: a whole tile)
+  int sk_v = blockIdx.x, sk_it = 0, sk_end = 0;
+  int frag_parts = 0, frag_part = 0, frag_tile = 0, frag_k0 = 0, frag_S = 0;
+  bool frag_last = false;
 #ifdef VQF_F32BIG_CLOCK
   int w_dbg = 0;
 #endif
@@ -474,6 +487,7 @@ __global__ void __launch_bounds__(NT, 2) gemm_f32_big_kernel(const BigArgs g) {
   int slot = 0;                                        // ring slot of the current tile's slab 0, then of slab s
   auto next_item = [&]() -> bool {                     // locate the next work item, issue its first NSLOT-1 slabs
     int tm, tn;
+    frag_parts = 0;
     if (cur_w < F) {
 #ifdef VQF_F32BIG_CLOCK
       w_dbg = cur_w;
@@ -496,6 +510,36 @@ __global__ void __launch_bounds__(NT, 2) gemm_f32_big_kernel(const BigArgs g) {
 #endif
       z = 0; tm = cur_e; tn = g.tiles_n - 1;
       cur_e += g.edge_wn;
+    } else if (g.sk_tail > 0) {
+      // stream-K tail: the next fragment of this workgroup's current virtual worker, or the next virtual worker's first one
+      const int Stile = (g.K + TK - 1) / TK, T = g.sk_tail * Stile;
+      while (sk_it >= sk_end) {
+        if (sk_v >= g.sk_V) return false;
+        sk_it = min(T, sk_v * g.sk_q);
+        sk_end = min(T, sk_it + g.sk_q);
+        sk_v += G;
+      }
+      const int tt = sk_it / Stile, s0 = sk_it - tt * Stile;
+      const int len = min(Stile - s0, sk_end - sk_it);
+      const int v_first = (tt * Stile) / g.sk_q;                     // the virtual worker that holds the tile's first slab
+      frag_part = sk_it / g.sk_q - v_first;
+      frag_parts = ((tt + 1) * Stile - 1) / g.sk_q - v_first + 1;
+      frag_tile = tt;
+      sk_it += len;
+      int id = g.sk_fw + tt;
+      {
+        const int q8 = ntiles1 / 8, r8 = ntiles1 % 8, xcd = id % 8, k = id / 8;
+        id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
+      }
+      const int per_group = g.group_m * g.tiles_n_full;
+      const int grp = id / per_group, in = id % per_group;
+      const int gm0 = grp * g.group_m;
+      const int gsz = min(g.group_m, g.tiles_m - gm0);
+      tm = gm0 + in % gsz; tn = in / gsz;
+      z = 0;
+      frag_k0 = s0 * TK;
+      frag_S = len;
+      frag_last = (s0 + len == Stile);
     } else {
       return false;
     }
@@ -505,6 +549,11 @@ __global__ void __launch_bounds__(NT, 2) gemm_f32_big_kernel(const BigArgs g) {
       const int klen = min(g.K, kbeg + g.kchunk) - kbeg;
       S = (klen + TK - 1) / TK;                        // slabs of this split
       kt = klen - (S - 1) * TK;                        // k of the last slab (TK, or K % TK: only the last split can be short)
+    }
+    if (frag_parts > 0) {                              // a stream-K fragment: slabs frag_k0 / TK .. of the tile
+      kbeg = frag_k0;
+      kt = frag_last ? kt : TK;
+      S = frag_S;
     }
     // live columns of the two column strips: a K-contiguous B strip with <= 64 of them is staged in identity order and its
     // waves multiply 1 or 2 column tiles; a strip without any multiplies nothing
@@ -550,6 +599,19 @@ __global__ void __launch_bounds__(NT, 2) gemm_f32_big_kernel(const BigArgs g) {
 #ifdef VQF_F32BIG_CLOCK
   const unsigned long long c2 = __builtin_amdgcn_s_memtime(), r2 = __builtin_amdgcn_s_memrealtime();
 #endif
+  if (frag_parts > 1) {
+    // a stream-K fragment: the accumulators go to this tile's part image (a full 256 x 256 tile, pitch 256: no edge guards),
+    // the tile's last-arriving fragment adds the parts up in part order and applies bias / ReLU (vqf_splitk_combine)
+    float* img = g.sk_slab + ((size_t)frag_tile * 3 + frag_part) * (TM * TN);
+    BigArgs gl = g;
+    gl.M = TM; gl.N = TN; gl.ldc = TN;
+    store_tile<TA, false, true>(gl, img, acc, wr * 64, wc * 128, lane, false, false);
+    const VqfSplitkTile st = {g.cnt, g.sk_slab + (size_t)frag_tile * 3 * (TM * TN), g.Cfinal, g.bias, g.M, g.N, g.ldc_final,
+                              g.flags, (long long)TM * TN, TN};
+    vqf_splitk_combine<TM, TN, NT>(st, frag_tile, frag_parts, m0, n0, tid, reinterpret_cast<float*>(smem));
+    if (!next_item()) break;
+    continue;
+  }
   const bool split = g.splits > 1;
   const bool relu = !split && (g.flags & VQF_GEMM_RELU) != 0;
   float* C = split ? g.C + (size_t)z * g.M * g.N : g.C;
@@ -725,6 +787,26 @@ int whole_round_rows(int ta, int tb, int M, int N, int K, int flags) {
   return 0;
 }
 
+// STREAM-K TAIL.  A mid-size product whose tile count is a whole number of rounds plus a substantial partial round (HieCoAtten's
+// 50176 x 512 products: 392 tiles = 1.53 rounds of 256 CUs) either runs that partial round with most CUs idle or hands its
+// rows to the 128x128 kernel (whole_round_rows above: 544 tiles on 256 CUs, 92 TF).  Instead the K slabs of the partial round's
+// tiles are shared out evenly over the CUs (kernel header, BigArgs::sk_*): 1.53 rounds take 1.53 tile times.  Returns the
+// number of tail tiles (0 = not this way).  Conditions: persistent launch form, no rowscale epilogue, whole column tiles
+// (N % 256 == 0), K >= 512, one to four rounds, a tail between 1/8 and 24/25 of a round, scratch for 3 part images per tail tile.
+int streamk_tail(int ta, int tb, int M, int N, int K, int flags, size_t ws_bytes, bool rowscale) {
+  if (vqf_opt(VQF_OPT_GEMM_F32_BIG, 1) == 0 || vqf_opt(VQF_OPT_GEMM_F32_STREAMK, 1) == 0) return 0;
+  if (vqf_opt(VQF_OPT_GEMM_F32_PERSIST, 1) == 0) return 0;
+  if (rowscale || (flags & VQF_GEMM_ACCUM) || (K % 4) || K < 512 || M < TM || (N % TN) || (ta && (M % 4))) return 0;
+  const int V = vqf_cu_count() & ~7;
+  if (V < 8) return 0;
+  const int tiles = ((M + TM - 1) / TM) * (N / TN);
+  if (tiles < V || tiles >= 4 * V) return 0;
+  const int tail = tiles % V;
+  if (tail * 8 < V || tail * 25 > V * 24) return 0;
+  if ((size_t)tail * 3 * TM * TN * sizeof(float) > ws_bytes) return 0;
+  return tail;
+}
+
 // 16 zero bytes in device memory (BigArgs::zeros), per device
 __device__ __attribute__((aligned(16))) float vqf_f32big_zeros[4] = {0.f, 0.f, 0.f, 0.f};
 const float* zeros16() {
@@ -753,6 +835,7 @@ size_t vqf_gemm_f32_big_ws_bytes(int ta, int tb, int M, int N, int K) {
 // block of a mid-size shape (the rest runs on the 128x128 / per-wave kernels)
 int vqf_gemm_f32_big_rows_impl(int ta, int tb, int M, int N, int K, int flags, size_t ws_bytes) {
   if (big_applies(ta, tb, M, N, K, flags, ws_bytes)) return M;
+  if (streamk_tail(ta, tb, M, N, K, flags, ws_bytes, false) > 0) return M;
   return whole_round_rows(ta, tb, M, N, K, flags);
 }
 
@@ -763,7 +846,8 @@ int vqf_gemm_f32_big_try(int ta, int tb, int M, int N, int K, const float* A, in
                           hipStream_t s, int* rc, int* rows_done) {
   const size_t ws_ok = (ws && aligned16(ws)) ? ws_bytes : 0;
   const bool whole = big_applies(ta, tb, M, N, K, flags, ws_ok);
-  const int Mb = whole ? M : whole_round_rows(ta, tb, M, N, K, flags);
+  const int sk_tail = whole ? 0 : streamk_tail(ta, tb, M, N, K, flags, ws_ok, rowscale != nullptr);
+  const int Mb = (whole || sk_tail > 0) ? M : whole_round_rows(ta, tb, M, N, K, flags);
   if (Mb <= 0) return 0;
   BigArgs g;
   g.A = A; g.B = B; g.C = C; g.bias = bias;
@@ -785,6 +869,16 @@ int vqf_gemm_f32_big_try(int ta, int tb, int M, int N, int K, const float* A, in
   splits = (K + g.kchunk - 1) / g.kchunk;
   g.splits = splits;
   g.cnt = nullptr; g.Cfinal = C; g.ldc_final = ldc;
+  g.sk_tail = 0; g.sk_fw = 0; g.sk_V = 0; g.sk_q = 0; g.sk_slab = nullptr;
+  if (sk_tail > 0) {
+    const int V = vqf_cu_count() & ~7;
+    g.cnt = vqf_splitk_counters(sk_tail);
+    if (g.cnt) {
+      g.sk_tail = sk_tail; g.sk_V = V; g.sk_fw = tiles - sk_tail;
+      g.sk_q = (int)(((long long)sk_tail * slabs + V - 1) / V);
+      g.sk_slab = (float*)ws;
+    }
+  }
   if (splits > 1) {
     g.C = (float*)ws; g.ldc = N;
     // combined in the launch when there are enough tiles for the last arrivers to read their slabs side by side (each reads
