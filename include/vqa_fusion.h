@@ -82,8 +82,9 @@ const char* vqf_build_info(void);
 #define VQF_OPT_GEMM_SPLITK_FUSED 13  /* split-K combined INSIDE the GEMM launch (the last-arriving workgroup of an output tile sums the slabs in
                                         split order; same bits as the slabs + vqf_splitk_reduce form): default = in the 256x256-tile kernels
                                         with >= 64 output tiles only; 1 = in the 128x128-tile kernels too (measured slower there); 0 = never */
-#define VQF_OPT_GEMM_F32_STREAMK 14   /* 0 = no stream-K tail in the large-tile fp32 GEMM: a mid-size product's partial last round goes to the
-                                        128x128 kernel by rows instead (A/B; csrc/gemm_f32_big.hip) */
+#define VQF_OPT_GEMM_F32_STREAMK 14   /* 1 = stream-K tail in the large-tile fp32 GEMM: the K slabs of a mid-size product's partial last round are
+                                        shared out evenly over the CUs, 2-3 part images per tail tile combined in the launch (opt-in:
+                                        measured a wash against the default, the whole-rounds row split; csrc/gemm_f32_big.hip) */
 #define VQF_OPT_COUNT 15
 int vqf_set_option(int option, int value, int* previous);
 int vqf_get_option(int option, int* value);

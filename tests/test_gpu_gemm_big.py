@@ -422,32 +422,32 @@ def test_large_tile_splitk_combined_in_the_launch_bitwise(ops, dtype, ta, tb, M,
     (1, 1, 512 * 98, 512, 1536, ""),           # K-major operands
 ])
 def test_stream_k_tail_of_the_large_tile_kernel(ops, ta, tb, M, N, K, extras):
-    """A mid-size product whose tiles are whole rounds of the CUs plus a substantial partial round runs that partial round
-    as a STREAM-K tail (gemm_f32_big.hip: the K slabs of the tail tiles shared out evenly over the CUs, 2-3 part images per
-    tail tile summed in part order by the tile's last-arriving fragment): against fp64; against the row-split form (option
-    gemm_f32_streamk = 0) to rounding; BIT-identical run to run and under a CU limit (the shares are those of 256 virtual
-    workers whatever the launch's grid); the whole product is ONE launch of the large-tile kernel."""
+    """Option gemm_f32_streamk = 1 (opt-in: measured a wash against the default row split): a mid-size product whose tiles are
+    whole rounds of the CUs plus a substantial partial round runs that partial round as a STREAM-K tail (gemm_f32_big.hip: the
+    K slabs of the tail tiles shared out evenly over the CUs, 2-3 part images per tail tile summed in part order by the tile's
+    last-arriving fragment): against fp64; against the default row-split form to rounding; BIT-identical run to run and under
+    a CU limit (the shares are those of 256 virtual workers whatever the launch's grid); ONE launch of the large-tile kernel."""
     A = _u((K, M) if ta else (M, K), 81)
     B = _u((K, N) if tb else (N, K), 82, 0.05)
     bias = _u((N,), 83) if "bias" in extras else None
     kw = dict(ta=bool(ta), tb=bool(tb), bias=bias, relu="relu" in extras)
-    assert ops.gemm_big_rows(ta, tb, M, N, K) == M
-    n0, t0 = ops.stat("gemm_f32_big"), ops.stat("gemm_f32_tile128")
-    out = ops.gemm(A, B, **kw)
-    assert ops.stat("gemm_f32_big") == n0 + 1 and ops.stat("gemm_f32_tile128") == t0
     ref = _ref64(A, B, ta, tb, bias)
     if "relu" in extras:
         ref = torch.relu(ref)
-    assert _rel(out, ref) <= 2e-6 * max(1.0, np.sqrt(K) / 8)
-    for _ in range(2):
-        assert torch.equal(ops.gemm(A, B, **kw), out)
-    with ops.options(gemm_cu_limit=128):
-        assert torch.equal(ops.gemm(A, B, **kw), out)
-    with ops.options(gemm_cu_limit=200):
-        assert torch.equal(ops.gemm(A, B, **kw), out)
-    with ops.options(gemm_f32_streamk=0):
-        assert ops.gemm_big_rows(ta, tb, M, N, K) < M
-        old = ops.gemm(A, B, **kw)
+    with ops.options(gemm_f32_streamk=1):
+        assert ops.gemm_big_rows(ta, tb, M, N, K) == M
+        n0, t0 = ops.stat("gemm_f32_big"), ops.stat("gemm_f32_tile128")
+        out = ops.gemm(A, B, **kw)
+        assert ops.stat("gemm_f32_big") == n0 + 1 and ops.stat("gemm_f32_tile128") == t0
+        assert _rel(out, ref) <= 2e-6 * max(1.0, np.sqrt(K) / 8)
+        for _ in range(2):
+            assert torch.equal(ops.gemm(A, B, **kw), out)
+        with ops.options(gemm_cu_limit=128):
+            assert torch.equal(ops.gemm(A, B, **kw), out)
+        with ops.options(gemm_cu_limit=200):
+            assert torch.equal(ops.gemm(A, B, **kw), out)
+    assert ops.gemm_big_rows(ta, tb, M, N, K) < M         # the default: whole rounds here, the remaining rows on the 128x128 kernel
+    old = ops.gemm(A, B, **kw)
     assert _rel(old, ref) <= 2e-6 * max(1.0, np.sqrt(K) / 8)
     d = (out - old).abs().max().item()
     assert d <= 4e-6 * float(ref.abs().max())       # whole tiles are bit-equal, tail tiles re-associate 2-3 partial sums

@@ -794,7 +794,12 @@ int whole_round_rows(int ta, int tb, int M, int N, int K, int flags) {
 // number of tail tiles (0 = not this way).  Conditions: persistent launch form, no rowscale epilogue, whole column tiles
 // (N % 256 == 0), K >= 512, one to four rounds, a tail between 1/8 and 24/25 of a round, scratch for 3 part images per tail tile.
 int streamk_tail(int ta, int tb, int M, int N, int K, int flags, size_t ws_bytes, bool rowscale) {
-  if (vqf_opt(VQF_OPT_GEMM_F32_BIG, 1) == 0 || vqf_opt(VQF_OPT_GEMM_F32_STREAMK, 1) == 0) return 0;
+  // OPT-IN (option gemm_f32_streamk = 1), measured and not the default: HieCoAtten's img_emb product 0.94 -> 0.92 ms, the input
+  // gradient of its concatenated layers 0.478 -> 0.490 (gpurun_out/r04: tools/gemm_census.py).  A fragment of ~68 slabs pays the
+  // tile epilogue (~9 slab times of stores, now into its part image) and its share of the combine (release + ticket; the last
+  // arriver reads 2-3 x 256 KB) on top: ~0.32 ms for the 0.25 ms of work the even shares would take -- what the whole-rounds row
+  // split (whole_round_rows) gets from the 128x128 kernel for the same rows.  Kept: correct, deterministic, tested.
+  if (vqf_opt(VQF_OPT_GEMM_F32_BIG, 1) == 0 || vqf_opt(VQF_OPT_GEMM_F32_STREAMK, 0) != 1) return 0;
   if (vqf_opt(VQF_OPT_GEMM_F32_PERSIST, 1) == 0) return 0;
   if (rowscale || (flags & VQF_GEMM_ACCUM) || (K % 4) || K < 512 || M < TM || (N % TN) || (ta && (M % 4))) return 0;
   const int V = vqf_cu_count() & ~7;
