@@ -418,7 +418,9 @@ def test_mfb_fuse_access_variants_give_the_same_bits(ops, pbf16):
             assert torch.equal(a.view(torch.uint8), b.view(torch.uint8)), v
 
 
-@pytest.mark.parametrize("T,V,E", [(7168, 1000, 300), (5000, 3, 300), (130, 50, 7), (64, 9, 1024)])
+@pytest.mark.parametrize("T,V,E", [(7168, 1000, 300), (5000, 3, 300), (130, 50, 7), (64, 9, 1024),
+                                   (7168, 20000, 300),      # a dataset-sized vocabulary (~15-20 k words, utils.py): 10 rows per workgroup
+                                   (3000, 5001, 512)])       # 3 rows per workgroup, V not a multiple of it
 def test_embed_tanh_fwd_bwd_vs_torch_fp64(ops, T, V, E):
     """tanh(Embedding(q)) (mfb.py:68) and its weight gradient: vs torch in fp64; the backward is a token-ordered segment
     sum (bit-reproducible), writes every vocabulary row (zeros for unused ids) and handles ids that repeat thousands of

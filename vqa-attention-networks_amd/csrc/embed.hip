@@ -5,8 +5,9 @@
 //
 // forward : out[t, :] = tanh(W[ids[t], :])                       one wave per token row, 16-byte accesses when E % 4 == 0
 // backward: dW[v, :] = sum_{t: ids[t] == v} dout[t, :] * (1 - out[t, :]^2)        for EVERY vocabulary row v (zeros where unused)
-//   One workgroup per vocabulary row: its four waves scan 2048 token ids per round (512 each, ballot) and list the matching
-//   tokens in LDS in increasing order; the workgroup then adds their rows column-parallel in that order.  No atomics, no sort: the sum
+//   One workgroup per 1-16 consecutive vocabulary rows: its four waves scan 2048 token ids per round (512 each, loaded once,
+//   one ballot pass per row) and list a row's matching tokens in LDS in increasing order; the workgroup then adds their rows
+//   column-parallel in that order.  No atomics, no sort: the sum
 //   order is the token order, the same on every run (torch's embedding backward sorts the indices and runs ~20 small kernels,
 //   ~0.1 ms of the MFB train step; this is one launch of ~10 us).
 // Ids outside [0, V) select no row: the forward writes zeros for them, the backward ignores them (the reference's ids come
@@ -38,61 +39,84 @@ __global__ void embed_fwd_kernel(const float* __restrict__ W, const long long* _
 }
 
 constexpr int EB_CHUNK = 2048;     // token ids scanned per round: 512 per wave (the match lists live in LDS)
+constexpr int EB_ROWS = 16;        // vocabulary rows per workgroup, at most
 
+// One workgroup owns RV <= 16 consecutive vocabulary rows (RV = 1 for the synthetic V = 1000: a workgroup per row as in round 3;
+// a dataset vocabulary of ~20 k words: 10 rows per workgroup, 2000 workgroups): the token ids of a round are loaded ONCE per
+// workgroup and compared against each of its rows from registers, so the work is O(V / RV * T) id loads + O(V * T / 64) compares,
+// not O(V * T) loads (at V = 20 k the one-row form re-read the whole id list 20 000 times).
 template <bool TANH>
 __global__ void __launch_bounds__(256) embed_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
-                                                            const long long* __restrict__ ids, int T, int E,
+                                                            const long long* __restrict__ ids, int T, int V, int E, int RV,
                                                             float* __restrict__ dW) {
   __shared__ int list[4][EB_CHUNK / 4];
   __shared__ int count[4];
-  const int v = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // every thread owns columns tid, tid + 256, ... (E <= 1024: at most 4)
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const int v0 = blockIdx.x * RV, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // every thread owns columns tid, tid + 256, ... (E <= 1024: at most 4) of each of the workgroup's rows
+  float acc[EB_ROWS][4];
+#pragma unroll
+  for (int r = 0; r < EB_ROWS; ++r)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[r][k] = 0.f;
   for (int t0 = 0; t0 < T; t0 += EB_CHUNK) {
-    {                                                    // wave w lists the matches among tokens t0 + 512 w .. + 511, in order
-      const int b0 = t0 + wave * (EB_CHUNK / 4);
-      long long idv[EB_CHUNK / 4 / 64];
+    const int b0 = t0 + wave * (EB_CHUNK / 4);
+    long long idv[EB_CHUNK / 4 / 64];
 #pragma unroll
-      for (int r = 0; r < EB_CHUNK / 4 / 64; ++r) {      // the 8 id loads of a wave are issued together
-        const int t = b0 + 64 * r + lane;
-        idv[r] = t < T ? ids[t] : -1;
-      }
-      int n = 0;
-#pragma unroll
-      for (int r = 0; r < EB_CHUNK / 4 / 64; ++r) {
-        const bool hit = idv[r] == (long long)v;
-        const unsigned long long m = __ballot(hit);
-        if (hit) list[wave][n + __popcll(m & ((1ull << lane) - 1ull))] = b0 + 64 * r + lane;
-        n += __popcll(m);
-      }
-      if (lane == 0) count[wave] = n;
+    for (int q = 0; q < EB_CHUNK / 4 / 64; ++q) {        // the 8 id loads of a wave are issued together, once per round
+      const int t = b0 + 64 * q + lane;
+      idv[q] = t < T ? ids[t] : -1;
     }
-    __syncthreads();
-    for (int w = 0; w < 4; ++w) {                        // wave lists in wave order = token order: a fixed summation order
-      const int n = count[w];
-      for (int i = 0; i < n; ++i) {
-        const long long row = (long long)list[w][i] * E;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int c = tid + 256 * k;
-          if (c < E) {
-            if (TANH) {
-              const float y = out[row + c];
-              acc[k] += dout[row + c] * (1.0f - y * y);
-            } else {
-              acc[k] += dout[row + c];
+    for (int r = 0; r < EB_ROWS; ++r) {
+      if (r >= RV) break;                                // (uniform)
+      const long long v = v0 + r;
+      {                                                  // wave w lists the matches among its 512 tokens, in order
+        int n = 0;
+#pragma unroll
+        for (int q = 0; q < EB_CHUNK / 4 / 64; ++q) {
+          const bool hit = idv[q] == v;
+          const unsigned long long m = __ballot(hit);
+          if (hit) list[wave][n + __popcll(m & ((1ull << lane) - 1ull))] = b0 + 64 * q + lane;
+          n += __popcll(m);
+        }
+        if (lane == 0) count[wave] = n;
+      }
+      __syncthreads();
+      for (int w = 0; w < 4; ++w) {                      // wave lists in wave order = token order: a fixed summation order
+        const int n = count[w];
+        for (int i = 0; i < n; ++i) {
+          const long long row = (long long)list[w][i] * E;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int c = tid + 256 * k;
+            if (c < E) {
+              if (TANH) {
+                const float y = out[row + c];
+                acc[r][k] += dout[row + c] * (1.0f - y * y);
+              } else {
+                acc[r][k] += dout[row + c];
+              }
             }
           }
         }
       }
+      __syncthreads();                                   // the lists are rewritten for the next row / round
     }
-    __syncthreads();                                     // the lists are rewritten in the next round
   }
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int c = tid + 256 * k;
-    if (c < E) dW[(long long)v * E + c] = acc[k];
+  for (int r = 0; r < EB_ROWS; ++r) {
+    if (r >= RV || v0 + r >= V) break;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = tid + 256 * k;
+      if (c < E) dW[(long long)(v0 + r) * E + c] = acc[r][k];
+    }
   }
+}
+
+static int embed_rows_per_wg(int V) {
+  int rv = (V + 2047) / 2048;
+  return rv < 1 ? 1 : (rv > EB_ROWS ? EB_ROWS : rv);
 }
 
 }  // namespace
@@ -111,7 +135,9 @@ int vqf_embed_tanh_bwd(const float* dout, const float* out, const long long* ids
   if (!dout || !out || !ids || !dW || T <= 0 || V <= 0 || E <= 0) return VQF_E_BADARG;
   if (E > 1024) return VQF_E_UNSUPPORTED;
   vqf_prof_dims(T, V, E);
-  VQF_LAUNCH(KID_EMBED_BWD, embed_bwd_kernel<true>, dim3(V), dim3(256), 0, (hipStream_t)stream, dout, out, ids, T, E, dW);
+  const int rv = embed_rows_per_wg(V);
+  VQF_LAUNCH(KID_EMBED_BWD, embed_bwd_kernel<true>, dim3((V + rv - 1) / rv), dim3(256), 0, (hipStream_t)stream, dout, out, ids, T, V, E,
+             rv, dW);
   return vqf_last_error();
 }
 
@@ -127,7 +153,9 @@ int vqf_embed_bwd(const float* dout, const long long* ids, int T, int V, int E, 
   if (E > 1024) return VQF_E_UNSUPPORTED;
   vqf_prof_dims(T, V, E);
   const float* none = nullptr;
-  VQF_LAUNCH(KID_EMBED_BWD, embed_bwd_kernel<false>, dim3(V), dim3(256), 0, (hipStream_t)stream, dout, none, ids, T, E, dW);
+  const int rv = embed_rows_per_wg(V);
+  VQF_LAUNCH(KID_EMBED_BWD, embed_bwd_kernel<false>, dim3((V + rv - 1) / rv), dim3(256), 0, (hipStream_t)stream, dout, none, ids, T, V,
+             E, rv, dW);
   return vqf_last_error();
 }
 

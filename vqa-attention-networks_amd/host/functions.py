@@ -355,7 +355,8 @@ def img_project(img, wi, bf16, cu_limit=0):
     img = _c(img)
     N, L, D = img.shape
     wi2 = _w2d(wi)
-    with ops.options(gemm_cu_limit=cu_limit if cu_limit else None):
+    # (no limit asked for: the option is left alone, so a limit the user set with ops.set_option / VQF_GEMM_CU_LIMIT applies)
+    with (ops.options(gemm_cu_limit=cu_limit) if cu_limit else ops.options()):
         if bf16:
             img2 = img.view(N * L, D) if img.dtype == torch.bfloat16 else ops.cast_bf16(img.view(N * L, D))
             wb = ops.cast_bf16(wi2)
@@ -385,7 +386,7 @@ class ImgProjLateFn(torch.autograd.Function):
     def backward(ctx, dP):
         img2, wi = ctx.saved_tensors
         dP = _c(dP)
-        with ops.options(gemm_cu_limit=ctx.cu_limit if ctx.cu_limit else None):
+        with (ops.options(gemm_cu_limit=ctx.cu_limit) if ctx.cu_limit else ops.options()):
             if img2.dtype == torch.bfloat16:
                 dPb = dP if dP.dtype == torch.bfloat16 else ops.cast_bf16(dP)
                 dwi = ops.gemm_bf16(dPb, img2, ta=True, tb=True).view_as(wi)
