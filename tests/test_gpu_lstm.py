@@ -186,7 +186,7 @@ def test_fused_lstm_step_is_bit_identical_to_product_plus_cell(B, H):
         if same_order:
             assert torch.equal(g1, g2) and torch.equal(c1, c2) and torch.equal(h1, h2)
         else:                                                   # (a split-K product re-associates the sum: rounding only)
-            assert _rel(g1, g2) <= 2e-6 and _rel(c1, c2) <= 2e-6 and _rel(h1, h2) <= 2e-6
+            assert _rel(g1, g2) <= 1e-5 and _rel(c1, c2) <= 1e-5 and _rel(h1, h2) <= 1e-5
     if B == 512 and H == 1024:
         assert same_order, "the headline shape's two-launch form is the per-wave kernel"
     fn = vqa_amd.functions.LstmBatchFn
