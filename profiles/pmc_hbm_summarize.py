@@ -24,7 +24,13 @@ ALG = {   # bytes one launch must move at the shapes of tools/hbm_kernels_one.py
     "att_logits_fwd_kernel": 4.0 * (ROWS * H + ROWS * 2),
     "att_logits_bwd_kernel": 4.0 * (2 * ROWS * H + ROWS * 2),
 }
-BENCH_NAME = {"mfb_fuse_fwd_kernel": "mfb_fuse_fwd", "mfb_fuse_bwd_kernel": "mfb_fuse_bwd", "scale_rows_kernel": "scale_rows",
+# csrc/hie.hip at BASELINE config 4's shapes (N = 256, L = 196, E = 512, T = 14; tools/hie_kernels_one.py): one (N*L, E) tensor in,
+# one out (mode 2 = rank_add reads and rewrites the same one), the per-sample (T, E) / (T, L) operands are noise
+HROWS, HE = 256 * 196, 512
+for _m in range(4):
+    ALG["hie_stream_kernel<%d>" % _m] = 4.0 * 2 * HROWS * HE
+BENCH_NAME = {"hie_stream_kernel<0>": "hie_hv_fwd", "hie_stream_kernel<1>": "hie_head_bwd", "hie_stream_kernel<2>": "hie_rank_add",
+              "hie_stream_kernel<3>": "hie_rank_left","mfb_fuse_fwd_kernel": "mfb_fuse_fwd", "mfb_fuse_bwd_kernel": "mfb_fuse_bwd", "scale_rows_kernel": "scale_rows",
               "rowdot_kernel": "rowdot", "glimpse_pool_fwd_kernel": "glimpse_pool_fwd", "glimpse_pool_bwd_kernel": "glimpse_pool_bwd",
               "att_logits_fwd_kernel": "att_logits_fwd", "att_logits_bwd_kernel": "att_logits_bwd"}
 
@@ -32,7 +38,7 @@ BENCH_NAME = {"mfb_fuse_fwd_kernel": "mfb_fuse_fwd", "mfb_fuse_bwd_kernel": "mfb
 def short(name):
     name = re.sub(r"\(anonymous namespace\)::", "", name)
     name = re.sub(r"^void ", "", name)
-    m = re.match(r"([A-Za-z0-9_]+)", name)
+    m = re.match(r"(hie_stream_kernel<\d>)", name) or re.match(r"([A-Za-z0-9_]+)", name)
     return m.group(1) if m else name
 
 
@@ -72,7 +78,7 @@ def main(src, out, label):
     json.dump(res, open(out + ".json", "w"), indent=1)
     with open(out + ".txt", "w") as f:
         f.write("# %s\n\n" % label)
-        f.write("`tools/profile_r03.sh hbm`: three separate `rocprofv3 --kernel-trace --pmc <group> -- python3 tools/hbm_kernels_one.py` passes\n"
+        f.write("`tools/profile_r0X.sh hbm|hie`: three separate `rocprofv3 --kernel-trace --pmc <group> -- python3 tools/hbm_kernels_one.py | hie_kernels_one.py` passes\n"
                 "(p2 = FETCH_SIZE ..., p3 = WRITE_SIZE TCC_HIT_sum TCC_MISS_sum), 3 launches per kernel at the headline shapes, means per dispatch.\n"
                 "traffic = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 correction; Infinity-Cache hits included); ms = median of the p2 pass.\n\n")
         f.write("| kernel | fetch GB | write GB | traffic GB | algorithmic GB | traffic / alg | L2 hit | scratch B/lane | ms (profiled) | GB/s (counter bytes) |\n|---|---|---|---|---|---|---|---|---|---|\n")

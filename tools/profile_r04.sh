@@ -1,6 +1,7 @@
 #!/bin/bash
 # rocprofv3 evidence of round 4 (run on the GPU box from the repo root).  PMC passes are separate runs with
 # --kernel-trace only (never combined with other trace domains); the program follows `--` directly.
+#   part "hie":   the same over the streaming passes of HieCoAtten's ladder (tools/hie_kernels_one.py)
 #   part "hbm":   three PMC passes over the HBM-bound kernels at the headline shapes (tools/hbm_kernels_one.py)
 #   part "trace": kernel trace + stats of the bench step (headline + secondary configs 3 and 4 in the same process)
 #   part "gemm":  three PMC passes over the dominant GEMM launches (tools/gemm_one.py)
@@ -25,6 +26,7 @@ pmc() {  # name, program args...
 for part in "$@"; do
   case $part in
     hbm)   pmc hbm $R/tools/hbm_kernels_one.py ;;
+    hie)   pmc hie $R/tools/hie_kernels_one.py ;;
     gemm)  pmc f32_fwd $R/tools/gemm_one.py --dtype f32 --shape fwd
            pmc f32_wgrad $R/tools/gemm_one.py --dtype f32 --shape wgrad
            pmc bf16_fwd $R/tools/gemm_one.py --dtype bf16 --shape fwd --out-bf16
