@@ -440,7 +440,9 @@ __device__ __forceinline__ void k_loop(const BigArgs& g, char* smem, int& slot, 
 // waves that share a SIMD (w and w + 4) sit in DIFFERENT column strips: in a short last column tile (N = 5000: 136 live
 // columns = 128 + 8) every SIMD then hosts one wave with 4 live column tiles and one with 1, instead of two SIMDs doing
 // all of the tile's work while the other two multiply clamped duplicates.
-template <bool TA, bool TB, int MODE>
+// SK: the stream-K tail (BigArgs::sk_*) is its own instantiation -- compiled into the regular one its work-item logic cost the
+// image projection 5 % (15.1 vs 14.3 ms, profiles/r04_big_ab.log)
+template <bool TA, bool TB, int MODE, bool SK = false>
 __global__ void __launch_bounds__(NT, 2) gemm_f32_big_kernel(const BigArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -465,7 +467,7 @@ __global__ void __launch_bounds__(NT, 2) gemm_f32_big_kernel(const BigArgs g) {
   // the longest workgroup).
   const int G = gridDim.x;
   const int ntiles1 = g.tiles_m * g.tiles_n_full;
-  const int F = g.sk_tail > 0 ? g.sk_fw : ntiles1 * g.splits;     // phase-1 items (stream-K: the whole rounds only)
+  const int F = (SK && g.sk_tail > 0) ? g.sk_fw : ntiles1 * g.splits;     // phase-1 items (stream-K: the whole rounds only)
   const int E = g.tiles_m * (g.tiles_n - g.tiles_n_full);   // phase-2 items
   int cur_w = blockIdx.x, cur_e;
   {
@@ -487,7 +489,7 @@ __global__ void __launch_bounds__(NT, 2) gemm_f32_big_kernel(const BigArgs g) {
   int slot = 0;                                        // ring slot of the current tile's slab 0, then of slab s
   auto next_item = [&]() -> bool {                     // locate the next work item, issue its first NSLOT-1 slabs
     int tm, tn;
-    frag_parts = 0;
+    if (SK) frag_parts = 0;
     if (cur_w < F) {
 #ifdef VQF_F32BIG_CLOCK
       w_dbg = cur_w;
@@ -510,7 +512,7 @@ __global__ void __launch_bounds__(NT, 2) gemm_f32_big_kernel(const BigArgs g) {
 #endif
       z = 0; tm = cur_e; tn = g.tiles_n - 1;
       cur_e += g.edge_wn;
-    } else if (g.sk_tail > 0) {
+    } else if (SK && g.sk_tail > 0) {
       // stream-K tail: the next fragment of this workgroup's current virtual worker, or the next virtual worker's first one
       const int Stile = (g.K + TK - 1) / TK, T = g.sk_tail * Stile;
       while (sk_it >= sk_end) {
@@ -550,7 +552,7 @@ __global__ void __launch_bounds__(NT, 2) gemm_f32_big_kernel(const BigArgs g) {
       S = (klen + TK - 1) / TK;                        // slabs of this split
       kt = klen - (S - 1) * TK;                        // k of the last slab (TK, or K % TK: only the last split can be short)
     }
-    if (frag_parts > 0) {                              // a stream-K fragment: slabs frag_k0 / TK .. of the tile
+    if (SK && frag_parts > 0) {                           // a stream-K fragment: slabs frag_k0 / TK .. of the tile
       kbeg = frag_k0;
       kt = frag_last ? kt : TK;
       S = frag_S;
@@ -599,7 +601,7 @@ __global__ void __launch_bounds__(NT, 2) gemm_f32_big_kernel(const BigArgs g) {
 #ifdef VQF_F32BIG_CLOCK
   const unsigned long long c2 = __builtin_amdgcn_s_memtime(), r2 = __builtin_amdgcn_s_memrealtime();
 #endif
-  if (frag_parts > 1) {
+  if (SK && frag_parts > 1) {
     // a stream-K fragment: the accumulators go to this tile's part image (a full 256 x 256 tile, pitch 256: no edge guards),
     // the tile's last-arriving fragment adds the parts up in part order and applies bias / ReLU (vqf_splitk_combine)
     float* img = g.sk_slab + ((size_t)frag_tile * 3 + frag_part) * (TM * TN);
@@ -727,6 +729,13 @@ int launch(const BigArgs& g_in, hipStream_t s) {
   const dim3 grid(nwg);
   BigArgs g = g_in;
   deal_edge_tiles(g, nwg);
+  if (g.sk_tail > 0) {                                 // stream-K tail: one loop form (the default one)
+    static VqfDynLdsFlags attr_sk = {};
+    if (int e = vqf_set_dyn_lds(reinterpret_cast<const void*>(&gemm_f32_big_kernel<TA, TB, VQF_F32BIG_DEFAULT_MODE, true>), SMEM_BIG, attr_sk))
+      return e;
+    VQF_LAUNCH(kid, (gemm_f32_big_kernel<TA, TB, VQF_F32BIG_DEFAULT_MODE, true>), grid, dim3(NT), SMEM_BIG, s, g);
+    return vqf_last_error();
+  }
   if (mode == 1) {
     if (int e = vqf_set_dyn_lds(reinterpret_cast<const void*>(&gemm_f32_big_kernel<TA, TB, 1>), SMEM_BIG, attr_pp)) return e;
     VQF_LAUNCH(kid, (gemm_f32_big_kernel<TA, TB, 1>), grid, dim3(NT), SMEM_BIG, s, g);
