@@ -18,6 +18,7 @@ for kv in filter(None, args.env.split(",")):
     os.environ[k] = v
 SH = {"fwd": (0, 0, 100352, 5000, 2048), "wgrad": (1, 1, 5000, 2048, 100352), "coatt_fwd": (0, 0, 100352, 1024, 1024),
       "coatt_dgrad": (0, 1, 100352, 1024, 1024), "sq": (0, 0, 8192, 8192, 8192),
+      "hie_fwd": (0, 0, 50176, 512, 2048), "hie_dgrad": (0, 1, 50176, 512, 1024), "hie_ci": (0, 0, 50176, 1024, 512),
       "coatt_wgrad": (1, 1, 1024, 1000, 100352), "coatt_wgrad512": (1, 1, 512, 1000, 100352)}
 dev = torch.device("cuda")
 bf = args.dtype == "bf16"

@@ -76,11 +76,16 @@ __global__ void att_logits_fwd_kernel(const float* __restrict__ hid, const float
 
 // ---- backward of the G-logit head, optionally through the ReLU in front of it ----------------
 // block = 256 threads, thread = 4 consecutive hidden columns (per 1024-column chunk); a block folds
-// LB_ROWS rows and writes one partial slab row of width (G+1)*Hh + 4:
+// `lb` rows (att_bwd_rows_per_block: 128 for the image grid's 100 352 rows; fewer for short inputs -- the question head's 7 168
+// rows as 56 blocks of 128 ran at 1 TB/s, 60 us; 448 blocks of 16: see DESIGN) and writes one partial slab row of width (G+1)*Hh + 4:
 //   part[b][g*Hh + j]      sum_m dl[m,g] * hid[m,j]            (g < G)
 //   part[b][G*Hh + j]      sum_m dhid_pre[m,j]
 //   part[b][(G+1)*Hh + g]  sum_m dl[m,g]
 constexpr int LB_ROWS = 128;
+inline int att_bwd_rows_per_block(int M) {            // a multiple of the kernel's 4-row trips, ~512 blocks or more when M allows
+  int lb = ((M / 512 + 3) / 4) * 4;
+  return lb < 16 ? 16 : (lb > LB_ROWS ? LB_ROWS : lb);
+}
 #ifndef VQF_ATT_BWD_ST_NT
 #define VQF_ATT_BWD_ST_NT 0    // 1: the hidden-layer gradient is stored non-temporal (A/B; measured 0.176-0.184 ms against 0.158-0.160 with plain stores)
 #endif
@@ -91,8 +96,8 @@ template <int G, bool RELU>
 __global__ void att_logits_bwd_kernel(const float* __restrict__ dl, const float* __restrict__ hid,
                                       const float* __restrict__ w2, int M, int Hh,
                                       float* __restrict__ dhid_pre, float* __restrict__ part,
-                                      const float* __restrict__ rowscale, int rps) {
-  const int r0 = blockIdx.x * LB_ROWS, r1 = min(M, r0 + LB_ROWS);
+                                      const float* __restrict__ rowscale, int rps, int lb) {
+  const int r0 = blockIdx.x * lb, r1 = min(M, r0 + lb);
   const int pw = (G + 1) * Hh + 4;
   float* prow = part + (long long)blockIdx.x * pw;
   const bool vec = ((Hh & 3) == 0) && aligned16_dev(hid) && aligned16_dev(dhid_pre);
@@ -392,7 +397,8 @@ int vqf_att_logits_fwd_lin(const float* hid, const float* w2, const float* b2, c
 
 size_t vqf_att_logits_bwd_ws_bytes(int M, int Hh) {
   if (M <= 0 || Hh <= 0) return 0;
-  return (size_t)((M + LB_ROWS - 1) / LB_ROWS + 1 + VQF_REDUCE_SPLITS) * (size_t)(3 * Hh + 4) * sizeof(float);
+  const int lb = att_bwd_rows_per_block(M);
+  return (size_t)((M + lb - 1) / lb + 1 + VQF_REDUCE_SPLITS) * (size_t)(3 * Hh + 4) * sizeof(float);
 }
 
 int vqf_att_logits_bwd(const float* dlogits, const float* hid, const float* w2, int M, int Hh, int G,
@@ -410,13 +416,14 @@ int vqf_att_logits_bwd_rowscale(const float* dlogits, const float* hid, const fl
   if (G != 1 && G != 2) return VQF_E_UNSUPPORTED;
   if (!ws || ws_bytes < vqf_att_logits_bwd_ws_bytes(M, Hh)) return VQF_E_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
-  const int nb = (M + LB_ROWS - 1) / LB_ROWS;
+  const int lb = att_bwd_rows_per_block(M);
+  const int nb = (M + lb - 1) / lb;
   const int pw = (G + 1) * Hh + 4;
   float* part = (float*)ws;
   float* red = part + (size_t)nb * pw;     // reduced row [pw]
 #define VQF_LB(G_, R_)                                                                           \
   VQF_LAUNCH(KID_ATT_LOGITS_BWD, (att_logits_bwd_kernel<G_, R_>), dim3(nb), dim3(256), 0, s,     \
-             dlogits, hid, w2, M, Hh, dhid_pre, part, rowscale, rows_per_scale)
+             dlogits, hid, w2, M, Hh, dhid_pre, part, rowscale, rows_per_scale, lb)
   if (G == 2) { if (relu_mask) VQF_LB(2, true); else VQF_LB(2, false); }
   else        { if (relu_mask) VQF_LB(1, true); else VQF_LB(1, false); }
 #undef VQF_LB

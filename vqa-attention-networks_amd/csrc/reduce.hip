@@ -6,8 +6,14 @@ namespace {
 
 constexpr int CS_ROWS = 256;   // rows folded by one colsum block ...
 // ... of the scalar kernel; the 16-byte kernels fold fewer rows per workgroup on tall tensors, so that a (50176, 512) tensor is
-// 784 workgroups, not 196 (one column tile wide: fewer workgroups than CUs)
-static inline int cs_rows_vec(int M) { return M > 16384 ? 64 : CS_ROWS; }
+// 784 workgroups, not 196 (one column tile wide: fewer workgroups than CUs), and fewer still on short ones: a (512, 5000) bias
+// gradient was 10 workgroups (15-24 us for 10 MB, five times per MFB step); ~512 workgroups when the tensor allows, >= 16 rows each
+static inline int cs_rows_vec(int M, int N) {
+  const long long tiles_c = (N / 4 + 255) / 256;
+  long long rpb = ((M * tiles_c / 512 + 7) / 8) * 8;
+  const int cap = M > 16384 ? 64 : CS_ROWS;
+  return (int)(rpb < 16 ? 16 : (rpb > cap ? cap : rpb));
+}
 
 // partial[b, c] = sum over rows [b*CS_ROWS, ...) of in[r, c];  thread = column
 __global__ void colsum_partial_kernel(const float* __restrict__ in, int M, int N, int ld,
@@ -284,7 +290,7 @@ extern "C" {
 
 size_t vqf_colsum_ws_bytes(int M, int N) {
   if (M <= 0 || N <= 0) return 0;
-  const int rpb = cs_rows_vec(M);
+  const int rpb = cs_rows_vec(M, N);
   return (size_t)((M + rpb - 1) / rpb + VQF_REDUCE_SPLITS) * (size_t)N * sizeof(float);
 }
 
@@ -301,7 +307,7 @@ int vqf_colsum_f32(const float* dY, int M, int N, int ldy, float* db, void* ws, 
   if (!ws || ws_bytes < vqf_colsum_ws_bytes(M, N)) return VQF_E_WORKSPACE;
   int nbv = nb;
   if ((N % 4) == 0 && (ldy % 4) == 0 && aligned16(dY) && aligned16(ws)) {      // 16-byte loads, eight rows in flight per thread
-    const int rpb = cs_rows_vec(M);
+    const int rpb = cs_rows_vec(M, N);
     nbv = (M + rpb - 1) / rpb;
     VQF_LAUNCH(KID_COLSUM, colsum_partial_vec_kernel, dim3((N / 4 + 255) / 256, nbv), dim3(256), 0, s, dY, M, N, ldy, rpb,
                (float*)ws);
@@ -340,7 +346,7 @@ int vqf_relu_bwd_rank1_f32(const float* dX, const float* Y, const float* wts, co
   if (C % 4) return VQF_E_UNSUPPORTED;
   if (!aligned16(dX) || !aligned16(Y) || !aligned16(dXpre) || (dpooled && !aligned16(dpooled))) return VQF_E_ALIGN;
   hipStream_t s = (hipStream_t)stream;
-  const int rpb = cs_rows_vec(M);
+  const int rpb = cs_rows_vec(M, C);
   const int nb = (M + rpb - 1) / rpb;
   float* partial = nullptr;
   if (dbias) {
