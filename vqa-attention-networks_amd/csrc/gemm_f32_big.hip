@@ -772,6 +772,12 @@ bool big_applies(int ta, int tb, int M, int N, int K, int flags, size_t ws_bytes
   // ... and the deep-K weight gradients (both operands K-major, few tiles, K = N*L): img_conv1d's 20 x 8 tiles x 8
   // splits of 784 slabs each, co_att_conv1's 4 x 4 tiles x 16 splits (one workgroup per CU, 392 slabs each).
   if (ta && tb && K >= 16384 && tiles * pick_splits(tiles, K, M, N, ws_bytes) >= F32BIG_WGRAD_MIN_BLOCKS) return true;   // needs its slabs
+  // ... and the LSTM's recurrent weight gradient (4096 x 1024 x 7168: 64 tiles x 4 splits; 447 us against 483-522 on the 128x128
+  // kernel, tools/gemm_m512_probe.py) -- K-major products with 4096 <= K < 16384 whose splits fill a round and whose last column
+  // tile is not mostly dead (N = 300, the input-weight gradient, stays: 225 vs 204 us)
+  if (ta && tb && K >= 4096 && ((N + TN - 1) / TN) * TN * 100LL <= (long long)N * 107 &&
+      tiles * pick_splits(tiles, K, M, N, ws_bytes) >= F32BIG_WGRAD_MIN_BLOCKS)
+    return true;
   return false;
 }
 
