@@ -80,7 +80,8 @@ def test_library_options_are_explicit_and_restorable(vqa):
 
 def test_workspace_size_queries_need_no_gpu(vqa):
     lib = vqa.lib.load()
-    assert lib.vqf_colsum_ws_bytes(1000, 512) == (4 + 32) * 512 * 4
+    assert lib.vqf_colsum_ws_bytes(1000, 512) == (63 + 32) * 512 * 4       # 16 rows per workgroup on a short tensor (reduce.hip cs_rows_vec)
+    assert lib.vqf_colsum_ws_bytes(100352, 512) == (1568 + 32) * 512 * 4   # 64 on a tall one
     assert lib.vqf_mfb_fuse_bwd_ws_bytes(512, 196, 1000) == (2 * 512 * 4 + 32) * 5000 * 4
     assert lib.vqf_att_logits_bwd_ws_bytes(100352, 1024) > 0
     assert lib.vqf_colsum_ws_bytes(0, 5) == 0
