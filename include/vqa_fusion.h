@@ -455,6 +455,11 @@ int vqf_embed_tanh_bwd(const float* dout, const float* out, const long long* ids
 /* the plain lookup e = Embedding(q) and its weight gradient (hieCoAtten.py:27, networks.py:23,56, mhb_coAtt.py:181) */
 int vqf_embed_fwd(const float* W, const long long* ids, int T, int V, int E, float* out, void* stream);
 int vqf_embed_bwd(const float* dout, const long long* ids, int T, int V, int E, float* dW, void* stream);
+/* time-major forms: ids (N, Tq) as the reference holds them (mfb.py:68), out / dout rows ordered (Tq, N) -- the layout the
+ * batch-major LSTM consumes (mfb.py:69 with batch_first=True == T steps of the N-row batch): no transposing copy in between */
+int vqf_embed_tanh_fwd_tm(const float* W, const long long* ids, int N, int Tq, int V, int E, float* out, void* stream);
+int vqf_embed_tanh_bwd_tm(const float* dout, const float* out, const long long* ids, int N, int Tq, int V, int E, float* dW,
+                          void* stream);
 
 /* --------------------------------------------------------------------------
  * Input staging.  data_loader.py:30-32 loads one [2048,14,14] .npy per image

@@ -469,6 +469,34 @@ def test_embed_tanh_module_path_matches_torch_embedding(ops):
     assert not type(fns.embed_tanh(pad, q).grad_fn).__name__.startswith("EmbedTanhFn")
 
 
+def test_embed_tanh_time_major_form(ops):
+    """vqf_embed_tanh_fwd_tm / _bwd_tm: ids (N,Tq) as the reference holds them, output rows in (Tq,N) order -- bitwise the
+    batch-major lookup transposed; the weight gradient vs torch in fp64 (its token order differs from the batch-major form's, so
+    only the rounding may); functions.embed_tanh(time_major=True) end to end."""
+    import vqa_amd
+    fns = vqa_amd.functions
+    g = torch.Generator().manual_seed(43)
+    N, Tq, V, E = 37, 14, 50, 300
+    W = torch.randn((V, E), generator=g).cuda()
+    ids = torch.randint(0, V, (N, Tq), generator=g).cuda()
+    out_tm = ops.embed_tanh_fwd(W, ids, True, time_major=True)
+    assert out_tm.shape == (Tq, N, E)
+    assert torch.equal(out_tm, ops.embed_tanh_fwd(W, ids).transpose(0, 1).contiguous())
+    dout = torch.randn((Tq, N, E), generator=g).cuda()
+    dW = ops.embed_tanh_bwd(dout, out_tm, ids, V, time_major=True)
+    W64 = W.double().cpu().requires_grad_(True)
+    torch.tanh(torch.nn.functional.embedding(ids.cpu(), W64)).backward(dout.transpose(0, 1).double().cpu())
+    assert _rel(dW, W64.grad) <= 2e-6 and torch.equal(dW, ops.embed_tanh_bwd(dout, out_tm, ids, V, time_major=True))
+    emb = torch.nn.Embedding(V, E).cuda()
+    y = fns.embed_tanh(emb, ids, time_major=True)
+    y.backward(dout)
+    g_hip, emb.weight.grad = emb.weight.grad.clone(), None
+    torch.tanh(emb(ids)).transpose(0, 1).backward(dout)
+    assert _rel(g_hip, emb.weight.grad.double().cpu()) <= 2e-6
+    pad = torch.nn.Embedding(V, E, padding_idx=0).cuda()                 # torch fallback keeps the layout contract
+    assert fns.embed_tanh(pad, ids, time_major=True).shape == (Tq, N, E)
+
+
 def test_embed_plain_lookup_is_exact(ops):
     """functions.embed (hieCoAtten.py:27, networks.py:23,56, mhb_coAtt.py:181): the lookup is a copy (bitwise torch's); the weight
     gradient is the token-ordered segment sum, vs torch in fp64, and bit-reproducible."""

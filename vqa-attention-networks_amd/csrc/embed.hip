@@ -16,13 +16,19 @@
 
 namespace {
 
+// Time-major form (swapN = N > 0): ids are stored (N, Tq) as the reference holds them, the rows of out / dout are ordered
+// (Tq, N) -- what the batch-major LSTM consumes (mfb.py:68-69), so no transposing copy sits between the lookup and the recursion.
+__device__ __forceinline__ int tok_of_row(int t, int T, int swapN) {
+  return swapN > 0 ? (t % swapN) * (T / swapN) + t / swapN : t;
+}
+
 template <bool TANH>
 __global__ void embed_fwd_kernel(const float* __restrict__ W, const long long* __restrict__ ids, int T, int V, int E,
-                                      float* __restrict__ out) {
+                                      float* __restrict__ out, int swapN) {
   const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (t >= T) return;
   const int lane = threadIdx.x & 63;
-  const long long id = ids[t];
+  const long long id = ids[tok_of_row(t, T, swapN)];
   const bool ok = id >= 0 && id < V;
   const float* w = W + (ok ? id : 0) * (long long)E;
   float* o = out + (long long)t * E;
@@ -48,7 +54,7 @@ constexpr int EB_ROWS = 16;        // vocabulary rows per workgroup, at most
 template <bool TANH>
 __global__ void __launch_bounds__(256) embed_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
                                                             const long long* __restrict__ ids, int T, int V, int E, int RV,
-                                                            float* __restrict__ dW) {
+                                                            float* __restrict__ dW, int swapN) {
   __shared__ int list[4][EB_CHUNK / 4];
   __shared__ int count[4];
   const int v0 = blockIdx.x * RV, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -64,7 +70,7 @@ __global__ void __launch_bounds__(256) embed_bwd_kernel(const float* __restrict_
 #pragma unroll
     for (int q = 0; q < EB_CHUNK / 4 / 64; ++q) {        // the 8 id loads of a wave are issued together, once per round
       const int t = b0 + 64 * q + lane;
-      idv[q] = t < T ? ids[t] : -1;
+      idv[q] = t < T ? ids[tok_of_row(t, T, swapN)] : -1;
     }
 #pragma unroll
     for (int r = 0; r < EB_ROWS; ++r) {
@@ -126,7 +132,7 @@ extern "C" {
 int vqf_embed_tanh_fwd(const float* W, const long long* ids, int T, int V, int E, float* out, void* stream) {
   if (!W || !ids || !out || T <= 0 || V <= 0 || E <= 0) return VQF_E_BADARG;
   vqf_prof_dims(T, V, E);
-  VQF_LAUNCH(KID_EMBED_FWD, embed_fwd_kernel<true>, dim3((T + 3) / 4), dim3(256), 0, (hipStream_t)stream, W, ids, T, V, E, out);
+  VQF_LAUNCH(KID_EMBED_FWD, embed_fwd_kernel<true>, dim3((T + 3) / 4), dim3(256), 0, (hipStream_t)stream, W, ids, T, V, E, out, 0);
   return vqf_last_error();
 }
 
@@ -137,14 +143,14 @@ int vqf_embed_tanh_bwd(const float* dout, const float* out, const long long* ids
   vqf_prof_dims(T, V, E);
   const int rv = embed_rows_per_wg(V);
   VQF_LAUNCH(KID_EMBED_BWD, embed_bwd_kernel<true>, dim3((V + rv - 1) / rv), dim3(256), 0, (hipStream_t)stream, dout, out, ids, T, V, E,
-             rv, dW);
+             rv, dW, 0);
   return vqf_last_error();
 }
 
 int vqf_embed_fwd(const float* W, const long long* ids, int T, int V, int E, float* out, void* stream) {
   if (!W || !ids || !out || T <= 0 || V <= 0 || E <= 0) return VQF_E_BADARG;
   vqf_prof_dims(T, V, E);
-  VQF_LAUNCH(KID_EMBED_FWD, embed_fwd_kernel<false>, dim3((T + 3) / 4), dim3(256), 0, (hipStream_t)stream, W, ids, T, V, E, out);
+  VQF_LAUNCH(KID_EMBED_FWD, embed_fwd_kernel<false>, dim3((T + 3) / 4), dim3(256), 0, (hipStream_t)stream, W, ids, T, V, E, out, 0);
   return vqf_last_error();
 }
 
@@ -155,7 +161,28 @@ int vqf_embed_bwd(const float* dout, const long long* ids, int T, int V, int E, 
   const float* none = nullptr;
   const int rv = embed_rows_per_wg(V);
   VQF_LAUNCH(KID_EMBED_BWD, embed_bwd_kernel<false>, dim3((V + rv - 1) / rv), dim3(256), 0, (hipStream_t)stream, dout, none, ids, T, V,
-             E, rv, dW);
+             E, rv, dW, 0);
+  return vqf_last_error();
+}
+
+// time-major forms: ids (N, Tq) int64, out / dout rows ordered (Tq, N)
+int vqf_embed_tanh_fwd_tm(const float* W, const long long* ids, int N, int Tq, int V, int E, float* out, void* stream) {
+  if (!W || !ids || !out || N <= 0 || Tq <= 0 || V <= 0 || E <= 0) return VQF_E_BADARG;
+  const int T = N * Tq;
+  vqf_prof_dims(T, V, E);
+  VQF_LAUNCH(KID_EMBED_FWD, embed_fwd_kernel<true>, dim3((T + 3) / 4), dim3(256), 0, (hipStream_t)stream, W, ids, T, V, E, out, N);
+  return vqf_last_error();
+}
+
+int vqf_embed_tanh_bwd_tm(const float* dout, const float* out, const long long* ids, int N, int Tq, int V, int E, float* dW,
+                          void* stream) {
+  if (!dout || !out || !ids || !dW || N <= 0 || Tq <= 0 || V <= 0 || E <= 0) return VQF_E_BADARG;
+  if (E > 1024) return VQF_E_UNSUPPORTED;
+  const int T = N * Tq;
+  vqf_prof_dims(T, V, E);
+  const int rv = embed_rows_per_wg(V);
+  VQF_LAUNCH(KID_EMBED_BWD, embed_bwd_kernel<true>, dim3((V + rv - 1) / rv), dim3(256), 0, (hipStream_t)stream, dout, out, ids, T, V, E,
+             rv, dW, N);
   return vqf_last_error();
 }
 

@@ -32,17 +32,17 @@ class EmbedTanhFn(torch.autograd.Function):
     deterministic one-launch weight gradient (csrc/embed.hip) instead of torch's sort-based embedding backward."""
 
     @staticmethod
-    def forward(ctx, ids, weight, tanh=True):
+    def forward(ctx, ids, weight, tanh=True, time_major=False):
         ids = ids.contiguous()
-        out = ops.embed_tanh_fwd(_c(weight), ids, tanh)
+        out = ops.embed_tanh_fwd(_c(weight), ids, tanh, time_major)
         ctx.save_for_backward(ids, out if tanh else None)
-        ctx.V = weight.shape[0]
+        ctx.V, ctx.tm = weight.shape[0], bool(time_major)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         ids, out = ctx.saved_tensors
-        return None, ops.embed_tanh_bwd(_c(dout), out, ids, ctx.V), None
+        return None, ops.embed_tanh_bwd(_c(dout), out, ids, ctx.V, ctx.tm), None, None
 
 
 def _plain_embedding(embedding, ids):
@@ -51,12 +51,14 @@ def _plain_embedding(embedding, ids):
             and embedding.max_norm is None and not embedding.sparse and not embedding.scale_grad_by_freq and w.shape[1] <= 1024)
 
 
-def embed_tanh(embedding, ids):
+def embed_tanh(embedding, ids, time_major=False):
     """tanh(embedding(ids)) on the HIP path when the nn.Embedding is a plain lookup (no padding_idx / max_norm / sparse grads /
-    frequency scaling) with an fp32 GPU weight of width <= 1024; torch otherwise."""
+    frequency scaling) with an fp32 GPU weight of width <= 1024; torch otherwise.  time_major: ids (N,Tq) -> (Tq,N,E), the layout
+    the batch-major LSTM consumes (the lookup writes it directly: no transposing copy)."""
     if _plain_embedding(embedding, ids):
-        return EmbedTanhFn.apply(ids, embedding.weight, True)
-    return torch.tanh(embedding(ids))
+        return EmbedTanhFn.apply(ids, embedding.weight, True, bool(time_major) and ids.dim() == 2)
+    y = torch.tanh(embedding(ids))
+    return y.transpose(0, 1).contiguous() if time_major and ids.dim() == 2 else y
 
 
 def embed(embedding, ids):
@@ -143,6 +145,10 @@ class AttHeadFn(torch.autograd.Function):
         x = _c(x)
         feat = _c(feat)
         ctx.bf16 = bool(bf16)
+        # the question head pools the very tensor its MLP reads (x is a view of feat, mfb.py:73-89): its backward then adds the MLP's
+        # input gradient onto the pooling's in the GEMM epilogue instead of leaving two gradients for autograd to add
+        ctx.same_src = (x.data_ptr() == feat.data_ptr() and x.numel() == feat.numel() and x.shape[-1] == feat.shape[-1]
+                        and x.dtype == feat.dtype)
         ctx.link = link if (link is not None and link.inv is not None) else None
         if ctx.link is not None:
             # x is the UN-NORMALISED fusion output: 1/norm of the sample goes into the conv GEMM's epilogue, and the logit
@@ -219,7 +225,11 @@ class AttHeadFn(torch.autograd.Function):
                 dx = ops.gemm_bf16(d1b, w1b, tb=True, N=cin)
         else:
             dw1 = ops.gemm(d1_pre, x, ta=True, tb=True).view_as(w1)
-            dx = ops.gemm(d1_pre, _w2d(w1), tb=True) if ctx.needs_input_grad[0] else None
+            if ctx.same_src and dfeat is not None and ctx.needs_input_grad[0]:
+                ops.gemm(d1_pre, _w2d(w1), tb=True, out=dfeat.view(x.shape), accumulate=True)     # dfeat += dx: one gradient for the shared source
+                dx = None
+            else:
+                dx = ops.gemm(d1_pre, _w2d(w1), tb=True) if ctx.needs_input_grad[0] else None
         return dx, dfeat, dw1, db1, dwm, dbm, dw2.view_as(w2), db2, None, None, None
 
 
@@ -769,6 +779,28 @@ class LogSoftmaxRowsFn(torch.autograd.Function):
         return ops.log_softmax_rows_bwd(_c(dy), y)
 
 
+def _bias_sum(b_ih, b_hh):
+    """b_ih + b_hh of an nn.LSTM (one library launch; torch for anything the launch does not take)"""
+    if b_ih is None:
+        return None
+    if b_ih.is_cuda and b_ih.dtype == torch.float32 and b_ih.is_contiguous() and b_hh.is_contiguous():
+        out = torch.empty_like(b_ih)
+        ops.multi_add([(b_ih.detach(), b_hh.detach(), out)])
+        return out
+    return b_ih + b_hh
+
+
+def _copy_of(t):
+    """a second tensor with t's values (b_hh's gradient beside b_ih's), one library launch"""
+    if t is None:
+        return None
+    if t.is_cuda and t.dtype == torch.float32 and t.is_contiguous():
+        out = torch.empty_like(t)
+        ops.multi_copy([(t, out)])
+        return out
+    return t.clone()
+
+
 def _lstm_in_proj(x2, w_ih, bias, bf16_proj):
     """Input projection of a whole sequence, x2 (S*B, I) @ w_ih^T (+ b_ih + b_hh).  bf16_proj (gemm_dtype "bf16-all"):
     bf16 operands, columns zero-padded to a multiple of 8 by the cast (I = 300 -> 304); returns the casts for the
@@ -798,7 +830,7 @@ class LstmSeqFn(torch.autograd.Function):
         x = _c(x)
         S, B, I = x.shape
         H = w_hh.shape[1]
-        bias = (b_ih + b_hh) if b_ih is not None else None
+        bias = _bias_sum(b_ih, b_hh)
         ctx.bf16 = bool(bf16)          # bf16 operands in the recurrent product (bf16 modes)
         ctx.bf16_proj = bf16 == "all" and H % 8 == 0       # "bf16-all": also in the input projection and its gradients
         xw, xb, wb = _lstm_in_proj(x.view(S * B, I), w_ih, bias, ctx.bf16_proj)
@@ -830,7 +862,7 @@ class LstmSeqFn(torch.autograd.Function):
         else:
             dw_hh = torch.zeros_like(w_hh)
         db = ops.colsum(dg2) if ctx.has_bias else None
-        return dx, dw_ih, dw_hh, db, (db.clone() if db is not None else None), None
+        return dx, dw_ih, dw_hh, db, _copy_of(db), None
 
 
 class LstmBatchFn(torch.autograd.Function):
@@ -848,7 +880,7 @@ class LstmBatchFn(torch.autograd.Function):
         x = _c(x)
         T, B, I = x.shape
         H = w_hh.shape[1]
-        bias = (b_ih + b_hh) if b_ih is not None else None
+        bias = _bias_sum(b_ih, b_hh)
         ctx.bf16 = bool(bf16) and H % 8 == 0
         ctx.bf16_proj = ctx.bf16 and bf16 == "all"          # "bf16-all": input projection and every weight gradient too
         whh = ops.cast_bf16(_c(w_hh)) if ctx.bf16 else _c(w_hh)
@@ -900,7 +932,7 @@ class LstmBatchFn(torch.autograd.Function):
         else:
             dw_hh = torch.zeros_like(w_hh)
         db = ops.colsum(dG2) if ctx.has_bias else None
-        return dx, dw_ih, dw_hh, db, (db.clone() if db is not None else None), None
+        return dx, dw_ih, dw_hh, db, _copy_of(db), None
 
 
 class UnitPoolFn(torch.autograd.Function):

@@ -107,6 +107,8 @@ SIGNATURES = {
     "vqf_embed_tanh_bwd": (c_i, [c_f, c_f, c_p, c_i, c_i, c_i, c_f, c_p]),
     "vqf_embed_fwd": (c_i, [c_f, c_p, c_i, c_i, c_i, c_f, c_p]),
     "vqf_embed_bwd": (c_i, [c_f, c_p, c_i, c_i, c_i, c_f, c_p]),
+    "vqf_embed_tanh_fwd_tm": (c_i, [c_f, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),
+    "vqf_embed_tanh_bwd_tm": (c_i, [c_f, c_f, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),
     "vqf_feat_transpose": (c_i, [c_f, c_i, c_i, c_i, c_i, c_p, c_p]),
     "vqf_loss_ws_bytes": (c_sz, [c_i, c_i]),
     "vqf_ce_loss": (c_i, [c_f, c_p, c_i, c_i, c_f, c_f, c_p, c_sz, c_p]),

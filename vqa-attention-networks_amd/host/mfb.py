@@ -53,16 +53,23 @@ def _lstm_bf16(gemm_dtype):
     return "all" if gemm_dtype == "bf16-all" else gemm_dtype == "bf16"
 
 
-def batch_first_lstm(lstm, x, use_hip=True, bf16=False):
+def hip_batch_lstm_ok(lstm, x_is_cuda_fp32, use_hip=True):
+    """whether batch_first_lstm runs the recursion on the HIP path (functions.LstmBatchFn)"""
+    return bool(use_hip and x_is_cuda_fp32 and lstm.num_layers == 1 and not lstm.bidirectional and lstm.proj_size == 0
+                and lstm.hidden_size % 4 == 0)
+
+
+def batch_first_lstm(lstm, x, use_hip=True, bf16=False, time_major_in=False):
     """nn.LSTM(batch_first=True) forward of x (N,T,E) -> (N,T,H) with zero initial state (mfb.py:69).  The
     recursion runs on the HIP path (MFMA GEMMs + one point-wise kernel per step, functions.LstmBatchFn) with
     the nn.LSTM module's own parameters; anything it does not cover (several layers, bidirectional,
-    projections) stays on nn.LSTM."""
-    if (use_hip and x.is_cuda and lstm.num_layers == 1 and not lstm.bidirectional and lstm.proj_size == 0
-            and lstm.hidden_size % 4 == 0 and x.dtype == torch.float32):
-        hs = LstmBatchFn.apply(x.transpose(0, 1).contiguous(), lstm.weight_ih_l0, lstm.weight_hh_l0,
+    projections) stays on nn.LSTM.  time_major_in: x arrives as (T,N,E) (embed_tanh(time_major=True))."""
+    if hip_batch_lstm_ok(lstm, x.is_cuda and x.dtype == torch.float32, use_hip):
+        hs = LstmBatchFn.apply(x if time_major_in else x.transpose(0, 1).contiguous(), lstm.weight_ih_l0, lstm.weight_hh_l0,
                                lstm.bias_ih_l0 if lstm.bias else None, lstm.bias_hh_l0 if lstm.bias else None, bf16)
         return hs.transpose(0, 1)
+    if time_major_in:
+        x = x.transpose(0, 1).contiguous()
     if use_hip:
         warn_once("lstm_batch", "question-encoder LSTM runs on nn.LSTM (MIOpen), not on the HIP LstmBatchFn: it needs "
                   "a GPU fp32 input, one layer, unidirectional, no projection, hidden_size %% 4 == 0 (got layers=%d, "
@@ -241,8 +248,11 @@ class MFB(nn.Module):
         proj = self._side.project(img_features, self.img_conv1d, bf16_img,
                                   self.overlap_streams == "same-stream", self.side_cu_limit) if side else None
         # a2: question encoder                                               mfb.py:68-70
-        que_embedded = embed_tanh(self.word_embedding, questions)
-        lstm_o = batch_first_lstm(self.lstm, que_embedded, self.use_hip_lstm, _lstm_bf16(self.gemm_dtype))
+        # (the lookup writes (T,N,E) directly when the recursion runs on the HIP path: no transposing copy in between)
+        tm = questions.dim() == 2 and hip_batch_lstm_ok(self.lstm, questions.is_cuda and self.word_embedding.weight.dtype == torch.float32,
+                                                        self.use_hip_lstm)
+        que_embedded = embed_tanh(self.word_embedding, questions, time_major=tm)
+        lstm_o = batch_first_lstm(self.lstm, que_embedded, self.use_hip_lstm, _lstm_bf16(self.gemm_dtype), time_major_in=tm)
         ques_feature = lstm_out_dropout(self.dropout_l, lstm_o, self._seeds)   # (N,T,H) contiguous; mfb.py:70
         N, T, H = ques_feature.shape
         L = img_features.shape[1]

@@ -449,6 +449,18 @@ def relu_bwd_rank1(dx, y, wts, dpooled, L, scale, want_bias=True, out=None):
     return dpre, db
 
 
+def scale_by_device_scalar(x, s):
+    """x (M,W) fp32 times the one-element GPU tensor s (a loss's incoming gradient), no host read: vqf_scale_rows with one scale
+    for all rows"""
+    _chk(x, s)
+    if x.dim() != 2 or s.numel() != 1:
+        raise _l.VqfError("scale_by_device_scalar: (M,W) tensor and a one-element scale expected")
+    M, W = x.shape
+    out = torch.empty_like(x)
+    _l.check(_lib().vqf_scale_rows(_ptr(x), _ptr(s), M, M, W, _ptr(out), _stream()), "vqf_scale_rows")
+    return out
+
+
 def _ptr_array(ts):
     return (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
 
@@ -732,24 +744,39 @@ def _chk_ids(ids):
         raise _l.VqfError("contiguous int64 GPU token ids expected")
 
 
-def embed_tanh_fwd(weight, ids, tanh=True):
-    """tanh(weight[ids]) (tanh=False: weight[ids]): weight (V,E) fp32, ids any shape int64 -> ids.shape + (E,)"""
+def embed_tanh_fwd(weight, ids, tanh=True, time_major=False):
+    """tanh(weight[ids]) (tanh=False: weight[ids]): weight (V,E) fp32, ids any shape int64 -> ids.shape + (E,);
+    time_major (ids (N,Tq), tanh only): -> (Tq, N, E), the rows in the order the batch-major LSTM walks them"""
     _chk(weight)
     _chk_ids(ids)
     V, E = weight.shape
     T = ids.numel()
+    if time_major:
+        if not tanh or ids.dim() != 2:
+            raise _l.VqfError("embed_tanh_fwd: the time-major form takes (N, Tq) ids and applies tanh")
+        N, Tq = ids.shape
+        out = torch.empty((Tq, N, E), dtype=torch.float32, device=weight.device)
+        _l.check(_lib().vqf_embed_tanh_fwd_tm(_ptr(weight), ctypes.c_void_p(ids.data_ptr()), N, Tq, V, E, _ptr(out), _stream()),
+                 "vqf_embed_tanh_fwd_tm")
+        return out
     out = torch.empty(tuple(ids.shape) + (E,), dtype=torch.float32, device=weight.device)
     fn = _lib().vqf_embed_tanh_fwd if tanh else _lib().vqf_embed_fwd
     _l.check(fn(_ptr(weight), ctypes.c_void_p(ids.data_ptr()), T, V, E, _ptr(out), _stream()), "vqf_embed_fwd")
     return out
 
 
-def embed_tanh_bwd(dout, out, ids, V):
-    """-> dW (V,E): deterministic segment sum of dout * (1 - out^2) over the tokens of each id (out=None: of dout, the plain lookup)"""
+def embed_tanh_bwd(dout, out, ids, V, time_major=False):
+    """-> dW (V,E): deterministic segment sum of dout * (1 - out^2) over the tokens of each id (out=None: of dout, the plain lookup);
+    time_major: dout / out are (Tq, N, E) for ids (N, Tq)"""
     _chk(dout, out)
     _chk_ids(ids)
     E = dout.shape[-1]
     dW = torch.empty((V, E), dtype=torch.float32, device=dout.device)
+    if time_major:
+        N, Tq = ids.shape
+        _l.check(_lib().vqf_embed_tanh_bwd_tm(_ptr(dout), _ptr(out), ctypes.c_void_p(ids.data_ptr()), N, Tq, V, E, _ptr(dW),
+                                              _stream()), "vqf_embed_tanh_bwd_tm")
+        return dW
     if out is None:
         _l.check(_lib().vqf_embed_bwd(_ptr(dout), ctypes.c_void_p(ids.data_ptr()), ids.numel(), V, E, _ptr(dW), _stream()),
                  "vqf_embed_bwd")

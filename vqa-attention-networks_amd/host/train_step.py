@@ -13,6 +13,13 @@ from torch import nn
 from . import ops
 
 
+def _times(d, g):
+    """d (N,A) * g, g = the scalar gradient arriving at the loss (loss.backward(): a one-element GPU tensor)"""
+    if g.is_cuda and g.dtype == torch.float32 and g.numel() == 1 and d.dim() == 2 and d.is_contiguous():
+        return ops.scale_by_device_scalar(d, g.reshape(1))
+    return d * g
+
+
 class _CeLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, target):
@@ -23,7 +30,7 @@ class _CeLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (d,) = ctx.saved_tensors
-        return d * g, None
+        return _times(d, g), None
 
 
 class _KlDivLossFn(torch.autograd.Function):
@@ -36,7 +43,7 @@ class _KlDivLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (d,) = ctx.saved_tensors
-        return d * g, None
+        return _times(d, g), None
 
 
 class CrossEntropyLoss(nn.Module):
