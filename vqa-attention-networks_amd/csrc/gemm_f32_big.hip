@@ -659,7 +659,7 @@ int pick_splits(int tiles, int K, int M, int N, size_t ws_bytes) {
   if (tiles >= 768) return 1;
   int best = 1;
   double best_cost = 1e30;
-  for (int sp = 1; sp <= 16; ++sp) {
+  for (int sp = 1; sp <= 32; ++sp) {      // (up to 32: HieCoAtten's 1024 x 512 x 50176 weight gradient is 8 tiles -- 32 slices of 49 slabs fill a round)
     if (sp > 1 && (size_t)sp * M * N * sizeof(float) > ws_bytes) break;
     if (sp > 1 && K / sp < 16 * TK) break;
     const long long blocks = (long long)tiles * sp;

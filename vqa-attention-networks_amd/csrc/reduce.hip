@@ -300,7 +300,10 @@ int vqf_colsum_f32(const float* dY, int M, int N, int ldy, float* db, void* ws, 
   hipStream_t s = (hipStream_t)stream;
   const int nb = (M + CS_ROWS - 1) / CS_ROWS;
   dim3 grid((N + 255) / 256, nb);
-  if (nb == 1) {
+  // (one block of rows: the column-per-thread kernel straight into db -- unless the 16-byte form can spread a tall-enough tensor
+  //  over more workgroups: a (256, 1000) logit gradient was 4 workgroups walking 256 rows each, 20 us)
+  const bool vec_ok = (N % 4) == 0 && (ldy % 4) == 0 && aligned16(dY) && ws && aligned16(ws) && ws_bytes >= vqf_colsum_ws_bytes(M, N);
+  if (nb == 1 && !(vec_ok && M >= 64)) {
     VQF_LAUNCH(KID_COLSUM, colsum_partial_kernel, grid, dim3(256), 0, s, dY, M, N, ldy, db);
     return vqf_last_error();
   }
