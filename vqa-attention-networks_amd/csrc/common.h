@@ -136,6 +136,16 @@ static inline int vqf_cu_count() {
   return n;
 }
 
+// tanh for the streaming kernels that were VALU-bound on libm's tanhf (hie.hip's fused tanh + Philox pass: 2 TB/s): one v_exp_f32 and
+// one v_rcp_f32, tanh(x) = (e - 1) / (e + 1) with e = exp(2x); e - 1 is exact for e in [1/2, 2], so the absolute error stays at the
+// exponential's (~1e-7) down to x = 0 (libm's tanhf: 1 ulp relative); e -> 0 gives -1, a huge e is cut off at +1 before inf * 0.
+// NOT used where a chain of steps feeds on the value (LSTM cells, the embedding's tanh keep tanhf).
+__device__ __forceinline__ float vqf_tanh_fast(float x) {
+  const float e = __expf(2.0f * x);
+  const float r = __builtin_amdgcn_rcpf(e + 1.0f);
+  return e > 16777216.0f ? 1.0f : (e - 1.0f) * r;      // (inf - 1) * 0 would be NaN
+}
+
 // ---- device helpers -------------------------------------------------------
 // Loads / stores of ONCE-touched streams (the projection P and its gradient in the fusion kernels, the image grid in the glimpse
 // pools, the hidden layer in the attention-logit kernels): VQF_STREAM_NT = 1 issues them non-temporal, so that the streamed

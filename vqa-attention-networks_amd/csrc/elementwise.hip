@@ -44,12 +44,12 @@ __global__ void ew_kernel(const float* __restrict__ a, const float* __restrict__
     } else if (MODE == 1) {
       if (b) x += *reinterpret_cast<const f32x4*>(b + 4 * i);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) y[j] = tanhf(x[j]) * sc[j];
+      for (int j = 0; j < 4; ++j) y[j] = vqf_tanh_fast(x[j]) * sc[j];
     } else {
       const f32x4 yy = *reinterpret_cast<const f32x4*>(b + 4 * i);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float t = sc[j] > 0.f ? yy[j] / sc[j] : 0.f;
+        const float t = sc[j] > 0.f ? yy[j] * (1.0f / inv_keep) : 0.f;
         y[j] = x[j] * sc[j] * (1.0f - t * t);
       }
     }
@@ -78,12 +78,12 @@ __global__ void ew2d_kernel(const float* __restrict__ a, int lda, const float* _
     } else if (MODE == 1) {
       if (b) x += *reinterpret_cast<const f32x4*>(b + (long long)r * ldb + 4 * c4);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) y[j] = tanhf(x[j]) * sc[j];
+      for (int j = 0; j < 4; ++j) y[j] = vqf_tanh_fast(x[j]) * sc[j];
     } else {
       const f32x4 yy = *reinterpret_cast<const f32x4*>(b + (long long)r * ldb + 4 * c4);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float t = sc[j] > 0.f ? yy[j] / sc[j] : 0.f;
+        const float t = sc[j] > 0.f ? yy[j] * (1.0f / inv_keep) : 0.f;
         y[j] = x[j] * sc[j] * (1.0f - t * t);
       }
     }

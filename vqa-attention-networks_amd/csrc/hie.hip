@@ -102,13 +102,14 @@ __global__ void __launch_bounds__(HT) hie_stream_kernel(const HieArgs g) {
     f32x4 oA, oB;
     if (MODE == MODE_HEAD) {
       const float dA = g.dl[mA], dB = g.dl[mB];
+      const float keep_q = 1.0f / g.inv_keep;
       f32x4 scA, scB;
       keep4v(g.keep, g.seed, g.thr, g.inv_keep, mA * CT + c4, scA);
       keep4v(g.keep, g.seed, g.thr, g.inv_keep, mB * CT + c4, scB);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float tA = scA[j] > 0.f ? xA[j] / scA[j] : 0.f;
-        const float tB = scB[j] > 0.f ? xB[j] / scB[j] : 0.f;
+        const float tA = scA[j] > 0.f ? xA[j] * keep_q : 0.f;       // tanh value back from the stored tanh * keep / (1 - p)
+        const float tB = scB[j] > 0.f ? xB[j] * keep_q : 0.f;
         oA[j] = dA * wv[j] * scA[j] * (1.0f - tA * tA);
         oB[j] = dB * wv[j] * scB[j] * (1.0f - tB * tB);
       }
@@ -143,8 +144,8 @@ __global__ void __launch_bounds__(HT) hie_stream_kernel(const HieArgs g) {
         keep4v(g.keep, g.seed, g.thr, g.inv_keep, mB * CT + c4, scB);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          oA[j] = tanhf(oA[j]) * scA[j];
-          oB[j] = tanhf(oB[j]) * scB[j];
+          oA[j] = vqf_tanh_fast(oA[j]) * scA[j];
+          oB[j] = vqf_tanh_fast(oB[j]) * scB[j];
         }
       }
     }
