@@ -64,7 +64,7 @@ def embed_tanh(embedding, ids, time_major=False):
 def embed(embedding, ids):
     """embedding(ids) (hieCoAtten.py:27, networks.py:23,56, mhb_coAtt.py:181) on the HIP path under the same conditions."""
     if _plain_embedding(embedding, ids):
-        return EmbedTanhFn.apply(ids, embedding.weight, False)
+        return EmbedTanhFn.apply(ids, embedding.weight, False, False)
     return embedding(ids)
 
 
