@@ -33,6 +33,8 @@ import sys
 import time
 import types
 
+_T0 = time.time()        # process start, before `import torch` (1-2 minutes on a fresh box): the stage markers count from here
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for _p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
     if _p not in sys.path:
@@ -522,6 +524,41 @@ def secondary_config(vqa_amd, which, dev, steps, warmup):
     return out
 
 
+def dp_one_rank(vqa_amd, parallel, dev, steps, warmup, plain_ms=None, pg_timeout=None):
+    """The headline step with the whole data-parallel machinery of host/parallel.py in a ONE-rank RCCL group (solver.py:34-36's
+    nn.DataParallel replaced): gradient hooks, bucket copies, asynchronous ncclAllReduce(AVG) on RCCL's high-priority stream,
+    large-tile GEMMs launched one workgroup per tile instead of persistent.  What a rank pays for data parallelism before any
+    byte crosses xGMI, timed by the driver's own run: the expected N-GPU step is this `ms_per_step` plus the exposed tail of
+    the real all-reduce."""
+    import socket
+    ops = vqa_amd.ops
+    if not dist.is_initialized():
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        parallel.init_distributed("nccl", force=True, timeout_s=pg_timeout)
+    wl = Workload(vqa_amd, "mfb", "f32", 512, 0, dev)
+    wl.reducer = parallel.GradientAllReducer(wl.model, single_rank=True)
+
+    def fence():
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed, loss = timed_steps(wl, ops, warmup, steps, fence)
+    ms = 1e3 * elapsed / steps
+    exposed = exposed_allreduce_steps(wl, CENSUS_STEPS, fence)
+    out = {"what": "MFB-baseline headline step (B=512, fp32, faithful) under GradientAllReducer in a one-rank RCCL group: hooks, "
+                   "bucket copies, %d collectives per step, per-tile GEMM launches" % len(wl.reducer.buckets),
+           "ms_per_step": round(ms, 3), "value": round(512 * steps / elapsed, 2), "unit": "QA-pairs/s", "steps": steps,
+           "warmup": warmup, "plain_ms_per_step": plain_ms,
+           "overhead_frac": round(ms / plain_ms - 1.0, 4) if plain_ms else None,
+           "gemm_workgroups": wl.reducer.gemm_workgroups()["f32"], "backend": dist.get_backend(),
+           "allreduce_bucket_bytes": wl.reducer.bucket_bytes_list(), "allreduce_exposed_ms": exposed,
+           "loss": round(float(loss.item()), 5)}
+    wl.free()
+    return out
+
+
 def _short(x, n=160):
     return x if not isinstance(x, str) or len(x) <= n else x[:n - 3] + "..."
 
@@ -580,6 +617,10 @@ def compact_line(out, args):
             if "error" in s2:
                 summ[which] = {"error": _short(s2["error"], 200)}
                 continue
+            if which == "dp_one_rank":
+                summ[which] = {k: s2[k] for k in ("ms_per_step", "plain_ms_per_step", "overhead_frac", "gemm_workgroups",
+                                                  "allreduce_exposed_ms", "backend", "steps")}
+                continue
             r2 = s2.get("roofline") or {}
             k2 = s2.get("kernels_ms_per_step") or {}
             summ[which] = {"workload": _short(s2["config"]["workload"], 90), "ms_per_step": s2["ms_per_step"], "value": s2["value"],
@@ -594,33 +635,185 @@ def compact_line(out, args):
     return line
 
 
-def spawn_ranks(n):
+RANK_LOG_DIR = os.path.join(ROOT, "gpurun_out")
+READY_MARK = "process group ready"
+
+
+def stage(msg):
+    """Progress marker of a rank: one line on stderr (the per-rank log under spawn_ranks) and, under any launcher, the last
+    marker in gpurun_out/rank<r>.stage -- what a peer's rendezvous time-out and the parent's deadline message quote."""
+    r = os.environ.get("RANK", "0")
+    line = "[bench rank %s +%.1fs] %s" % (r, time.time() - _T0, msg)
+    sys.stderr.write(line + "\n")
+    sys.stderr.flush()
+    if "WORLD_SIZE" in os.environ:
+        try:
+            os.makedirs(RANK_LOG_DIR, exist_ok=True)
+            with open(os.path.join(RANK_LOG_DIR, "rank%s.stage" % r), "w") as f:
+                f.write(line + "\n")
+        except OSError:
+            pass
+
+
+def peer_stages(world):
+    """{rank: last stage marker} as the ranks of this launch left them (a rank that never started has none)."""
+    out = {}
+    for r in range(world):
+        try:
+            st = os.stat(os.path.join(RANK_LOG_DIR, "rank%d.stage" % r))
+            txt = open(os.path.join(RANK_LOG_DIR, "rank%d.stage" % r)).read().strip()
+            out[r] = txt if st.st_mtime >= _T0 - 3600 else "(stale marker) " + txt
+        except OSError:
+            out[r] = "no marker: the rank never reached bench.py's main()"
+    return out
+
+
+def _tail(path, n=40):
+    try:
+        with open(path, errors="replace") as f:
+            return f.read().splitlines()[-n:]
+    except OSError as e:
+        return ["(no log: %s)" % e]
+
+
+def spawn_ranks(n, launch_timeout):
     """`python bench.py --gpus N` WITHOUT a launcher (no WORLD_SIZE in the environment): this process -- which has not touched
-    the GPU and never will -- starts N fresh ranks with `python -m torch.distributed.run` as a CHILD (no exec), relays
-    rank 0's JSON line and the children's stderr, and exits with their status."""
+    the GPU and never will -- starts N fresh ranks as CHILDREN (no exec; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as torchrun
+    sets them), each in its own session with stdout + stderr in gpurun_out/rank<r>.log, and watches them:
+      * every rank must log "process group ready" within `launch_timeout` seconds of the start (the first `import torch` on a
+        fresh box takes 1-2 minutes; the rendezvous itself is bounded by host/parallel.py's 120 s);
+      * afterwards the job may not go `launch_timeout` seconds without ANY rank's log growing or a rank ending;
+      * a rank that ends non-zero ends the job: its peers get 15 s to follow, then their process groups are killed.
+    On any of these the parent terminates every child process group, says which ranks had not reached which stage, prints the
+    last 40 lines of each rank's log and exits non-zero (124 for a deadline) -- a stalled rank on an 8-GPU lease ends with a
+    diagnosis, not with a silent time-limit kill.  On success rank 0's ONE JSON line is relayed on stdout."""
+    import signal
     import socket
     import subprocess
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.makedirs(RANK_LOG_DIR, exist_ok=True)
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # the host driver only supports dmabuf IPC (RCCL needs it)
     env.setdefault("OMP_NUM_THREADS", "4")
-    p = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, text=True)
-    lines = []
-    for line in p.stdout:
-        if line.lstrip().startswith("{"):
-            lines.append(line.rstrip("\n"))
-        else:
-            sys.stderr.write(line)
-    rc = p.wait()
-    for line in lines:
-        print(line, flush=True)
-    if rc == 0 and len(lines) != 1:
-        sys.stderr.write("bench.py: expected one JSON line from rank 0, got %d\n" % len(lines))
-        rc = 1
+    env.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               PYTHONUNBUFFERED="1")
+    logs = [os.path.join(RANK_LOG_DIR, "rank%d.log" % r) for r in range(n)]
+    for r in range(n):
+        try:
+            os.remove(os.path.join(RANK_LOG_DIR, "rank%d.stage" % r))
+        except OSError:
+            pass
+    procs = []
+    for r in range(n):
+        f = open(logs[r], "w")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], cwd=ROOT,
+                                      env=dict(env, RANK=str(r), LOCAL_RANK=str(r), GROUP_RANK="0", ROLE_RANK=str(r)),
+                                      stdout=f, stderr=subprocess.STDOUT, start_new_session=True))
+        f.close()
+
+    def ready(r):
+        try:
+            return READY_MARK in open(logs[r], errors="replace").read()
+        except OSError:
+            return False
+
+    def sizes():
+        out = []
+        for lg in logs:
+            try:
+                out.append(os.path.getsize(lg))
+            except OSError:
+                out.append(0)
+        return out
+
+    def kill_all():
+        for sig, wait in ((signal.SIGTERM, 5.0), (signal.SIGKILL, 5.0)):
+            alive = [p for p in procs if p.poll() is None]
+            if not alive:
+                return
+            for p in alive:
+                try:
+                    os.killpg(p.pid, sig)
+                except OSError:
+                    pass
+            t_end = time.time() + wait
+            while time.time() < t_end and any(p.poll() is None for p in alive):
+                time.sleep(0.1)
+
+    def report(reason):
+        sys.stderr.write("bench.py: %s\n" % reason)
+        st = peer_stages(n)
+        for r in range(n):
+            rc = procs[r].poll()
+            sys.stderr.write("  rank %d: %s; exit code %s; last marker: %s\n"
+                             % (r, "reached '%s'" % READY_MARK if ready(r) else "NEVER reached '%s'" % READY_MARK,
+                                "none (killed by the parent)" if rc is None else rc, st[r]))
+        for r in range(n):
+            sys.stderr.write("----- last 40 lines of %s -----\n" % os.path.relpath(logs[r], ROOT))
+            for line in _tail(logs[r]):
+                sys.stderr.write("  " + line + "\n")
+        sys.stderr.flush()
+
+    t0 = time.time()
+    last_growth, last_sizes, last_beat = t0, sizes(), t0
+    all_ready = False
+    rc = None
+    while True:
+        time.sleep(0.25)
+        now = time.time()
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            rc = max((abs(c) for c in codes), default=0)
+            if rc:
+                report("rank(s) %s ended non-zero" % [r for r, c in enumerate(codes) if c])
+            break
+        bad = [r for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            t_end = now + 15.0
+            while time.time() < t_end and any(p.poll() is None for p in procs):
+                time.sleep(0.25)
+            report("rank(s) %s ended non-zero (exit code %s) while rank(s) %s were still running"
+                   % (bad, [codes[r] for r in bad], [r for r, p in enumerate(procs) if p.poll() is None]))
+            kill_all()
+            rc = abs(codes[bad[0]]) or 1
+            break
+        sz = sizes()
+        if sz != last_sizes:
+            last_sizes, last_growth = sz, now
+        if not all_ready:
+            all_ready = all(ready(r) for r in range(n))
+            if not all_ready and now - t0 > launch_timeout:
+                st = peer_stages(n)
+                late = [r for r in range(n) if not ready(r)]
+                waiting = [r for r in late if "] rendezvous:" in st[r]]         # arrived, blocked on their peers
+                absent = [r for r in late if r not in waiting]
+                report("launch deadline: rank(s) %s had not reached '%s' %.0f s after the start (--launch-timeout %.0f); "
+                       "rank(s) %s never ARRIVED at the rendezvous, rank(s) %s were waiting in it for their peers"
+                       % (late, READY_MARK, now - t0, launch_timeout, absent, waiting))
+                kill_all()
+                rc = 124
+                break
+        elif now - last_growth > launch_timeout:
+            report("stall: no rank has written to its log or ended for %.0f s (--launch-timeout %.0f)"
+                   % (now - last_growth, launch_timeout))
+            kill_all()
+            rc = 124
+            break
+        if now - last_beat > 60.0:
+            last_beat = now
+            st = peer_stages(n)
+            sys.stderr.write("bench.py: %d ranks running for %.0f s; %s\n"
+                             % (n, now - t0, "; ".join("rank %d: %s" % (r, st[r].split("] ", 1)[-1]) for r in range(n))))
+            sys.stderr.flush()
+    lines = [l for l in _tail(logs[0], 100000) if l.lstrip().startswith("{")]
+    if rc == 0:
+        for line in lines:
+            print(line, flush=True)
+        if len(lines) != 1:
+            report("expected one JSON line from rank 0, got %d" % len(lines))
+            rc = 1
     return rc
 
 
@@ -663,20 +856,56 @@ def main():
     ap.add_argument("--one-rank-group", action="store_true",
                     help="N = 1 only: run the data-parallel machinery anyway (a one-rank RCCL group, buckets, hooks, per-tile "
                          "GEMM launches): what data parallelism costs a rank before any byte crosses xGMI")
+    ap.add_argument("--launch-timeout", type=float, default=420.0,
+                    help="bare `--gpus N` launch: seconds every rank has to reach 'process group ready', and afterwards the longest "
+                         "silence (no rank log growing, no rank ending) before the parent kills the job with a diagnosis")
+    ap.add_argument("--pg-timeout", type=float, default=None,
+                    help="bound in seconds on the torch.distributed rendezvous and on each collective (default 120: host/parallel.py)")
+    ap.add_argument("--no-dp-one-rank", action="store_true",
+                    help="skip the one-rank data-parallel rehearsal (`secondary_summary.dp_one_rank`) of a default 1-GPU run")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(spawn_ranks(args.gpus))       # before anything here has initialised the GPU
+        sys.exit(spawn_ranks(args.gpus, args.launch_timeout))       # before anything here has initialised the GPU
 
+    multi = int(os.environ.get("WORLD_SIZE", "1")) > 1
+    if multi:
+        # In-rank watchdog for launches this file does not supervise (the driver's torchrun line): a C-level timer thread that
+        # needs no GIL -- it fires inside a blocked rendezvous or RCCL bootstrap too --, dumps every thread's stack to the rank's
+        # stderr and ends the process (exit code 1; torchrun then ends the peers).  Armed for the launch phase here and again
+        # for the timed loop; the last marker in gpurun_out/rank<r>.stage says how far the rank got.
+        import faulthandler
+        faulthandler.dump_traceback_later(args.launch_timeout, exit=True)
+        stage("start, pid %d; watchdog %.0f s for the launch phase" % (os.getpid(), args.launch_timeout))
     import vqa_amd
     from importlib import import_module
     parallel = import_module("vqa-attention-networks_amd.host.parallel")
     ops = vqa_amd.ops
     vqa_amd.lib.load()
+    if multi:
+        stage("torch imported, libvqa_fusion.so loaded")
 
     if args.no_defer:
         import_module("vqa-attention-networks_amd.host.mfb")._SideStream.DEFER = False
-    rank, world, local = parallel.init_distributed(args.backend, force=args.one_rank_group)
+    if os.environ.get("VQF_TEST_STALL_RANK") == os.environ.get("RANK", "0") and multi:
+        # test switch (tests/test_launch_deadline.py): this rank never arrives at the rendezvous
+        stage("VQF_TEST_STALL_RANK: sleeping %s s before the rendezvous" % os.environ.get("VQF_TEST_STALL_S", "600"))
+        time.sleep(float(os.environ.get("VQF_TEST_STALL_S", "600")))
+    if multi:
+        stage("rendezvous: init_process_group(%s), bound %s s" % (args.backend or "nccl", args.pg_timeout or parallel.PG_TIMEOUT_S))
+    try:
+        rank, world, local = parallel.init_distributed(args.backend, force=args.one_rank_group, timeout_s=args.pg_timeout)
+    except RuntimeError as e:
+        if multi:       # name the ranks that never got to the rendezvous: their last markers (gpurun_out/rank<r>.stage)
+            st = peer_stages(int(os.environ["WORLD_SIZE"]))
+            sys.stderr.write("bench.py: %s\n" % e)
+            for r, m in st.items():
+                sys.stderr.write("  rank %d last marker: %s\n" % (r, m))
+            sys.stderr.flush()
+            sys.exit(3)
+        raise
+    if multi:
+        stage("%s (world %d, backend %s)" % (READY_MARK, world, dist.get_backend()))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: an explicit WORLD_SIZE must equal --gpus (unset it and bench.py starts "
                          "the N ranks itself, or launch them with `python -m torch.distributed.run --nnodes=1 "
@@ -694,6 +923,11 @@ def main():
     reducer = parallel.GradientAllReducer(wl.model, gemm_workgroups=args.gemm_workgroups,   # broadcasts rank 0's weights; no-op at world 1
                                           single_rank=args.one_rank_group)
     wl.reducer = reducer
+    if multi:
+        faulthandler.cancel_dump_traceback_later()
+        loop_bound = args.launch_timeout + 2.0 * (args.warmup + args.steps + 2 * CENSUS_STEPS)
+        faulthandler.dump_traceback_later(loop_bound, exit=True)
+        stage("parameters broadcast, %d gradient buckets; watchdog %.0f s for the step loops" % (len(reducer.buckets), loop_bound))
 
     def fence():
         if world > 1:
@@ -701,6 +935,8 @@ def main():
         torch.cuda.synchronize()
 
     elapsed, loss = timed_steps(wl, ops, args.warmup, args.steps, fence)
+    if multi:
+        stage("%d warm-up + %d timed steps done (%.1f ms per step on this rank)" % (args.warmup, args.steps, 1e3 * elapsed / args.steps))
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -824,11 +1060,20 @@ def main():
                 out["secondary"][which] = secondary_config(vqa_amd, which, dev, args.secondary_steps, args.secondary_warmup)
             except Exception as e:          # the headline line must survive a secondary failure; say what happened
                 out["secondary"][which] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        if not args.no_dp_one_rank:
+            try:
+                out["secondary"]["dp_one_rank"] = dp_one_rank(vqa_amd, parallel, dev, args.secondary_steps, args.secondary_warmup,
+                                                              plain_ms=ms_per_step, pg_timeout=args.pg_timeout)
+            except Exception as e:
+                out["secondary"]["dp_one_rank"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and not args.one_rank_group:
             out["cpu_baseline"] = cpu_baseline(batch=args.cpu_batch)
             out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
-        print(json.dumps(compact_line(out, args)))
+        print(json.dumps(compact_line(out, args)), flush=True)
+    if multi:
+        faulthandler.cancel_dump_traceback_later()
+        stage("line printed" if rank == 0 else "done")
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

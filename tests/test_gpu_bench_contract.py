@@ -56,7 +56,7 @@ def test_bench_prints_one_contract_line():
         assert 0.3 < y["frac"] < 1.0 and abs(y["frac"] - y["achieved"] / 8000.0) < 1e-3
     # the line stays small enough for the driver's record, and ends with the summary of BASELINE configs 3 and 4
     assert len(lines[0]) < 6500, len(lines[0])
-    assert lines[0].rstrip().endswith("}}}") and lines[0].index('"secondary_summary"') > len(lines[0]) - 1900
+    assert lines[0].rstrip().endswith("}}}") and lines[0].index('"secondary_summary"') > len(lines[0]) - 2000
     assert "kernels_ms_per_step" not in d and "secondary" not in d and d["launches_per_step"] > 50 and d["top_kernels_ms_per_step"]
     # ... the full objects (census tables, notes, the secondary configs' roofline objects) are in the census file
     full = json.load(open(os.path.join(ROOT, d["census_file"])))
@@ -77,6 +77,20 @@ def test_bench_prints_one_contract_line():
         assert sm["ms_per_step"] == s2["ms_per_step"] and sm["value"] == s2["value"] and sm["dtype"] == dtype
         assert sm["roofline_frac"] == r2["frac"] and sm["roofline_peak"] == peak and sm["step_roofline_frac"] == s2["step_roofline"]["frac"]
         assert sm["launches_per_step"] > 10
+    # the data-parallel machinery in a one-rank RCCL group (solver.py:34-36 replaced), timed in the same run: what a rank pays
+    # before any byte crosses xGMI
+    dp, dps = sec["dp_one_rank"], summ["dp_one_rank"]
+    assert "error" not in dp, dp
+    assert dps["backend"] == "nccl" and dps["gemm_workgroups"] == "one per tile" and dps["steps"] == 2
+    assert dps["ms_per_step"] == dp["ms_per_step"] and 0.5 * d["ms_per_step"] < dps["ms_per_step"] < 2.0 * d["ms_per_step"]
+    assert dps["plain_ms_per_step"] == d["ms_per_step"] and abs(dps["overhead_frac"] - (dps["ms_per_step"] / d["ms_per_step"] - 1)) < 1e-3
+    assert len(dps["allreduce_exposed_ms"]) == len(dp["allreduce_bucket_bytes"]) >= 4 and sum(dp["allreduce_bucket_bytes"]) == 240124080
+
+
+def test_stalled_rank_trips_the_launch_deadline_on_the_gpu_box():
+    """tests/test_launch_deadline.py's first case again where the driver's GPU suite runs (the stall precedes any GPU call)."""
+    import test_launch_deadline as t
+    t.test_a_rank_that_never_reaches_the_rendezvous_trips_the_launch_deadline()
 
 
 def test_bench_refuses_an_inconsistent_explicit_world_size():

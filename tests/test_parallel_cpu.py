@@ -133,6 +133,92 @@ def test_allreduce_equals_full_batch_gradient(bucket_bytes):
                     assert torch.allclose(torch.from_numpy(gavg), gref, rtol=1e-5, atol=1e-7)
 
 
+def _ragged_worker(rank, world, store, q):
+    try:
+        sys.path.insert(0, ROOT)
+        torch.set_num_threads(1)
+        os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+        from importlib import import_module
+        par = import_module("vqa-attention-networks_amd.host.parallel")
+        par.init_distributed(backend="gloo", init_method="file://" + store, timeout_s=60)
+        model = _make_model()
+        model.only0 = torch.nn.Parameter(torch.full((9,), 0.5))       # a branch only rank 0's shard takes
+        model.only1 = torch.nn.Parameter(torch.full((3,), 0.25))      # ... and one only rank 1 takes
+        red = par.GradientAllReducer(model, bucket_bytes=64)          # one parameter per bucket: order matters
+        g = torch.Generator().manual_seed(11)
+        X = torch.randn(16, 12, generator=g)
+        Y = torch.randint(0, 7, (16,), generator=g)
+        lo, hi = par.shard_rows(16, rank, world)
+        outs = []
+        for step in range(3):
+            model.zero_grad(set_to_none=True)
+            loss = torch.nn.functional.cross_entropy(model[2](model[1](model[0](X[lo:hi]))), Y[lo:hi])
+            if rank == 0:
+                loss = loss + (model.only0 * torch.arange(9.0)).sum()
+            else:
+                loss = loss + (model.only1 * torch.tensor([1.0, 2.0, 3.0])).sum() * (step + 1)
+            loss.backward()
+            red.finish()
+            outs.append({k: (None if p.grad is None else p.grad.clone().numpy()) for k, p in model.named_parameters()})
+            assert {id(model.only0), id(model.only1)} == red.ragged and red.unused == {id(model.unused)}
+            late = [b["late"] for b in red.buckets]
+            assert late == sorted(late) and late.count(False) == 4 and late.count(True) >= 1      # eager buckets first
+        red.close()
+        q.put((rank, outs, None, 0))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        q.put((rank, "error", traceback.format_exc(), 0))
+        raise
+
+
+def test_parameter_with_a_gradient_on_one_rank_only():
+    """a parameter that gets its gradient on one rank and not on the other.  The first step runs its collectives
+    in strict bucket order and exchanges the participation mask AFTER the buckets, so the ranks never pair different
+    collectives; from then on such parameters travel in `late` buckets launched from finish().  Result on every rank: the
+    average over ranks with the absent gradient counted as zero; three steps, one parameter per bucket."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    res = {}
+    with tempfile.TemporaryDirectory(prefix="vqf_dp_") as d:
+        procs = [ctx.Process(target=_ragged_worker, args=(r, world, os.path.join(d, "store"), q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        try:
+            for _ in range(world):
+                rank, outs, tb, _ = q.get(timeout=240)
+                assert outs != "error", "rank %d failed:\n%s" % (rank, tb)
+                res[rank] = outs
+            for r, p in enumerate(procs):
+                p.join(timeout=60)
+                assert p.exitcode == 0, "rank %d exit code %s" % (r, p.exitcode)
+        finally:
+            for p in procs:
+                if p.is_alive():
+                    p.kill()
+    import numpy as np
+    for step in range(3):
+        a, b = res[0][step], res[1][step]
+        assert a.keys() == b.keys()
+        for k in a:
+            if k == "unused":
+                assert a[k] is None and b[k] is None
+                continue
+            assert np.array_equal(a[k], b[k]), (step, k)                       # replicas agree
+        assert np.allclose(a["only0"], np.arange(9.0) / 2)                     # (g0 + 0) / 2
+        assert np.allclose(a["only1"], np.array([1.0, 2.0, 3.0]) * (step + 1) / 2)
+    # the shared layers: the full-batch gradient, as in the test above
+    model = _make_model()
+    g = torch.Generator().manual_seed(11)
+    X = torch.randn(16, 12, generator=g)
+    Y = torch.randint(0, 7, (16,), generator=g)
+    torch.nn.functional.cross_entropy(model(X), Y).backward()
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            assert torch.allclose(torch.from_numpy(res[0][0][k]), p.grad, rtol=1e-5, atol=1e-7), k
+
+
 def test_shard_rows_partitions_the_batch():
     from importlib import import_module
     sys.path.insert(0, ROOT)

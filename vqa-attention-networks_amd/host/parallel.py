@@ -12,15 +12,22 @@ xGMI is point-to-point (7 links x ~153 GB/s per GPU), so a ring all-reduce is
 per-link bound; buckets are therefore few and large (default 64 MiB: MFB's
 240 MB of gradients travel in 4 collectives).
 """
+import datetime
 import os
 
 import torch
 import torch.distributed as dist
 
+# Bound on the rendezvous and on every collective of the group (the watchdog of the nccl backend aborts the process when a
+# collective exceeds it; gloo raises): a rank that never arrives must end the job with a message, not hold it until an outer
+# time limit kills it silently.  The steady-state collectives of this path take milliseconds.
+PG_TIMEOUT_S = 120.0
 
-def init_distributed(backend=None, init_method=None, force=False):
+
+def init_distributed(backend=None, init_method=None, force=False, timeout_s=None):
     """Initialise torch.distributed from the torchrun environment.  Returns (rank, world, local_rank).
     force: create the process group at WORLD_SIZE 1 too (a one-rank RCCL group: the rehearsal a one-GPU box allows).
+    timeout_s: bound on the rendezvous and on each collective (default PG_TIMEOUT_S, or the environment's VQF_PG_TIMEOUT_S).
 
     `init_method` (or the environment variable VQF_DIST_INIT) overrides the env:// rendezvous, e.g.
     "file:///tmp/x/store" — used by the tests, whose parent cannot hold a TCP port open for its children."""
@@ -33,7 +40,9 @@ def init_distributed(backend=None, init_method=None, force=False):
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        kw = dict(rank=rank, world_size=world)
+        if timeout_s is None:
+            timeout_s = float(os.environ.get("VQF_PG_TIMEOUT_S") or PG_TIMEOUT_S)
+        kw = dict(rank=rank, world_size=world, timeout=datetime.timedelta(seconds=float(timeout_s)))
         if init_method:
             kw["init_method"] = init_method
         if backend == "nccl":
@@ -50,7 +59,14 @@ def init_distributed(backend=None, init_method=None, force=False):
                 kw["pg_options"] = opts
             except Exception:                     # an older torch without the option object: default stream priority
                 pass
-        dist.init_process_group(backend, **kw)
+        try:
+            dist.init_process_group(backend, **kw)
+        except Exception as e:
+            raise RuntimeError("rank %d of %d: torch.distributed rendezvous (%s, %s) did not complete within %.0f s -- a peer rank "
+                               "never arrived or the store is unreachable: %s: %s"
+                               % (rank, world, backend, init_method or "env://%s:%s" % (os.environ.get("MASTER_ADDR"),
+                                                                                         os.environ.get("MASTER_PORT")),
+                                  float(timeout_s), type(e).__name__, str(e)[:300])) from e
     return rank, world, local
 
 
@@ -102,7 +118,9 @@ class GradientAllReducer:
     over ranks.  With world_size == 1 it is a no-op (grads are left untouched).
     A parameter that received no gradient on ANY rank in the first step (HieCoAtten's fc_Wbq: hieCoAtten.py:11 builds it,
     :31 never uses it) keeps p.grad = None, as without the reducer -- so it gets no optimizer state either -- and leaves
-    the buckets; the graph is taken to be static after that (such a parameter receiving a gradient later raises).
+    the buckets; the graph is taken to be static after that (such a parameter receiving a gradient later raises).  A parameter
+    with a gradient on SOME ranks only gets the average over all ranks (absent = zero) through buckets every rank launches
+    from finish(); the first step runs its collectives in strict bucket order, so ranks never pair different buckets.
     gemm_workgroups: None (default: one workgroup per tile at world > 1 unless the library option was set explicitly),
     "per-tile" or "persistent" -- how the large-tile GEMMs launch while this reducer is alive (see __init__).
     """
@@ -129,6 +147,8 @@ class GradientAllReducer:
         self._hooks = []
         self._seen = set()          # id() of the parameters whose hook fired in the current step
         self.unused = None          # id() of the parameters without a gradient on any rank (known after the first finish())
+        self.ragged = None          # ... with a gradient on some ranks only (their buckets are launched from finish())
+        self._next = 0
         self._bucket_bytes = bucket_bytes
         if self.active:
             # The large-tile GEMMs normally run as PERSISTENT workgroups (one per CU, holding all of its LDS for the whole
@@ -192,30 +212,48 @@ class GradientAllReducer:
                 dist.broadcast(t.data, src=src, group=self.group)
 
     def _build_buckets(self, bucket_bytes):
-        # gradients become ready roughly in reverse registration order
-        cur, cur_bytes = [], 0
-        groups = []
+        """Buckets in the order the gradients become ready (roughly reverse registration order).  Parameters without a gradient
+        on any rank (`unused`) hold no bucket space; parameters that received a gradient on SOME ranks only (`ragged`, known
+        after the first step) go into buckets of their own at the end, flagged `late`: those are launched from finish() only."""
         self.buckets, self._index = [], {}
-        for p in reversed([p for p in self.params if not (self.unused and id(p) in self.unused)]):
-            nbytes = p.numel() * p.element_size()
-            if cur and cur_bytes + nbytes > bucket_bytes:
+        live = [p for p in reversed(self.params) if not (self.unused and id(p) in self.unused)]
+        eager = [p for p in live if not (self.ragged and id(p) in self.ragged)]
+        late = [p for p in live if self.ragged and id(p) in self.ragged]
+        for ps_all, is_late in ((eager, False), (late, True)):
+            cur, cur_bytes, groups = [], 0, []
+            for p in ps_all:
+                nbytes = p.numel() * p.element_size()
+                if cur and cur_bytes + nbytes > bucket_bytes:
+                    groups.append(cur)
+                    cur, cur_bytes = [], 0
+                cur.append(p)
+                cur_bytes += nbytes
+            if cur:
                 groups.append(cur)
-                cur, cur_bytes = [], 0
-            cur.append(p)
-            cur_bytes += nbytes
-        if cur:
-            groups.append(cur)
-        for bi, ps in enumerate(groups):
-            total = sum(p.numel() for p in ps)
-            flat = torch.zeros(total, dtype=ps[0].dtype, device=ps[0].device)
-            entries, off = [], 0
-            for p in ps:
-                entries.append((p, off, p.numel()))
-                self._index[id(p)] = (bi, off)
-                off += p.numel()
-            self.buckets.append(dict(flat=flat, params=entries, pending=len(entries), handle=None))
+            for ps in groups:
+                bi = len(self.buckets)
+                total = sum(p.numel() for p in ps)
+                flat = torch.zeros(total, dtype=ps[0].dtype, device=ps[0].device)
+                entries, off = [], 0
+                for p in ps:
+                    entries.append((p, off, p.numel()))
+                    self._index[id(p)] = (bi, off)
+                    off += p.numel()
+                self.buckets.append(dict(flat=flat, params=entries, pending=len(entries), handle=None, late=is_late,
+                                         complete=False))
+        self._next = 0              # first step only: the next bucket (by index) the strict order may launch
 
     # -- per step ------------------------------------------------------------
+    # Collective ORDER must be the same on every rank.  Steady state: a bucket is launched the moment its last gradient has
+    # arrived; with the same autograd graph on every rank that order is the same everywhere.  What may differ between ranks is
+    # WHICH parameters receive a gradient (a branch one shard does not take), so
+    #   * the FIRST step launches strictly in bucket-index order (complete buckets as early as the order allows, the rest from
+    #     finish()): the same sequence on every rank whatever arrived where;
+    #   * finish() of that step then all-reduces (SUM) a has-gradient mask: parameters seen by no rank leave the buckets and
+    #     keep grad = None; parameters seen by some ranks only move to `late` buckets, which every rank launches from
+    #     finish(), in index order, after the eager ones (zero-filled where the gradient is absent);
+    #   * a parameter that had a gradient on every rank in step one and misses it later would make this rank launch its bucket
+    #     out of order: that raises here instead of mis-pairing collectives (the peers then end on the group's timeout).
     def _on_grad(self, p):
         if id(p) not in self._index:
             raise RuntimeError("GradientAllReducer: a parameter that had no gradient on any rank in the first step (shape %s) "
@@ -234,7 +272,16 @@ class GradientAllReducer:
             b.setdefault("events", []).append(ev)
         b["pending"] -= 1
         if b["pending"] == 0:
-            self._launch(b)
+            b["complete"] = True
+            if self.unused is None:               # first step: strict index order
+                self._launch_in_order()
+            elif not b["late"]:
+                self._launch(b)
+
+    def _launch_in_order(self):
+        while self._next < len(self.buckets) and self.buckets[self._next]["complete"]:
+            self._launch(self.buckets[self._next])
+            self._next += 1
 
     def _launch(self, b):
         cur = torch.cuda.current_stream(b["flat"].device) if b["flat"].is_cuda else None
@@ -258,20 +305,31 @@ class GradientAllReducer:
     def _has_avg(self):
         return dist.get_backend(self.group) == "nccl"
 
+    def _launch_rest(self, first):
+        """finish(): every bucket that is not in flight yet, in index order; gradients absent on THIS rank contribute zeros."""
+        for b in self.buckets:
+            if b["handle"] is not None:
+                continue
+            if not first and not b["late"] and b["pending"] != 0:
+                missing = [tuple(p.shape) for p, _, _ in b["params"] if id(p) not in self._seen]
+                raise RuntimeError("GradientAllReducer: parameter(s) of shape %s received a gradient on every rank in the first "
+                                   "step and none on this rank now: launching their bucket here would pair it with another "
+                                   "bucket's collective on the peers.  The reducer assumes a static graph after the first step "
+                                   "-- build a new reducer" % (missing,))
+            for p, off, n in b["params"]:
+                if id(p) not in self._seen:
+                    b["flat"][off:off + n].zero_()
+            self._launch(b)
+        self._next = len(self.buckets)
+
     def finish(self):
         """wait for the collectives and expose the averaged gradients as p.grad."""
         if not self.active:
             return
         first = self.unused is None
+        self._launch_rest(first)                   # BEFORE the mask exchange: the same collective sequence on every rank
         if first:
-            self.unused = self._globally_unused()
-        for b in self.buckets:
-            if b["pending"] != 0:
-                # parameters that received no gradient on THIS rank this step contribute zeros
-                for p, off, n in b["params"]:
-                    if id(p) not in self._seen:
-                        b["flat"][off:off + n].zero_()
-                self._launch(b)
+            self.unused, self.ragged = self._participation()
         cuda = self.timing and self.buckets and self.buckets[0]["flat"].is_cuda
         marks = None
         if cuda:
@@ -290,24 +348,30 @@ class GradientAllReducer:
                 if id(p) not in self.unused:
                     p.grad = b["flat"][off:off + n].view_as(p)
             b["pending"] = len(b["params"])
-            b["handle"] = None
+            b["handle"], b["complete"] = None, False
         self._seen = set()
-        if first and self.unused:
-            # the buckets of the following steps hold live gradients only (the views handed out above keep this step's alive)
+        self._next = 0
+        if first and (self.unused or self.ragged):
+            # the buckets of the following steps: live gradients only, ragged ones at the end (the views handed out above keep
+            # this step's buffers alive)
             self._build_buckets(self._bucket_bytes)
         if marks:
             self._marks.append(marks)
             if len(self._marks) > 1024:                # timing is a bench-only switch; never grow without bound
                 del self._marks[:512]
 
-    def _globally_unused(self):
-        """Parameters whose hook fired on NO rank in the step that just ran: one small MAX all-reduce of a has-gradient mask,
-        once (its result is read on the host: a synchronisation the steady state does not pay)."""
+    def _participation(self):
+        """-> (unused, ragged): ids of the parameters whose hook fired on NO rank / on SOME BUT NOT ALL ranks in the step that just
+        ran.  One small SUM all-reduce of a has-gradient mask, once (its result is read on the host: a synchronisation the
+        steady state does not pay); issued after every bucket of the step, so every rank reaches it at the same place."""
         dev = self.params[0].device if self.params else torch.device("cpu")
         mask = torch.tensor([1 if id(p) in self._seen else 0 for p in self.params], dtype=torch.int32, device=dev)
         if mask.numel():
-            dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=self.group)
-        return {id(p) for p, m in zip(self.params, mask.tolist()) if not m}
+            dist.all_reduce(mask, op=dist.ReduceOp.SUM, group=self.group)
+        counts = mask.tolist()
+        unused = {id(p) for p, m in zip(self.params, counts) if m == 0}
+        ragged = {id(p) for p, m in zip(self.params, counts) if 0 < m < self.world}
+        return unused, ragged
 
     def exposed_ms(self):
         """Mean over the timed steps of [ms from the end of the backward kernels to bucket i's completion],
