@@ -1063,7 +1063,7 @@ def main():
         if not args.no_dp_one_rank:
             try:
                 out["secondary"]["dp_one_rank"] = dp_one_rank(vqa_amd, parallel, dev, args.secondary_steps, args.secondary_warmup,
-                                                              plain_ms=ms_per_step, pg_timeout=args.pg_timeout)
+                                                              plain_ms=round(ms_per_step, 3), pg_timeout=args.pg_timeout)
             except Exception as e:
                 out["secondary"]["dp_one_rank"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
     if rank == 0:

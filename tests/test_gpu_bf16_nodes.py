@@ -17,444 +17,17 @@ gradient).  Then
       Nodes without a singular derivative (projections, attention heads, LSTM, log-softmax): a fixed norm-relative
       tolerance.  The two MFB fusion nodes: golden_util's conditioning-aware bound, node-local -- the HIP gradient must be
       as close to the fp64 one as an fp32 evaluation of the same formulas is (x8, floor 2e-3).
-The oracle of this test is torch (fp64 / fp32 on the GPU), test infrastructure only.
+The oracle of this test is torch (fp64 / fp32 on the GPU), test infrastructure only; the harness is tests/node_harness.py
+(round 5: shared with the fp32 node checks of the B = 512 / 256 model-level tests).
 """
-import numpy as np
 import pytest
 import torch
 
 import recipe
 from cases import make_cfg
+from node_harness import Recorder as _Recorder, check_every_node
 
 pytestmark = pytest.mark.gpu
-
-BENIGN_TOL_BF16 = 2e-3      # nodes fed bf16-rounded operands, fp32 accumulate, vs fp64 on the same rounded operands
-BENIGN_TOL_F32 = 1e-4
-
-
-# ---------------------------------------------------------------------------------------------------------------
-# rounding helpers of the emulation
-def bf(x):
-    """round-to-nearest-even to bf16, back in x's dtype"""
-    return x.to(torch.float32).to(torch.bfloat16).to(x.dtype)
-
-
-class _RoundSTE(torch.autograd.Function):          # forward: bf16 rounding; backward: identity
-    @staticmethod
-    def forward(ctx, x):
-        return bf(x)
-
-    @staticmethod
-    def backward(ctx, g):
-        return g
-
-
-class _GradRound(torch.autograd.Function):         # forward: identity; backward: the gradient is rounded to bf16
-    @staticmethod
-    def forward(ctx, x):
-        return x.view_as(x)
-
-    @staticmethod
-    def backward(ctx, g):
-        return bf(g)
-
-
-def _nrel(a, ref):
-    a, ref = a.detach().double(), ref.detach().double()
-    return float((a - ref).norm() / max(float(ref.norm()), 1e-30))
-
-
-def _cond_check(name, got, r64, r32, k=8.0, floor=2e-3):
-    """node-local grad_parity: |got - r64| <= max(k |r32 - r64|, floor |r64|)"""
-    r64 = r64.detach().double()
-    err = float((got.detach().double() - r64).norm())
-    noise = float((r32.detach().double() - r64).norm())
-    bound = max(k * noise, floor * float(r64.norm()))
-    assert err <= bound, (name, "err %.3e bound %.3e noise %.3e norm %.3e" % (err, bound, noise, float(r64.norm())))
-    return err / bound
-
-
-# ---------------------------------------------------------------------------------------------------------------
-# reference formulas (dtype-generic torch)
-def ref_fuse(P, q, N, L, normalise=True):
-    """mfb.py:98-106 / mhb_coAtt.py:100-108 without dropout: product, k=5 sum-pool, signed sqrt, per-sample L2
-    (normalise=False: the signed square roots R themselves, the output of a fusion node with a NormLink)."""
-    z = P.view(N, L, -1) * q[:, None, :]
-    s = z.view(N, L, -1, 5).sum(-1)
-    r = torch.sqrt(torch.relu(s)) - torch.sqrt(torch.relu(-s))
-    if not normalise:
-        return r.reshape(N * L, -1)
-    nrm = r.reshape(N, -1).norm(dim=1).clamp_min(1e-12)
-    return (r / nrm[:, None, None]).reshape(N * L, -1)
-
-
-def linked_cotangent(R, dYs, N):
-    """A fusion node with a NormLink outputs R and is handed dYs = dL/dR with 1/||R_n|| held CONSTANT (its consumer applies
-    that factor in its GEMM epilogue).  The total gradient adds the dependence of 1/||R_n|| on R:
-    dR = dYs - R_n (sum_n R dYs) / ||R_n||^2   (F.normalize's backward written for the un-normalised tensor)."""
-    Rn, d = R.detach().reshape(N, -1), dYs.reshape(N, -1)
-    s = (Rn * d).sum(1, keepdim=True)
-    n2 = (Rn * Rn).sum(1, keepdim=True).clamp_min(1e-24)
-    return (d - Rn * s / n2).reshape(R.shape)
-
-
-def ref_att_head(x, feat, w1, b1, w2, b2, bf16, inv_rows=None):
-    """AttHeadFn without the multilayer conv, live softmax: conv1 + ReLU -> 2 logits -> softmax over S -> glimpse sums.
-    inv_rows (N*S,): the NormLink form -- x is the un-normalised fusion output, the per-sample 1/norm (a CONSTANT of this
-    node) multiplies the conv's accumulator; the gradient that enters the bf16 products is rounded AFTER that factor."""
-    N, S, C = feat.shape
-    sc = 1.0 if inv_rows is None else inv_rows[:, None]
-    if bf16:
-        hid = _GradRound.apply(_RoundSTE.apply(x) @ _RoundSTE.apply(w1).t()) * sc + b1
-    else:
-        hid = (x @ w1.t()) * sc + b1
-    hid = torch.relu(hid)
-    logits = (hid @ w2.t() + b2).view(N, S, -1)
-    wts = torch.softmax(logits, dim=1)                       # over the S positions, per glimpse
-    return torch.einsum("nsg,nsc->ngc", wts, feat).reshape(N, -1)
-
-
-class _RecProd(torch.autograd.Function):
-    """the recurrent product h W_hh^T with bf16 operands: forward bf(h) bf(W)^T; backward dh = bf(g) bf(W); dW from the rounded
-    operands too (wgrad_bf16: LstmSeqFn in both bf16 modes, LstmBatchFn in "bf16-all") or from the unrounded g, h (LstmBatchFn
-    in "bf16": its recurrent weight gradient is an fp32 product)"""
-    @staticmethod
-    def forward(ctx, h, w, wgrad_bf16):
-        ctx.save_for_backward(h, w)
-        ctx.wgrad_bf16 = wgrad_bf16
-        return bf(h) @ bf(w).t()
-
-    @staticmethod
-    def backward(ctx, g):
-        h, w = ctx.saved_tensors
-        gb = bf(g)
-        return gb @ bf(w), (gb.t() @ bf(h)) if ctx.wgrad_bf16 else (g.t() @ h), None
-
-
-def ref_lstm_seq(x, w_ih, w_hh, b_ih, b_hh, bf16, wgrad_bf16=True):
-    """LstmSeqFn / LstmBatchFn: recursion over dim 0 of x (S,B,I); bf16 = True: bf16 operands in the recurrent product (forward:
-    h and W_hh, backward: dG and W_hh); "all": also in the input projection and its two gradients."""
-    S, B, I = x.shape
-    H = w_hh.shape[1]
-    if bf16 == "all":
-        xw = _GradRound.apply(_RoundSTE.apply(x.reshape(S * B, I)) @ _RoundSTE.apply(w_ih).t()) + (b_ih + b_hh)
-    else:
-        xw = x.reshape(S * B, I) @ w_ih.t() + (b_ih + b_hh)
-    xw = xw.view(S, B, 4 * H)
-    h = x.new_zeros(B, H)
-    c = x.new_zeros(B, H)
-    outs = []
-    for s in range(S):
-        rec = (_RecProd.apply(h, w_hh, wgrad_bf16) if bf16 else h @ w_hh.t()) if s else 0.0
-        g = xw[s] + rec
-        i, f, gg, o = g.chunk(4, dim=1)
-        c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
-        h = torch.sigmoid(o) * torch.tanh(c)
-        outs.append(h)
-    return torch.stack(outs, 0)
-
-
-# ---------------------------------------------------------------------------------------------------------------
-class _Recorder:
-    def __init__(self, monkeypatch, fns, names):
-        self.records, self.orig = [], {}
-        for name in names:
-            cls = getattr(fns, name)
-            self.orig[cls] = cls.apply
-            monkeypatch.setattr(cls, "apply", staticmethod(self._wrap(cls)))
-
-    def _wrap(self, cls):
-        def call(*args):
-            out = self.orig[cls](*args)
-            rec = dict(cls=cls, args=args, out=out, dout=None)
-            if torch.is_tensor(out) and out.requires_grad:
-                out.register_hook(lambda g, rec=rec: rec.__setitem__("dout", g.detach().clone()))
-            self.records.append(rec)
-            return out
-        return call
-
-    def replay(self, rec, between=None):
-        """the node alone: fresh leaves from the recorded inputs -> (output, {arg index: gradient}); `between` runs after the
-        forward (a linked fusion node gets its consumer's (dlogits, lin) back there)"""
-        args2 = [a.detach().clone().requires_grad_(a.requires_grad) if (torch.is_tensor(a) and a.is_floating_point()) else a
-                 for a in rec["args"]]
-        out = self.orig[rec["cls"]](*args2)
-        saved = tuple(out.grad_fn.saved_tensors)          # before the backward frees them (the kernel's own P, qq, vv)
-        if between is not None:
-            between()
-        idx = [i for i, a in enumerate(args2) if torch.is_tensor(a) and a.requires_grad]
-        grads = torch.autograd.grad(out, [args2[i] for i in idx], grad_outputs=rec["dout"], allow_unused=True)
-        return out, dict(zip(idx, grads)), saved
-
-
-def _dbl(t, dt):
-    return None if t is None else t.detach().to(dt)
-
-
-def _check_linear(rec, out, grads, rep):
-    x, w, b, relu, bf16 = (list(rec["args"]) + [False, False])[:5]
-    assert not relu
-    w2 = w.reshape(w.shape[0], -1)
-    use_bf16 = bool(bf16) and all(d % 8 == 0 for d in (x.shape[0], x.shape[1], w2.shape[0]))
-    xo, wo = (bf(x.detach()), bf(w2.detach())) if use_bf16 else (x.detach(), w2.detach())
-    tol = BENIGN_TOL_BF16 if use_bf16 else BENIGN_TOL_F32
-    dy = rec["dout"]
-    y64 = xo.double() @ wo.double().t() + b.detach().double()
-    dyo = bf(dy) if use_bf16 else dy
-    worst = _nrel(out, y64)
-    assert worst <= tol, ("LinearFn y", worst)
-    for i, ref in ((0, dyo.double() @ wo.double()), (1, (dyo.double().t() @ xo.double()).view_as(w)), (2, dy.double().sum(0))):
-        if i in grads and grads[i] is not None:
-            e = _nrel(grads[i], ref)
-            assert e <= tol, ("LinearFn grad of arg %d" % i, e, tuple(x.shape), tuple(w2.shape))
-            worst = max(worst, e)
-    rep.append("LinearFn%s %s: %.1e" % ("[bf16]" if use_bf16 else "", tuple(w2.shape), worst))
-
-
-def _check_logsoftmax(rec, out, grads, rep):
-    x = rec["args"][0].detach().double().requires_grad_(True)
-    y = torch.log_softmax(x, dim=1)
-    (dx,) = torch.autograd.grad(y, x, rec["dout"].double())
-    e = max(_nrel(out, y), _nrel(grads[0], dx))
-    assert e <= 1e-5, ("LogSoftmaxRowsFn", e)
-    rep.append("LogSoftmaxRowsFn: %.1e" % e)
-
-
-def _check_att_head(rec, out, grads, rep):
-    x, feat, w1, b1, wm, bm, w2, b2, unit, bf16 = rec["args"][:10]
-    link = rec["args"][10] if len(rec["args"]) > 10 else None
-    assert wm is None and not unit
-    inv_rows = link.inv.detach().double().repeat_interleave(link.L) if link is not None else None
-    bf16 = bool(bf16)
-    dt = torch.float64
-    leaves = {0: _dbl(x, dt), 2: _dbl(w1.reshape(w1.shape[0], -1), dt), 3: _dbl(b1, dt),
-              6: _dbl(w2.reshape(w2.shape[0], -1), dt), 7: _dbl(b2, dt)}
-    if feat.requires_grad:                       # question side: the LSTM states are pooled AND feed the MLP
-        leaves[1] = _dbl(feat, dt)
-    for t in leaves.values():
-        t.requires_grad_(True)
-    y = ref_att_head(leaves[0], leaves.get(1, _dbl(feat, dt)), leaves[2], leaves[3], leaves[6], leaves[7], bf16, inv_rows)
-    want = [i for i in leaves if i in grads and grads[i] is not None]
-    g64 = torch.autograd.grad(y, [leaves[i] for i in want], rec["dout"].double())
-    tol = BENIGN_TOL_BF16 if bf16 else BENIGN_TOL_F32
-    worst = _nrel(out, y)
-    assert worst <= tol, ("AttHeadFn pooled", worst)
-    for i, g in zip(want, g64):
-        e = _nrel(grads[i].reshape(g.shape), g)
-        # the two biases in front of the softmax (b2) carry a mathematically-zero gradient: compare against the scale of dw2
-        if i == 7:
-            scale = float(g64[want.index(6)].norm()) if 6 in want else 1.0
-            assert float((grads[i].double() - g).norm()) <= tol * max(scale, 1e-30), ("AttHeadFn db2", e)
-            continue
-        assert e <= tol, ("AttHeadFn grad of arg %d" % i, e, tuple(x.shape))
-        worst = max(worst, e)
-    rep.append("AttHeadFn%s%s x%s: %.1e" % ("[bf16]" if bf16 else "", "[linked]" if link is not None else "", tuple(x.shape), worst))
-
-
-def _check_img_fuse(rec, out, grads, rep, saved):
-    img, wi, bi, q, keep, seed, p_drop, bf16 = rec["args"][:8]
-    assert bool(bf16) and keep is None and p_drop == 0.0
-    linked = len(rec["args"]) > 8 and rec["args"][8] is not None       # NormLink: the node outputs R, receives dYs
-    N, L, D = img.shape
-    img_b, P_k = saved[0], saved[3]                               # saved: (img2d bf16, wi, q, P, Y, norm, inv, keep)
-    assert img_b.dtype == torch.bfloat16 and P_k.dtype == torch.bfloat16, "config 3 stores the image grid and P in bf16"
-    wb = bf(wi.detach().reshape(wi.shape[0], -1))
-    dY = rec["dout"]
-    # link 1: the stored projection is RNE(bf16 x bf16 -> fp32 accumulate + bias), up to rounding flips of the accumulation
-    rows = torch.arange(0, N * L, 7, device=img.device)          # every 7th row: 14 336 x 5000 outputs
-    P64 = img_b[rows].double() @ wb.double().t() + bi.detach().double()
-    Pk = P_k[rows].double()
-    assert float(((Pk - P64).abs() - (2.0 ** -8) * P64.abs()).max()) <= 1e-6, "stored P is not a bf16 rounding of the product"
-    eq = float((P_k[rows] == P64.to(torch.float32).to(torch.bfloat16)).float().mean())
-    assert eq >= 0.98, ("stored P vs RNE(fp64 product)", eq)
-    del P64, Pk
-    # links 2-4: fusion forward / backward from the kernel's own P, fp64 and fp32 (the noise of the formulas themselves)
-    res = {}
-    for dt in (torch.float64, torch.float32):
-        Pl, ql = P_k.to(dt).requires_grad_(True), q.detach().to(dt).requires_grad_(True)
-        Y = ref_fuse(Pl, ql, N, L, normalise=not linked)
-        dP, dq = torch.autograd.grad(Y, [Pl, ql], linked_cotangent(Y, dY.to(dt), N) if linked else dY.to(dt))
-        dwi = (bf(dP).double().t() @ img_b.double()).view_as(wi)         # the bf16 hand-off: dW = RNE(dP)^T X
-        res[dt] = (Y.detach(), dq, dP.sum(0), dwi)
-        del Pl, ql, Y, dP
-    y_err = _nrel(out, res[torch.float64][0])
-    assert y_err <= 1e-5, ("ImgFuseFn Y", y_err)
-    worst = 0.0
-    for name, i, j in (("dq", 3, 1), ("dbias", 2, 2), ("dW (bf16 dP hand-off)", 1, 3)):
-        worst = max(worst, _cond_check("ImgFuseFn " + name, grads[i], res[torch.float64][j], res[torch.float32][j]))
-    rep.append("ImgFuseFn[bf16]%s N=%d: Y %.1e, P bit-equal %.4f, grads err/bound %.2f" % ("[linked]" if linked else "", N, y_err, eq, worst))
-
-
-def _check_img_proj_late(rec, out, grads, rep):
-    """side-stream form: P0 = RNE(bf16 img x bf16 W^T) computed early without a node; the late node only owns the weight
-    gradient dW = dP^T X with the bf16 dP it is handed."""
-    P0, img2, wi, _ = rec["args"]
-    assert P0.dtype == torch.bfloat16 and img2.dtype == torch.bfloat16 and rec["dout"].dtype == torch.bfloat16
-    wb = bf(wi.detach().reshape(wi.shape[0], -1))
-    rows = torch.arange(0, img2.shape[0], 7, device=img2.device)
-    P64 = img2[rows].double() @ wb.double().t()
-    assert float(((P0[rows].double() - P64).abs() - (2.0 ** -8) * P64.abs()).max()) <= 1e-6, "stored P0 is not a bf16 rounding of the product"
-    eq = float((P0[rows] == P64.to(torch.float32).to(torch.bfloat16)).float().mean())
-    assert eq >= 0.98, eq
-    ref = (rec["dout"].double().t() @ img2.double()).view_as(wi)
-    e = _nrel(grads[2], ref)
-    assert e <= BENIGN_TOL_BF16, ("ImgProjLateFn dW", e)
-    rep.append("ImgProjLateFn[bf16]: P0 bit-equal %.4f, dW %.1e" % (eq, e))
-
-
-def _check_mfb_fuse(rec, out, grads, rep):
-    """side-stream form of the image fusion: bf16 P0 (+ bias inside the kernel) in, bf16 dP out."""
-    P0, bi, q, keep, seed, p_drop, N, L = rec["args"][:8]
-    assert P0.dtype == torch.bfloat16 and keep is None and p_drop == 0.0
-    linked = len(rec["args"]) > 8 and rec["args"][8] is not None
-    res = {}
-    for dt in (torch.float64, torch.float32):
-        Pl = P0.detach().to(dt).requires_grad_(True)
-        bl, ql = bi.detach().to(dt).requires_grad_(True), q.detach().to(dt).requires_grad_(True)
-        Y = ref_fuse(Pl + bl, ql, N, L, normalise=not linked)
-        dP, db, dq = torch.autograd.grad(Y, [Pl, bl, ql], linked_cotangent(Y, rec["dout"].to(dt), N) if linked else rec["dout"].to(dt))
-        res[dt] = (Y.detach(), dP, db, dq)
-        del Pl, Y
-    y_err = _nrel(out, res[torch.float64][0])
-    assert y_err <= 1e-5, ("MfbFuseFn Y", y_err)
-    assert grads[0].dtype == torch.bfloat16
-    worst = _cond_check("MfbFuseFn dP (bf16)", grads[0].float(), res[torch.float64][1], res[torch.float32][1], floor=5e-3)
-    worst = max(worst, _cond_check("MfbFuseFn dbias", grads[1], res[torch.float64][2], res[torch.float32][2]))
-    worst = max(worst, _cond_check("MfbFuseFn dq", grads[2], res[torch.float64][3], res[torch.float32][3]))
-    rep.append("MfbFuseFn[bf16 P/dP]%s N=%d: Y %.1e, grads err/bound %.2f" % ("[linked]" if linked else "", N, y_err, worst))
-
-
-def _check_final_mfb(rec, out, grads, rep, saved):
-    qa, va, wq, bq, wv, bv, keep, seed, p_drop, cascade, want_zdrop, bf16 = (list(rec["args"]) + [None, False, False])[:12]
-    assert keep is None and p_drop == 0.0 and cascade is None and not want_zdrop
-    N = qa.shape[0]
-    qq_k, vv_k = saved[4], saved[5]               # saved: (qa_s, va_s, wq, wv, qq, vv, y, norm, inv, keep, cascade, wqb, wvb)
-    bf16 = bool(bf16) and all(d % 8 == 0 for d in (N, qa.shape[1], va.shape[1], wq.shape[0]))
-    rnd = bf if bf16 else (lambda t: t)
-    qa_o, va_o, wq_o, wv_o = rnd(qa.detach()), rnd(va.detach()), rnd(wq.detach()), rnd(wv.detach())
-    tol = BENIGN_TOL_BF16 if bf16 else BENIGN_TOL_F32
-    e_proj = max(_nrel(qq_k, qa_o.double() @ wq_o.double().t() + bq.detach().double()),
-                 _nrel(vv_k, va_o.double() @ wv_o.double().t() + bv.detach().double()))
-    assert e_proj <= tol, ("FinalMfbFn projections", e_proj)
-    res = {}
-    for dt in (torch.float64, torch.float32):
-        ql, vl = qq_k.to(dt).requires_grad_(True), vv_k.to(dt).requires_grad_(True)
-        y = ref_fuse(vl, ql, N, 1)
-        dvv, dqq = torch.autograd.grad(y, [vl, ql], rec["dout"].to(dt))
-        dqo, dvo = rnd(dqq).double(), rnd(dvv).double()
-        res[dt] = (y.detach(), dqo @ wq_o.double(), dvo @ wv_o.double(), dqo.t() @ qa_o.double(), dqq.double().sum(0),
-                   dvo.t() @ va_o.double(), dvv.double().sum(0))
-    y_err = _nrel(out, res[torch.float64][0])
-    assert y_err <= 1e-5, ("FinalMfbFn y", y_err)
-    worst = 0.0
-    for i in range(6):
-        if i in grads and grads[i] is not None:
-            worst = max(worst, _cond_check("FinalMfbFn grad of arg %d" % i, grads[i], res[torch.float64][1 + i], res[torch.float32][1 + i]))
-    rep.append("FinalMfbFn%s: proj %.1e, y %.1e, grads err/bound %.2f" % ("[bf16]" if bf16 else "", e_proj, y_err, worst))
-
-
-def _check_lstm_seq(rec, out, grads, rep):
-    x, w_ih, w_hh, b_ih, b_hh, bf16 = (list(rec["args"]) + [False])[:6]
-    dt = torch.float64
-    leaves = [t.detach().to(dt).requires_grad_(True) for t in (x, w_ih, w_hh, b_ih, b_hh)]
-    batch_form = rec["cls"].__name__ == "LstmBatchFn"
-    if batch_form and bf16 and w_hh.shape[1] % 8:
-        bf16 = False                                           # functions.LstmBatchFn: bf16 needs H % 8 == 0
-    if batch_form and bf16 == "all" and x.shape[1] % 8:
-        wg = False                                             # ... and its bf16 recurrent weight gradient B % 8 == 0
-    else:
-        wg = (bf16 == "all") if batch_form else True
-    hs = ref_lstm_seq(*leaves, bf16, wg)
-    want = [i for i in range(5) if i in grads and grads[i] is not None]
-    g64 = torch.autograd.grad(hs, [leaves[i] for i in want], rec["dout"].double())
-    tol = BENIGN_TOL_BF16 if bf16 else BENIGN_TOL_F32
-    worst = _nrel(out, hs)
-    assert worst <= tol, ("LstmSeqFn hs", worst)
-    for i, g in zip(want, g64):
-        e = _nrel(grads[i], g)
-        assert e <= tol, ("%s grad of arg %d (bf16=%r)" % (rec["cls"].__name__, i, bf16), e)
-        worst = max(worst, e)
-    rep.append("%s[bf16=%r] S=%d: %.1e" % (rec["cls"].__name__, bf16, x.shape[0], worst))
-
-
-def check_every_node(model, recd, label, min_links=3, skip_params=("word_embedding.weight",)):
-    """Replays every recorded node of the step that `model` has just run (forward + backward) alone and checks wiring and
-    numerics as the module docstring says.  -> the report line."""
-    import vqa_amd
-    params = {id(p): (k, p) for k, p in model.named_parameters()}
-    produced = {id(r["out"]): r for r in recd.records}
-    into = {}                                    # id(intermediate tensor) -> list of node-local gradients handed to it
-    seen_params, rep = set(), []
-    # a fusion node with a NormLink and the attention head that consumes its output share the link object: the head's backward
-    # leaves (dlogits, lin) in it for the fusion node's backward.  Replayed alone, the head goes first and the fusion node gets
-    # that pair back between its forward (which re-arms the link) and its backward.
-    cache = {}
-    for rec in recd.records:
-        name = rec["cls"].__name__
-        link = (rec["args"][8] if len(rec["args"]) > 8 else None) if name in ("ImgFuseFn", "MfbFuseFn") else None
-        if link is not None:
-            head = [r for r in recd.records if r["cls"].__name__ == "AttHeadFn" and len(r["args"]) > 10 and r["args"][10] is link]
-            assert len(head) == 1
-            cache[id(head[0])] = recd.replay(head[0])
-            lin = link.lin
-            assert lin is not None
-            out2, grads, saved = recd.replay(rec, between=lambda: setattr(link, "lin", lin))
-        elif id(rec) in cache:
-            out2, grads, saved = cache.pop(id(rec))
-        else:
-            out2, grads, saved = recd.replay(rec)
-        torch.cuda.synchronize()
-        assert torch.equal(out2, rec["out"]), (rec["cls"].__name__, "a node replayed alone is not bit-identical")
-        for i, g in grads.items():
-            a = rec["args"][i]
-            if id(a) in params and g is not None:
-                k, p = params[id(a)]
-                assert torch.equal(g, p.grad), (k, "model-level gradient is not this node's gradient, bit for bit")
-                seen_params.add(k)
-            elif g is not None:
-                # a consumer may take a VIEW of a producer's output (AttHeadFn gets hs and hs.view(N*T, H)): credit the base
-                base = a._base if (a._base is not None and id(a._base) in produced) else a
-                into.setdefault(id(base), []).append(g.reshape(base.shape))
-        name = rec["cls"].__name__
-        if name == "LinearFn":
-            _check_linear(rec, out2, grads, rep)
-        elif name == "LogSoftmaxRowsFn":
-            _check_logsoftmax(rec, out2, grads, rep)
-        elif name == "AttHeadFn":
-            _check_att_head(rec, out2, grads, rep)
-        elif name == "ImgFuseFn":
-            _check_img_fuse(rec, out2, grads, rep, saved)
-        elif name == "ImgProjLateFn":
-            _check_img_proj_late(rec, out2, grads, rep)
-        elif name == "MfbFuseFn":
-            _check_mfb_fuse(rec, out2, grads, rep)
-        elif name == "FinalMfbFn":
-            _check_final_mfb(rec, out2, grads, rep, saved)
-        elif name in ("LstmSeqFn", "LstmBatchFn"):
-            _check_lstm_seq(rec, out2, grads, rep)
-        del out2, grads, saved
-        torch.cuda.empty_cache()
-    # every parameter except the embedding (a torch op upstream of the first node) was produced by exactly one node
-    assert seen_params == {k for k, _ in model.named_parameters()} - set(skip_params)
-    # chain wiring: what the consumers hand to an intermediate adds up to the gradient recorded at its producer
-    n_links = 0
-    for tid, gs in into.items():
-        if tid in produced:
-            tot = gs[0].double()
-            for g in gs[1:]:
-                tot = tot + g.double()
-            e = _nrel(tot, produced[tid]["dout"])
-            assert e <= 1e-6, (produced[tid]["cls"].__name__, "consumers' gradients do not add up to the producer's", e)
-            n_links += 1
-    assert n_links >= min_links                  # qa (3 consumers), qp, Y, va (2), logits
-    line = label + ": " + " | ".join(rep)
-    print(line)
-    import os
-    root = os.environ.get("GRAFT_REPO_ROOT")
-    if root and os.path.isdir(os.path.join(root, "gpurun_out")):
-        with open(os.path.join(root, "gpurun_out", "grad_parity.log"), "a") as f:
-            f.write(line + "\n")
-    return line
 
 
 @pytest.mark.parametrize("bf16_mode", ["bf16", "bf16-all", "bf16-side"])

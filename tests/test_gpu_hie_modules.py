@@ -364,7 +364,7 @@ def test_hiecoatten_philox_masks_are_the_same_in_every_form():
             assert d <= 1e-4 * float(g.norm()) + 1e-6 * gmax, (form, k, d, float(g.norm()))
 
 
-def test_config4_hiecoatten_full_batch_256_gradients_vs_oracle():
+def test_config4_hiecoatten_full_batch_256_gradients_vs_oracle(monkeypatch):
     """BASELINE config 4 at its full batch, every output and every gradient: HieCoAtten, B=256, 196 regions x 2048,
     fp32, dropout off, against the oracle run on the same batch in fp32 and fp64 (forward 1e-4, gradients by
     grad_parity).  These are the shapes of the bench line for this model: the 50176-row img_emb GEMM, its
@@ -378,13 +378,20 @@ def test_config4_hiecoatten_full_batch_256_gradients_vs_oracle():
     img = torch.relu(torch.randn((N, L, 2048), generator=torch.Generator().manual_seed(4331)))
     q = torch.randint(1, 1000, (N, T), generator=torch.Generator().manual_seed(4332))
     ans = torch.randint(0, 1000, (N,), generator=torch.Generator().manual_seed(4333))
+    from node_harness import Recorder, check_every_node, ALL_NODES
+    recd = Recorder(monkeypatch, vqa.functions, ALL_NODES)
     x, av, aq = model.forward(img.cuda(), q.cuda())
     torch.nn.CrossEntropyLoss()(x, ans.cuda()).backward()
     torch.cuda.synchronize()
+    assert [r["cls"].__name__ for r in recd.records] == ["HieCoreFn", "LinearFn"]
+    # the ladder (one autograd node) and the classifier against their own fp64 evaluations on the same operands
+    _, covered = check_every_node(model, recd, "config 4 (HieCoAtten, fp32) node checks at B=256", min_links=1, skip_params=())
+    del recd
     (ox, oav, oaq), g32, g64 = _hie_oracle_pair(case, img, q, ans)
     assert rel_err(x.detach().cpu().numpy(), ox.numpy()) <= OUT_TOL
     assert rel_err(av.detach().cpu().numpy(), oav.numpy()) <= OUT_TOL
     assert rel_err(aq.detach().cpu().numpy(), oaq.numpy()) <= OUT_TOL
     grads = _grads(model)
     assert float(grads["img_emb.weight"].abs().max()) > 0.0 and model.fc_Wbq.weight.grad is None
-    grad_parity(grads, g32, g64)
+    assert covered == {k for k, g in grads.items() if g is not None}
+    grad_parity(grads, g32, g64, node_checked=covered)

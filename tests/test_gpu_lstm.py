@@ -164,17 +164,25 @@ def test_mfb_hip_lstm_equals_miopen_lstm():
 
 
 @pytest.mark.parametrize("B,H", [(512, 1024), (128, 256), (256, 768)])
-def test_fused_lstm_step_is_bit_identical_to_product_plus_cell(B, H):
-    """vqf_lstm_step_fwd (recurrent product with the cell in its epilogue, gate-interleaved W_hh rows) against
-    vqf_gemm_f32(VQF_GEMM_ACCUM) + vqf_lstm_cell_fwd on the same operands: activated gates, c and h BIT-identical, with and
-    without a previous cell state; then the module-level sequence (LstmBatchFn, T = 5) both ways incl. gradients."""
+def test_fused_lstm_step_vs_fp64_and_bitwise_where_the_k_order_is_shared(B, H):
+    """vqf_lstm_step_fwd (recurrent product with the cell in its epilogue, gate-interleaved W_hh rows) and the two-launch form
+    vqf_gemm_f32(VQF_GEMM_ACCUM) + vqf_lstm_cell_fwd on the same operands.  Neither is the other's reference: EACH is bounded
+    against an fp64 product + cell (activated gates, c, h; max-abs relative to the largest entry): 2e-6 * max(1, sqrt(H) / 8) for
+    the fp32 accumulation over K = H + 5e-7 for the fast tanh / sigmoid (1e-7 absolute each).  Where both products run on the
+    per-wave kernel they add k in the same order and must agree BIT for bit (the headline shape does); where the two-launch
+    form is a split-K product the sums are re-associated and only the fp64 bounds apply (round 4 compared the two forms with
+    each other and widened that tolerance after a red run: 2.2e-6 measured at K = 768, each side ~1e-6 from fp64).
+    Then the module-level sequence (LstmBatchFn, T = 5) both ways incl. gradients, the same way."""
     import vqa_amd
+    from node_harness import ref_lstm_seq, gemm_tol, LSTM_BATCH_TOL_F32
     ops = vqa_amd.ops
     assert ops.lstm_step_supported(B, H) and not ops.lstm_step_supported(B + 32, H) and not ops.lstm_step_supported(B, 64)
     g = torch.Generator().manual_seed(B + H)
     r = lambda *s: ((torch.rand(s, generator=g) * 2 - 1)).cuda()
     h_prev, w_hh, pre, c_prev = r(B, H), r(4 * H, H) * 0.05, r(B, 4 * H) * 1.5, r(B, H)
+    step_tol = gemm_tol(H) + 5e-7
     same_order = True
+    worst = 0.0
     for cp in (c_prev, None):
         g1, c1, h1 = pre.clone(), torch.empty(B, H, device="cuda"), torch.empty(B, H, device="cuda")
         ops.lstm_step_fwd(h_prev, w_hh, g1, cp, c1, h1)
@@ -183,30 +191,44 @@ def test_fused_lstm_step_is_bit_identical_to_product_plus_cell(B, H):
         ops.gemm(h_prev, w_hh, out=g2, accumulate=True)
         same_order = ops.stat("gemm_f32_wave") == n0 + 1      # the two-launch product ran on the per-wave kernel: one k-ordered chain
         ops.lstm_cell_fwd(g2, cp, c2, h2)
+        # fp64 product + cell (gate order i, f, g, o: torch.nn.LSTM's)
+        p64 = pre.double() + h_prev.double() @ w_hh.double().t()
+        i64, f64, gg64, o64 = p64.chunk(4, dim=1)
+        act64 = torch.cat((torch.sigmoid(i64), torch.sigmoid(f64), torch.tanh(gg64), torch.sigmoid(o64)), 1)
+        c64 = torch.sigmoid(i64) * torch.tanh(gg64) + (torch.sigmoid(f64) * cp.double() if cp is not None else 0.0)
+        h64 = torch.sigmoid(o64) * torch.tanh(c64)
+        for form, (ga, ca, ha) in (("fused step", (g1, c1, h1)), ("product + cell", (g2, c2, h2))):
+            for what, got, ref in (("gates", ga, act64), ("c", ca, c64), ("h", ha, h64)):
+                e = _rel(got, ref)
+                assert e <= step_tol, (form, what, e, step_tol)
+                worst = max(worst, e)
         if same_order:
             assert torch.equal(g1, g2) and torch.equal(c1, c2) and torch.equal(h1, h2)
-        else:                                                   # (a split-K product re-associates the sum: rounding only)
-            assert _rel(g1, g2) <= 1e-5 and _rel(c1, c2) <= 1e-5 and _rel(h1, h2) <= 1e-5
+    print("lstm step B=%d H=%d: both forms vs fp64 worst %.2e (bound %.2e); same k order: %s" % (B, H, worst, step_tol, same_order))
     if B == 512 and H == 1024:
         assert same_order, "the headline shape's two-launch form is the per-wave kernel"
     fn = vqa_amd.functions.LstmBatchFn
     x = r(5, B, 40)
     ps = [r(4 * H, 40) * 0.1, w_hh, r(4 * H) * 0.1, r(4 * H) * 0.1]
+    wgt = torch.linspace(-1, 1, 5 * B * H, device="cuda").view(5, B, H)
+    l64 = [t.double().requires_grad_() for t in ps]
+    hs64 = ref_lstm_seq(x.double(), *l64, False)
+    (hs64 * wgt.double()).sum().backward()
     res = []
     for fused in (True, False):
         fn.FUSED_STEP = fused
         try:
             leaves = [p.clone().requires_grad_() for p in ps]
             hs = fn.apply(x, *leaves)
-            (hs * torch.linspace(-1, 1, hs.numel(), device="cuda").view_as(hs)).sum().backward()
+            (hs * wgt).sum().backward()
             res.append((hs.detach(), [p.grad for p in leaves]))
         finally:
             fn.FUSED_STEP = True
+        nrel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+        assert nrel(hs.detach(), hs64.detach()) <= LSTM_BATCH_TOL_F32, ("fused" if fused else "two-launch", "hs")
+        for a, b in zip(res[-1][1], l64):
+            assert nrel(a, b.grad) <= LSTM_BATCH_TOL_F32, ("fused" if fused else "two-launch", "gradient", nrel(a, b.grad))
     if same_order:
         assert torch.equal(res[0][0], res[1][0])
         for a, b in zip(res[0][1], res[1][1]):
             assert torch.equal(a, b)
-    else:
-        assert _rel(res[0][0], res[1][0]) <= 1e-5
-        for a, b in zip(res[0][1], res[1][1]):
-            assert _rel(a, b) <= 1e-4

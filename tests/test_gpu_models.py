@@ -17,6 +17,7 @@ import recipe
 from cases import MFB_CASES, MHBCOATT_CASES, MHB_CASES, make_cfg
 from golden_util import load_golden, recipe_sd, mfb_inputs, rel_err, check_grads, grad_parity
 from oracle import ref_torch as O
+from node_harness import Recorder, check_every_node, ALL_NODES
 
 pytestmark = pytest.mark.gpu
 
@@ -405,8 +406,10 @@ def test_pruned_mode_is_bit_identical_to_faithful(multilayer):
     assert any(float(g.abs().max()) > 0 for k, g in res[True][1].items() if not k.startswith(dead))
 
 
-def test_config2_mfb_batch_512_gradients_vs_oracle_live_softmax():
-    """BASELINE config 2 at its full batch, gradients: MFB, B=512, 196x2048, fp32, with
+def test_config2_mfb_batch_512_gradients_vs_oracle_live_softmax(monkeypatch):
+    """(round 5: every autograd node of this step is also checked against its own fp64 evaluation, tests/node_harness.py,
+    and every tensor whose model-level fp32 noise exceeds 5 % of its gradient must be covered by such a check.)
+    BASELINE config 2 at its full batch, gradients: MFB, B=512, 196x2048, fp32, with
     `unit_softmax=False` so that EVERY tensor is live -- in faithful mode dY == 0 and the image projection's
     weight gradient multiplies zeros.  The HIP gradients (large-tile forward GEMM, K=100352 split-K weight
     gradient, fusion kernels at N*L = 100352 rows) against the oracle in fp32 and fp64 on the same inputs,
@@ -421,10 +424,13 @@ def test_config2_mfb_batch_512_gradients_vs_oracle_live_softmax():
     img = torch.relu(torch.randn((512, 196, 2048), generator=g))
     q = torch.randint(1, 1000, (512, 14), generator=torch.Generator().manual_seed(1235))
     a = torch.randint(0, 1000, (512,), generator=torch.Generator().manual_seed(1236))
+    recd = Recorder(monkeypatch, vqa.functions, ALL_NODES)
     out = model.forward(img.cuda(), q.cuda())
     torch.nn.CrossEntropyLoss()(out, a.cuda()).backward()
     torch.cuda.synchronize()
     grads = _named_grads(model)
+    _, covered = check_every_node(model, recd, "config 2 (MFB live softmax, fp32) node checks at B=512", skip_params=())
+    del recd
     res = []
     for dt in (torch.float32, torch.float64):
         sd = {k: v.to(dt).requires_grad_(True) for k, v in recipe_sd(O.mfb_shapes(cfg), case["salt"]).items()}
@@ -434,10 +440,11 @@ def test_config2_mfb_batch_512_gradients_vs_oracle_live_softmax():
         del sd, o
     assert rel_err(out.detach().cpu().numpy(), res[0][0].numpy()) <= OUT_TOL
     assert float(grads["img_conv1d.weight"].abs().max()) > 0.0 and float(grads["co_att_conv1.weight"].abs().max()) > 0.0
-    grad_parity(grads, res[0][1], res[1][1])
+    assert covered == set(grads)
+    grad_parity(grads, res[0][1], res[1][1], node_checked=covered)
 
 
-def test_config2_mfb_batch_512_faithful_gradients_vs_oracle():
+def test_config2_mfb_batch_512_faithful_gradients_vs_oracle(monkeypatch):
     """The exact mode bench.py times (VERDICT r02 weak #1a): MFB-baseline, B=512, fp32, FAITHFUL (`unit_softmax=True`: the
     reference's singleton-axis softmaxes, mfb.py:84,118), forward + backward, against the oracle in fp32 and fp64 on the
     same inputs.  Live tensors (embedding, LSTM, ques_proj2, img_proj2, linear_pred) by grad_parity; the 12 tensors whose
@@ -454,10 +461,17 @@ def test_config2_mfb_batch_512_faithful_gradients_vs_oracle():
     img = torch.relu(torch.randn((512, 196, 2048), generator=torch.Generator().manual_seed(1234)))
     q = torch.randint(1, 1000, (512, 14), generator=torch.Generator().manual_seed(1235))
     a = torch.randint(0, 1000, (512,), generator=torch.Generator().manual_seed(1236))
+    recd = Recorder(monkeypatch, vqa.functions, ALL_NODES)
     out = model.forward(img.cuda(), q.cuda())
     vqa.CrossEntropyLoss()(out, a.cuda()).backward()      # the HIP criterion, as in bench.py
     torch.cuda.synchronize()
     grads = _named_grads(model)
+    kinds = [r["cls"].__name__ for r in recd.records]
+    assert kinds == ["ImgProjDeferFn", "EmbedTanhFn", "LstmBatchFn", "DropoutBTFn", "AttHeadFn", "LinearFn", "MfbFuseFn", "AttHeadFn",
+                     "FinalMfbFn", "LinearFn"], kinds
+    # every node of the step bench.py times against its own fp64 evaluation (the dead ones: exact zeros)
+    _, covered = check_every_node(model, recd, "config 2 (MFB faithful, fp32, the headline step) node checks at B=512", skip_params=())
+    del recd
     res = []
     for dt in (torch.float32, torch.float64):
         sd = {k: v.to(dt).requires_grad_(True) for k, v in recipe_sd(O.mfb_shapes(cfg), case["salt"]).items()}
@@ -477,10 +491,11 @@ def test_config2_mfb_batch_512_faithful_gradients_vs_oracle():
         else:
             assert float(g.abs().max()) > 0.0, (k, "live tensor without a gradient")
     assert n_dead == 12
-    grad_parity({k: g for k, g in grads.items() if not k.startswith(dead)}, res[0][1], res[1][1])
+    assert covered == set(grads)
+    grad_parity({k: g for k, g in grads.items() if not k.startswith(dead)}, res[0][1], res[1][1], node_checked=covered)
 
 
-def test_config3_shapes_mhbcoatt_batch_512_fp32_gradients_vs_oracle():
+def test_config3_shapes_mhbcoatt_batch_512_fp32_gradients_vs_oracle(monkeypatch):
     """MHBCoAtt at the full B=512 in fp32, every output row and every gradient against the oracle run on the SAME
     512-sample batch in fp32 and fp64 (the batch-axis LSTM recursion, mhb_coAtt.py:72-74, makes row n depend on rows
     0..n-1, so only the whole batch exercises the 512-step chain and its backward): forward 1e-4, gradients by
@@ -494,10 +509,13 @@ def test_config3_shapes_mhbcoatt_batch_512_fp32_gradients_vs_oracle():
     img = torch.relu(torch.randn((512, 196, 2048), generator=torch.Generator().manual_seed(1234)))
     q = torch.randint(1, 1000, (512, 14), generator=torch.Generator().manual_seed(1235))
     soft = torch.softmax(torch.randn((512, 1000), generator=torch.Generator().manual_seed(1236)), 1)
+    recd = Recorder(monkeypatch, vqa.functions, ALL_NODES)
     out = model.forward(img.cuda(), q.cuda())
     torch.nn.KLDivLoss()(out, soft.cuda()).backward()
     torch.cuda.synchronize()
     grads = _named_grads(model)
+    _, covered = check_every_node(model, recd, "config 3 shapes (MHBCoAtt, fp32) node checks at B=512", skip_params=())
+    del recd
     res = []
     for dt in (torch.float32, torch.float64):
         sd = {k: v.to(dt).requires_grad_(True) for k, v in recipe_sd(O.mfb_shapes(cfg, mhb=True), case["salt"]).items()}
@@ -508,7 +526,8 @@ def test_config3_shapes_mhbcoatt_batch_512_fp32_gradients_vs_oracle():
     assert rel_err(out.detach().cpu().numpy(), res[0][0].numpy()) <= OUT_TOL
     assert rel_err(out.detach().cpu().numpy(), res[1][0].float().numpy()) <= OUT_TOL
     assert float(grads["img_conv1d.weight"].abs().max()) > 0.0 and float(grads["lstm.weight_hh_l0"].abs().max()) > 0.0
-    grad_parity(grads, res[0][1], res[1][1])
+    assert covered == set(grads)
+    grad_parity(grads, res[0][1], res[1][1], node_checked=covered)
 
 
 @pytest.mark.parametrize("bf16_mode", ["bf16", "bf16-all"])
