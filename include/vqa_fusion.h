@@ -40,7 +40,8 @@ extern "C" {
 #define VQF_E_ALIGN (-2)       /* pointer or leading dimension not 16-B aligned where required */
 #define VQF_E_UNSUPPORTED (-3) /* shape outside what the kernel supports     */
 #define VQF_E_WORKSPACE (-4)   /* caller's scratch buffer too small          */
-#define VQF_E_TIMEOUT (-5)     /* an in-launch hand-off timed out (vqf_lstm_persist_status) */
+#define VQF_E_TIMEOUT (-5)     /* reserved: no entry point of the product build returns it (the whole-sequence LSTM whose in-launch
+                                  hand-off could time out left the library in ABI 5: tools/variants/README.md) */
 
 #define VQF_POOL_K 5           /* mfb.py:100  .view(N, L, 1000, 5)           */
 
@@ -52,7 +53,8 @@ extern "C" {
 
 /* ABI version (2: LSTM entry points take a workspace and flags, large-tile GEMMs, solver tail, staging; 4: library
  * options, row-scaled GEMM; 5: the whole-sequence LSTM entry points left the library, HBM yardsticks, fused epilogues of
- * the HieCoAtten path) and build information ("libvqa_fusion gfx950 fp32-mfma(...) tiles ...") */
+ * the HieCoAtten path; 6: vqf_gate_tanh_sigmoid_*, per-sample-tile GEMM entry points, stated tanh accuracy contract) and
+ * build information ("libvqa_fusion gfx950 fp32-mfma(...) tiles ...") */
 int vqf_abi_version(void);
 const char* vqf_build_info(void);
 
@@ -353,7 +355,16 @@ int vqf_dropout_f32(const float* x, const uint8_t* keep, uint64_t seed, float p_
  * keep: (B*T, H) uint8).  H and every stride % 4 == 0. */
 int vqf_dropout_bt(const float* x, long long sb_in, long long st_in, const uint8_t* keep, uint64_t seed, float p_drop, int B,
                    int T, int H, float* y, long long sb_out, long long st_out, void* stream);
-/* y = dropout(tanh(a + b))  (b may be NULL)   hieCoAtten.py:32-33,38-39,45-46 */
+/* The gate of modules.py:103-109 (Nonlinear_layer.forward): y = tanh(a) * sigmoid(b) over n elements (n % 4 == 0, 16-byte aligned
+ * pointers), and its backward from the saved inputs: da = dy * sigmoid(b) * (1 - tanh(a)^2), db = dy * tanh(a) * sigmoid(b) *
+ * (1 - sigmoid(b)).  libm tanhf / expf (1-2 ulp). */
+int vqf_gate_tanh_sigmoid_fwd(const float* a, const float* b, long long n, float* y, void* stream);
+int vqf_gate_tanh_sigmoid_bwd(const float* dy, const float* a, const float* b, long long n, float* da, float* db, void* stream);
+/* y = dropout(tanh(a + b))  (b may be NULL)   hieCoAtten.py:32-33,38-39,45-46.
+ * Accuracy contract of the tanh in THIS entry point, in vqf_tanh_dropout_fwd2d and in vqf_hie_hv_fwd: (e^2x - 1) / (e^2x + 1) with
+ * the hardware exponential and reciprocal -- ABSOLUTE error <= 2e-7 everywhere, i.e. relative accuracy is lost for |x| < 1e-3
+ * (6 % at x = 1e-6).  Their consumers are bounded activations in front of a softmax (hieCoAtten.py:32-46); the entry points a
+ * chain of steps feeds on (vqf_lstm_*, vqf_embed_tanh_*, vqf_gate_tanh_sigmoid_*) use libm's tanhf (1 ulp relative). */
 int vqf_tanh_dropout_fwd(const float* a, const float* b, const uint8_t* keep, uint64_t seed,
                          float p_drop, long long n, float* y, void* stream);
 /* dx = dy * keep/(1-p) * (1 - tanh^2), tanh recovered from the saved output y */

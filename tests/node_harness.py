@@ -282,6 +282,7 @@ def _check_logsoftmax(rec, out, grads, rep):
 def _check_att_head(rec, out, grads, rep, saved):
     x, feat, w1, b1, wm, bm, w2, b2, unit, bf16 = rec["args"][:10]
     link = rec["args"][10] if len(rec["args"]) > 10 else None
+    same_src = bool(rec["args"][11]) if len(rec["args"]) > 11 else False     # x = feat.view(N*S, C): ONE gradient, handed to feat
     assert wm is None
     unit = bool(unit)
     inv_rows = link.inv.detach().double().repeat_interleave(link.L) if link is not None else None
@@ -294,6 +295,9 @@ def _check_att_head(rec, out, grads, rep, saved):
         leaves[1] = _dbl(feat, dt)
     for t in leaves.values():
         t.requires_grad_(True)
+    if same_src and grads.get(0) is None:        # the MLP reads the pooled tensor itself: its input gradient landed in feat's
+        assert 1 in leaves                       # (the bf16 head returns the two gradients separately)
+        leaves[0] = leaves[1].view(x.shape)
     y = ref_att_head(leaves[0], leaves.get(1, _dbl(feat, dt)), leaves[2], leaves[3], leaves[6], leaves[7], bf16, inv_rows, unit, mask)
     tol = BENIGN_TOL_BF16 if bf16 else ATT_TOL_F32
     worst = _nrel(out, y)

@@ -511,3 +511,54 @@ def test_embed_plain_lookup_is_exact(ops):
     ref = torch.zeros((300, 40), dtype=torch.float64).index_add_(0, q.cpu().reshape(-1), up.double().cpu().reshape(-1, 40))
     assert _rel(emb.weight.grad, ref) <= 1e-6
     assert torch.equal(emb.weight.grad, ops.embed_tanh_bwd(up, None, q, 300))
+
+
+def test_linear2_equals_the_linear_of_the_concatenation():
+    """Linear2Fn (mhb_coAtt.py:147-148,213-214: linear_pred(cat((y2, y3), 1)) without the concatenated tensor): output and
+    every gradient against fp64 of the concatenated form, and against LinearFn on a torch.cat of the same operands."""
+    import vqa_amd
+    F = vqa_amd.functions
+    g = torch.Generator().manual_seed(77)
+    M, K1, K2, N = 512, 1000, 1000, 1000
+    x1, x2 = torch.randn((M, K1), generator=g).cuda(), torch.randn((M, K2), generator=g).cuda()
+    w, b = (torch.randn((N, K1 + K2), generator=g) * 0.03).cuda(), torch.randn(N, generator=g).cuda()
+    dy = torch.randn((M, N), generator=g).cuda()
+    leaves = [t.clone().requires_grad_() for t in (x1, x2, w, b)]
+    y = F.Linear2Fn.apply(*leaves)
+    y.backward(dy)
+    l64 = [t.double().requires_grad_() for t in (x1, x2, w, b)]
+    y64 = torch.cat((l64[0], l64[1]), 1) @ l64[2].t() + l64[3]
+    y64.backward(dy.double())
+    nrel = lambda a, r: float((a.double() - r).norm() / r.norm())
+    assert nrel(y.detach(), y64.detach()) <= 2e-6 * (K1 + K2) ** 0.5 / 8
+    for a, r, k in zip(leaves, l64, (N, N, M, M)):
+        assert nrel(a.grad, r.grad) <= 2e-6 * max(1.0, k ** 0.5 / 8), (tuple(a.shape), nrel(a.grad, r.grad))
+    xc = torch.cat((x1, x2), 1).requires_grad_()
+    wc, bc = w.clone().requires_grad_(), b.clone().requires_grad_()
+    yc = F.LinearFn.apply(xc, wc, bc)
+    yc.backward(dy)
+    assert nrel(y.detach(), yc.detach().double()) <= 1e-6 and nrel(leaves[2].grad, wc.grad.double()) <= 1e-6
+    assert torch.equal(leaves[3].grad, bc.grad)
+
+
+def test_gate_tanh_sigmoid_kernel_vs_fp64():
+    """vqf_gate_tanh_sigmoid_fwd / _bwd (modules.py:103-109, Nonlinear_layer's tanh(W1 x) * sigmoid(W2 x)) against fp64."""
+    import vqa_amd
+    F = vqa_amd.functions
+    g = torch.Generator().manual_seed(78)
+    a, b = (torch.randn((300, 516), generator=g) * 3).cuda(), (torch.randn((300, 516), generator=g) * 3).cuda()
+    dy = torch.randn((300, 516), generator=g).cuda()
+    la, lb = a.clone().requires_grad_(), b.clone().requires_grad_()
+    y = F.GateFn.apply(la, lb)
+    y.backward(dy)
+    a64, b64 = a.double().requires_grad_(), b.double().requires_grad_()
+    y64 = torch.tanh(a64) * torch.sigmoid(b64)
+    y64.backward(dy.double())
+    for got, ref in ((y.detach(), y64.detach()), (la.grad, a64.grad), (lb.grad, b64.grad)):
+        assert float((got.double() - ref).abs().max()) <= 5e-7 * max(1.0, float(ref.abs().max()))
+    from importlib import import_module
+    m = import_module("vqa-attention-networks_amd.host.modules").Nonlinear_layer(516).cuda()
+    x = torch.randn((7, 12, 516), generator=g).cuda()
+    out = m(x)
+    ref = torch.tanh(m.fc1(x)) * torch.sigmoid(m.fc2(x))
+    assert float((out - ref).abs().max()) <= 2e-5

@@ -84,6 +84,7 @@ int vqf_colreduce_2stage(const float* in, int J, int W, float* out, float* scrat
 
 int vqf_splitk_reduce(const float* slab, int splits, int M, int N, float* C, int ldc,
                       const float* bias, int flags, hipStream_t s);   // gemm_f32.hip
+void vqf_splitk_counters_clear(int* words, int tiles, hipStream_t s);   // after a launch that did not return VQF_OK
 int* vqf_splitk_counters(int tiles);   // gemm_f32.hip: `tiles` zero words of the in-launch split-K combine's counter ring, or nullptr
 
 // gemm_bf16_big.hip: 256x256-tile kernel; returns 0 when it does not apply to the shape

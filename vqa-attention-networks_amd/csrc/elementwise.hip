@@ -113,6 +113,33 @@ __global__ void dropout_bt_kernel(const float* __restrict__ x, long long sb_in, 
   }
 }
 
+// The gate of modules.py:103-109 (Nonlinear_layer): y = tanh(a) * sigmoid(b), and its backward from the inputs:
+// da = dy * sigmoid(b) * (1 - tanh(a)^2), db = dy * tanh(a) * sigmoid(b) * (1 - sigmoid(b)).  tanhf / expf of libm accuracy class
+// (the modules of networks.py chain six such layers).
+template <bool BWD>
+__global__ void gate_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ dy, long long n4,
+                            float* __restrict__ o1, float* __restrict__ o2) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const f32x4 x = *reinterpret_cast<const f32x4*>(a + 4 * i), z = *reinterpret_cast<const f32x4*>(b + 4 * i);
+    f32x4 r1, r2;
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+    if (BWD) g = *reinterpret_cast<const f32x4*>(dy + 4 * i);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float t = tanhf(x[j]), sg = 1.0f / (1.0f + expf(-z[j]));
+      if (BWD) {
+        r1[j] = g[j] * sg * (1.0f - t * t);
+        r2[j] = g[j] * t * sg * (1.0f - sg);
+      } else {
+        r1[j] = t * sg;
+      }
+    }
+    *reinterpret_cast<f32x4*>(o1 + 4 * i) = r1;
+    if (BWD) *reinterpret_cast<f32x4*>(o2 + 4 * i) = r2;
+  }
+}
+
 // one wave per row
 __global__ void softmax_rows_fwd_kernel(const float* __restrict__ x, int R, int W, float* __restrict__ y) {
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -262,6 +289,28 @@ int vqf_tanh_dropout_bwd(const float* dy, const float* y, const uint8_t* keep, u
   if (rc) return rc;
   if (!y || !aligned16(y)) return VQF_E_BADARG;
   return ew_launch<2>(KID_TANH_DROP_BWD, dy, y, keep, seed, p_drop, n, dx, stream);
+}
+
+int vqf_gate_tanh_sigmoid_fwd(const float* a, const float* b, long long n, float* y, void* stream) {
+  if (!a || !b || !y || n <= 0) return VQF_E_BADARG;
+  if (n % 4) return VQF_E_UNSUPPORTED;
+  if (!aligned16(a) || !aligned16(b) || !aligned16(y)) return VQF_E_ALIGN;
+  long long blocks = (n / 4 + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  VQF_LAUNCH(KID_TANH_DROP_FWD, gate_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, b,
+             (const float*)nullptr, n / 4, y, (float*)nullptr);
+  return vqf_last_error();
+}
+
+int vqf_gate_tanh_sigmoid_bwd(const float* dy, const float* a, const float* b, long long n, float* da, float* db, void* stream) {
+  if (!dy || !a || !b || !da || !db || n <= 0) return VQF_E_BADARG;
+  if (n % 4) return VQF_E_UNSUPPORTED;
+  if (!aligned16(dy) || !aligned16(a) || !aligned16(b) || !aligned16(da) || !aligned16(db)) return VQF_E_ALIGN;
+  long long blocks = (n / 4 + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  VQF_LAUNCH(KID_TANH_DROP_BWD, gate_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, b, dy, n / 4, da,
+             db);
+  return vqf_last_error();
 }
 
 int vqf_softmax_rows_fwd(const float* x, int R, int W, float* y, void* stream) {

@@ -357,7 +357,10 @@ static int gemm_bf16_impl(int ta, int tb, int M, int N, int K, const void* A, in
   else if (!ta && tb) rc = launch<false, true>(g, grid, s);
   else if (ta && !tb) rc = launch<true, false>(g, grid, s);
   else rc = launch<true, true>(g, grid, s);
-  if (rc != VQF_OK) return rc;
+  if (rc != VQF_OK) {
+    vqf_splitk_counters_clear(g.cnt, (int)tiles, s);
+    return rc;
+  }
   if (splits > 1 && !g.cnt) rc = vqf_splitk_reduce((const float*)ws, splits, M, N, C, ldc, bias, flags, s);
   return rc;
 }

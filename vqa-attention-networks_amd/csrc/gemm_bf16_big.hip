@@ -792,6 +792,7 @@ int vqf_gemm_bf16_big_try(int ta, int tb, int M, int N, int K, const void* A, in
   vqf_stat_bump(VQF_STAT_GEMM_BF16_BIG);
   if (ta) *rc = tb ? launch<true, true>(g, s) : launch<true, false>(g, s);
   else    *rc = tb ? launch<false, true>(g, s) : launch<false, false>(g, s);
+  if (*rc != VQF_OK) vqf_splitk_counters_clear(g.cnt, tiles, s);
   if (*rc == VQF_OK && splits > 1 && !g.cnt) *rc = vqf_splitk_reduce((const float*)ws, splits, M, N, C, ldc, bias, flags, s);
   return 1;
 }

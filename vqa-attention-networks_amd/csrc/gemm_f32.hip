@@ -505,6 +505,11 @@ int launch_gemm(const GemmArgs& g, dim3 grid, hipStream_t s, int kid) {
 // global).  A launch takes `tiles` consecutive words; its last arrivers leave them at zero, so the ring needs no clearing
 // between launches, and concurrent launches (two streams) hold different words as long as fewer than VQF_SPLITK_RING tiles are
 // in flight.  nullptr: no counters (the caller runs the two-launch form).
+// Bounds: a launch takes at most RING / 4 words, so four launches of the largest admitted size may be in flight on
+// different streams before the ring wraps onto words still in use; the library's callers hold at most two streams (the compute
+// stream and the image projection's side stream).  A launch whose status is not VQF_OK may not have run its last arrivers:
+// the launcher clears that launch's words on its stream (vqf_splitk_counters_clear), so a failed launch cannot leave tickets
+// behind for the launch that draws the same words 65536 tiles later.
 constexpr int VQF_SPLITK_RING = 1 << 16;
 __device__ int vqf_splitk_ring[VQF_SPLITK_RING];      // zero-initialised when the code object is loaded
 int* vqf_splitk_counters(int tiles) {
@@ -523,6 +528,10 @@ int* vqf_splitk_counters(int tiles) {
     start = (cur % VQF_SPLITK_RING) + (unsigned)tiles <= (unsigned)VQF_SPLITK_RING ? cur % VQF_SPLITK_RING : 0u;   // contiguous
   } while (!next.compare_exchange_weak(cur, start + (unsigned)tiles, std::memory_order_relaxed));
   return base[dev] + start;
+}
+
+void vqf_splitk_counters_clear(int* words, int tiles, hipStream_t s) {
+  if (words && tiles > 0) (void)hipMemsetAsync(words, 0, (size_t)tiles * sizeof(int), s);
 }
 
 // shared with gemm_bf16.hip
@@ -647,7 +656,10 @@ static int gemm_tile128(int ta, int tb, int M, int N, int K, const float* A, int
   else if (!ta && tb) rc = launch_gemm<false, true>(g, grid, s, kid);
   else if (ta && !tb) rc = launch_gemm<true, false>(g, grid, s, kid);
   else rc = launch_gemm<true, true>(g, grid, s, kid);
-  if (rc != VQF_OK) return rc;
+  if (rc != VQF_OK) {
+    vqf_splitk_counters_clear(g.cnt, (int)tiles, s);
+    return rc;
+  }
   if (splits > 1 && !g.cnt) rc = vqf_splitk_reduce((const float*)ws, splits, M, N, C, ldc, bias, flags, s);
   return rc;
 }

@@ -891,6 +891,9 @@ int vqf_gemm_f32_big_try(int ta, int tb, int M, int N, int K, const float* A, in
   g.cnt = nullptr; g.Cfinal = C; g.ldc_final = ldc;
   g.sk_tail = 0; g.sk_fw = 0; g.sk_V = 0; g.sk_q = 0; g.sk_slab = nullptr;
   if (sk_tail > 0) {
+    // (the stream-K tail only exists for products that are NOT split over K: `splits` is 1 on this path by construction -- see
+    //  its initialisation above --, so the split-K branch below never draws a second set of counters over g.cnt)
+    if (splits != 1) return 0;
     const int V = vqf_cu_count() & ~7;
     g.cnt = vqf_splitk_counters(sk_tail);
     if (g.cnt) {
@@ -919,6 +922,7 @@ int vqf_gemm_f32_big_try(int ta, int tb, int M, int N, int K, const float* A, in
   vqf_stat_bump(VQF_STAT_GEMM_F32_BIG);
   if (ta) *rc = tb ? launch<true, true>(g, s) : launch<true, false>(g, s);
   else    *rc = tb ? launch<false, true>(g, s) : launch<false, false>(g, s);
+  if (*rc != VQF_OK) vqf_splitk_counters_clear(g.cnt, g.sk_tail > 0 ? g.sk_tail : tiles, s);
   if (*rc == VQF_OK && splits > 1 && !g.cnt) *rc = vqf_splitk_reduce((const float*)ws, splits, Mb, N, C, ldc, bias, flags, s);
   *rows_done = Mb;
   return 1;

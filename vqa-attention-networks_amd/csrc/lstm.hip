@@ -30,7 +30,7 @@
 // in their natural row-major layouts (7.8 / 13.5 us), a v_mfma_f32_4x4x1_16B_f32 backward that wastes
 // no tile columns (17.0 us: the step is bound by its load chain, not by the 3.4 us of MFMAs), 8 or 16
 // hidden units per workgroup in the backward (14.5 / 17.1 us), and a whole-sequence persistent
-// kernel (lstm_persist.hip).
+// kernel (not in the product build since ABI 5: tools/variants/lstm_persist.hip).
 // PyTorch gate order i,f,g,o; zero initial state (mfb.py:69, mhb_coAtt.py:72-74 pass no hx).
 // Constraints: B <= 32, H in {256, 512, 768, 1024} (else VQF_E_UNSUPPORTED: the caller keeps nn.LSTM).
 #include "common.h"

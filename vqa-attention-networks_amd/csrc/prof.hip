@@ -77,7 +77,7 @@ void vqf_prof_end(int id, hipStream_t s) {
 void vqf_prof_dims(int d0, int d1, int d2) { t_dims[0] = d0; t_dims[1] = d1; t_dims[2] = d2; }
 
 extern "C" {
-int vqf_abi_version(void) { return 5; }
+int vqf_abi_version(void) { return 6; }
 int vqf_set_option(int option, int value, int* previous) {
   if (option < 0 || option >= VQF_OPT_COUNT) return VQF_E_BADARG;
   if (previous) *previous = g_vqf_opt[option];

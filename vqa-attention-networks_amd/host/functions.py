@@ -130,6 +130,59 @@ class LinearFn(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
+class Linear2Fn(torch.autograd.Function):
+    """y = [x1 | x2] @ W^T + b without materialising the concatenation (mhb_coAtt.py:147-148,213-214: the two final MFB blocks
+    are concatenated along the feature axis and fed to the classifier).  x1 (M,K1), x2 (M,K2), W (N, K1+K2): two products into
+    one output (the second accumulates), the weight's column blocks read in place as row-strided operands; the backward hands
+    each block its own contiguous gradient and writes the weight gradient's column blocks in place."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, w, b):
+        x1, x2 = _c(x1), _c(x2)
+        w2 = _w2d(w)
+        K1 = x1.shape[1]
+        y = ops.gemm(x1, w2[:, :K1], bias=b)
+        ops.gemm(x2, w2[:, K1:], out=y, accumulate=True)
+        ctx.save_for_backward(x1, x2, w)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x1, x2, w = ctx.saved_tensors
+        w2 = _w2d(w)
+        dy = _c(dy)
+        K1 = x1.shape[1]
+        dx1 = ops.gemm(dy, w2[:, :K1], tb=True) if ctx.needs_input_grad[0] else None
+        dx2 = ops.gemm(dy, w2[:, K1:], tb=True) if ctx.needs_input_grad[1] else None
+        dw = None
+        if ctx.needs_input_grad[2]:
+            dw = torch.empty_like(w2)
+            ops.gemm(dy, x1, ta=True, tb=True, out=dw[:, :K1])
+            ops.gemm(dy, x2, ta=True, tb=True, out=dw[:, K1:])
+            dw = dw.view_as(w)
+        db = ops.colsum(dy) if (ctx.has_bias and ctx.needs_input_grad[3]) else None
+        return dx1, dx2, dw, db
+
+
+class JoinRowsFn(torch.autograd.Function):
+    """cat((v, q), 0) where v and q already ARE the two row blocks of `buf` (their producers wrote them there): returns buf,
+    hands each block its contiguous half of the gradient (hieCoAtten.py:52)."""
+
+    @staticmethod
+    def forward(ctx, v, q, buf):
+        n = v.shape[0]
+        if v.data_ptr() != buf.data_ptr() or q.data_ptr() != buf[n:].data_ptr() or buf.shape[0] != n + q.shape[0]:
+            raise ops._l.VqfError("JoinRowsFn: v and q must be the row blocks of buf")
+        ctx.n = n
+        return buf.view_as(buf)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        return g[:ctx.n], g[ctx.n:], None
+
+
 class AttHeadFn(torch.autograd.Function):
     """Attention MLP + glimpse pooling.
 
@@ -137,18 +190,21 @@ class AttHeadFn(torch.autograd.Function):
     feat (N, S, C)   what the glimpses pool (LSTM states / the image tensor)
     w1,b1 [wm,bm] w2,b2: conv1 (+ "multilayer" conv) + conv2 -> 2 logits
     unit_softmax: reproduce mfb.py:84,118 (softmax over the singleton axis == 1)
+    same_src: the CALLER's statement that x is feat.view(N*S, C) of the same autograd tensor (the question head pools the very
+        tensor its MLP reads, mfb.py:73-89): the backward then adds the MLP's input gradient onto the pooling's in the GEMM
+        epilogue and returns ONE gradient (for feat; None for x) instead of leaving two for autograd to add.  Never inferred
+        from pointers: an alias with a different autograd history must keep its own gradient.
     returns pooled (N, 2C); the attention weights (N,2,S) are kept on ctx.
     """
 
     @staticmethod
-    def forward(ctx, x, feat, w1, b1, wm, bm, w2, b2, unit_softmax, bf16=False, link=None):
+    def forward(ctx, x, feat, w1, b1, wm, bm, w2, b2, unit_softmax, bf16=False, link=None, same_src=False):
         x = _c(x)
         feat = _c(feat)
         ctx.bf16 = bool(bf16)
-        # the question head pools the very tensor its MLP reads (x is a view of feat, mfb.py:73-89): its backward then adds the MLP's
-        # input gradient onto the pooling's in the GEMM epilogue instead of leaving two gradients for autograd to add
-        ctx.same_src = (x.data_ptr() == feat.data_ptr() and x.numel() == feat.numel() and x.shape[-1] == feat.shape[-1]
-                        and x.dtype == feat.dtype)
+        ctx.same_src = bool(same_src)
+        if ctx.same_src and (x.numel() != feat.numel() or x.shape[-1] != feat.shape[-1] or x.dtype != feat.dtype):
+            raise ops._l.VqfError("AttHeadFn: same_src needs x = feat.view(N*S, C)")
         ctx.link = link if (link is not None and link.inv is not None) else None
         if ctx.link is not None:
             # x is the UN-NORMALISED fusion output: 1/norm of the sample goes into the conv GEMM's epilogue, and the logit
@@ -201,10 +257,10 @@ class AttHeadFn(torch.autograd.Function):
                 d1b = ops.cast_bf16(d1s)
                 dw1 = ops.gemm_bf16(d1b, x, ta=True, tb=True)[:, :cin].contiguous().view_as(w1)
                 dx = ops.gemm_bf16(d1b, ops.cast_bf16(_w2d(w1), 32), tb=True, N=cin) if ctx.needs_input_grad[0] else None
-                return dx, dfeat, dw1, db1, None, None, dw2.view_as(w2), db2, None, None, None
+                return dx, dfeat, dw1, db1, None, None, dw2.view_as(w2), db2, None, None, None, None
             dw1 = ops.gemm(d1s, x, ta=True, tb=True).view_as(w1)                    # = dpre^T Y
             dx = ops.gemm(d1s, _w2d(w1), tb=True) if ctx.needs_input_grad[0] else None   # dYs = dY / norm
-            return dx, dfeat, dw1, db1, None, None, dw2.view_as(w2), db2, None, None, None
+            return dx, dfeat, dw1, db1, None, None, dw2.view_as(w2), db2, None, None, None, None
         last = hid2 if hid2 is not None else hid1
         dlast_pre, dw2, db2, dblast = ops.att_logits_bwd(dlogits, last, _w2d(w2), relu_mask=True)
         dwm = dbm = None
@@ -225,12 +281,12 @@ class AttHeadFn(torch.autograd.Function):
                 dx = ops.gemm_bf16(d1b, w1b, tb=True, N=cin)
         else:
             dw1 = ops.gemm(d1_pre, x, ta=True, tb=True).view_as(w1)
-            if ctx.same_src and dfeat is not None and ctx.needs_input_grad[0]:
+            if ctx.same_src and dfeat is not None:
                 ops.gemm(d1_pre, _w2d(w1), tb=True, out=dfeat.view(x.shape), accumulate=True)     # dfeat += dx: one gradient for the shared source
                 dx = None
             else:
                 dx = ops.gemm(d1_pre, _w2d(w1), tb=True) if ctx.needs_input_grad[0] else None
-        return dx, dfeat, dw1, db1, dwm, dbm, dw2.view_as(w2), db2, None, None, None
+        return dx, dfeat, dw1, db1, dwm, dbm, dw2.view_as(w2), db2, None, None, None, None
 
 
 def _arm_link(link, inv, L):
@@ -517,8 +573,8 @@ class DropoutBTFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         B, T, H = dy.shape
-        if dy.stride(2) != 1:
-            dy = dy.contiguous()
+        if dy.stride(2) != 1 or dy.stride(0) % 4 or dy.stride(1) % 4 or dy.data_ptr() % 16:
+            dy = dy.contiguous()           # an offset view or odd strides: the kernel wants 16-byte rows
         sb, st = ctx.in_strides
         if st > sb and sb == H and st == B * H:                     # x was the transposed view of a contiguous (T, B, H) tensor
             dx = torch.empty((T, B, H), dtype=torch.float32, device=dy.device).transpose(0, 1)
@@ -534,7 +590,7 @@ def lstm_out_dropout(module, x, seeds, tag="l"):
     p = float(module.p) if module.training else 0.0
     keep = seeds.keep.get(tag)
     if x.dim() == 3 and x.is_cuda and x.dtype == torch.float32 and x.stride(2) == 1 and x.shape[2] % 4 == 0 \
-            and all(s % 4 == 0 for s in x.stride()[:2]):
+            and all(s % 4 == 0 for s in x.stride()[:2]) and x.data_ptr() % 16 == 0:
         if p <= 0.0 and keep is None and x.is_contiguous():
             return x
         seed, pp = seeds.next(module.training, p)
@@ -559,6 +615,21 @@ class TanhDropFn(torch.autograd.Function):
         (y,) = ctx.saved_tensors
         dx = ops.tanh_dropout_bwd(_c(dy), y, keep=ctx.keep, seed=ctx.seed, p_drop=ctx.p)
         return dx, (dx if ctx.has_b else None), None, None, None
+
+
+class GateFn(torch.autograd.Function):
+    """y = tanh(a) * sigmoid(b): the gate of Nonlinear_layer (modules.py:103-109), one launch each way."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _c(a), _c(b)
+        ctx.save_for_backward(a, b)
+        return ops.gate_tanh_sigmoid_fwd(a, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, b = ctx.saved_tensors
+        return ops.gate_tanh_sigmoid_bwd(_c(dy), a, b)
 
 
 class BmmFn(torch.autograd.Function):
@@ -600,13 +671,16 @@ class AttPoolFn(torch.autograd.Function):
     x (N*S, Cin), feat (N,S,C), w (G,Cin), b (G)."""
 
     @staticmethod
-    def forward(ctx, x, feat, w, b):
+    def forward(ctx, x, feat, w, b, pooled_out=None):
+        """pooled_out: a contiguous (N, G*C) buffer (a row block of a larger one) the pooled vectors are written into"""
         x, feat = _c(x), _c(feat)
         w2 = _w2d(w)
         logits = ops.att_logits_fwd(x, w2, b)
-        wts, pooled = ops.glimpse_pool_fwd(feat, logits, False)
+        wts, pooled = ops.glimpse_pool_fwd(feat, logits, False, pooled_out=pooled_out)
         ctx.save_for_backward(x, feat, w, wts)
-        return pooled, wts
+        # (pooled_out is written as raw memory, like ImgProjDeferFn.fill: the output is a fresh view of it, autograd sees no
+        #  in-place operation on the buffer)
+        return (pooled.view_as(pooled) if pooled_out is not None else pooled), wts
 
     @staticmethod
     def backward(ctx, dpooled, dwts):
@@ -614,7 +688,7 @@ class AttPoolFn(torch.autograd.Function):
         dlogits, dfeat = ops.glimpse_pool_bwd(_c(dpooled), feat, wts, False, ctx.needs_input_grad[1],
                                               dwts=None if dwts is None else _c(dwts))
         dx, dw, db, _ = ops.att_logits_bwd(dlogits, x, _w2d(w), relu_mask=False)
-        return (dx if ctx.needs_input_grad[0] else None), dfeat, dw.view_as(w), db
+        return (dx if ctx.needs_input_grad[0] else None), dfeat, dw.view_as(w), db, None
 
 
 class HieCoreFn(torch.autograd.Function):

@@ -10,7 +10,7 @@ state_dict keys.  Reference behaviour kept on purpose:
 import torch
 import torch.nn as nn
 
-from .functions import LinearFn, DropoutFn, TanhDropFn, BmmFn, AttPoolFn, HieCoreFn, embed, _plain_embedding
+from .functions import LinearFn, DropoutFn, TanhDropFn, BmmFn, AttPoolFn, JoinRowsFn, HieCoreFn, embed, _plain_embedding
 from .mfb import _DropSeeds
 
 
@@ -71,12 +71,13 @@ class HieCoAtten(nn.Module):
         que_ = lin(que, self.fc_Wq)                                             # :36
         tq = BmmFn.apply(C, que_.view(N, T, E), True, True)                     # (N,L,E) = C^T que_   :38
         Hv = TanhDropFn.apply(img_, tq.view(N * L, E), *self._drop_args('Hv'))  # :38-39
-        v, av = AttPoolFn.apply(Hv, img.view(N, L, E), self.fc_Whv.weight, self.fc_Whv.bias)   # :40-42
+        xcat = torch.empty((2 * N, E), dtype=torch.float32, device=img.device)      # v and q are written into its two row blocks
+        v, av = AttPoolFn.apply(Hv, img.view(N, L, E), self.fc_Whv.weight, self.fc_Whv.bias, xcat[:N])   # :40-42
 
         ti = BmmFn.apply(C, img_.view(N, L, E), False, True)                    # (N,T,E) = C img_     :45
         Hq = TanhDropFn.apply(que_, ti.view(N * T, E), *self._drop_args('Hq'))  # :45-46
-        q, aq = AttPoolFn.apply(Hq, que.view(N, T, E), self.fc_Whq.weight, self.fc_Whq.bias)   # :47-49
+        q, aq = AttPoolFn.apply(Hq, que.view(N, T, E), self.fc_Whq.weight, self.fc_Whq.bias, xcat[N:])   # :47-49
 
-        x = torch.cat((v, q), 0).view(N, -1)                                    # :52-53 (row pairing)
+        x = JoinRowsFn.apply(v, q, xcat).view(N, -1)                            # :52-53 cat((v, q), 0).view(N, -1): row pairing, no copy
         x = lin(x, self.fc)                                                     # :54
         return x, torch.squeeze(av.view(N, L, 1)), torch.squeeze(aq.view(N, T, 1))   # :43,50,55

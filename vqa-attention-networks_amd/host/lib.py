@@ -18,7 +18,7 @@ if os.environ.get("VQF_LIB"):          # A/B builds (tools/build_variant.sh); ne
 HEADER_PATH = os.path.join(os.path.dirname(PKG_DIR), "include", "vqa_fusion.h")
 
 # The one place the expected ABI number lives (csrc/prof.hip returns it from vqf_abi_version()).
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _lock = threading.Lock()
 _lib = None
@@ -63,6 +63,8 @@ SIGNATURES = {
     "vqf_dropout_f32": (c_i, [c_f, c_p, c_u64, ctypes.c_float, ctypes.c_longlong, c_f, c_p]),
     "vqf_dropout_bt": (c_i, [c_f, ctypes.c_longlong, ctypes.c_longlong, c_p, c_u64, ctypes.c_float, c_i, c_i, c_i, c_f,
                              ctypes.c_longlong, ctypes.c_longlong, c_p]),
+    "vqf_gate_tanh_sigmoid_fwd": (c_i, [c_f, c_f, ctypes.c_longlong, c_f, c_p]),
+    "vqf_gate_tanh_sigmoid_bwd": (c_i, [c_f, c_f, c_f, ctypes.c_longlong, c_f, c_f, c_p]),
     "vqf_tanh_dropout_fwd": (c_i, [c_f, c_f, c_p, c_u64, ctypes.c_float, ctypes.c_longlong, c_f, c_p]),
     "vqf_tanh_dropout_bwd": (c_i, [c_f, c_f, c_p, c_u64, ctypes.c_float, ctypes.c_longlong, c_f, c_p]),
     "vqf_tanh_dropout_fwd2d": (c_i, [c_f, c_i, c_f, c_i, c_p, c_u64, ctypes.c_float, c_i, c_i, c_f, c_i, c_p]),

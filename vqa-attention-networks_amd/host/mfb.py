@@ -264,7 +264,7 @@ class MFB(nn.Module):
         wm, bm = self._mc('ques_att_multiconv')
         qa = AttHeadFn.apply(ques_feature.view(N * T, H), ques_feature,
                              self.ques_att_conv1.weight, self.ques_att_conv1.bias, wm, bm,
-                             self.ques_att_conv2.weight, self.ques_att_conv2.bias, self.unit_softmax, bf16_all)
+                             self.ques_att_conv2.weight, self.ques_att_conv2.bias, self.unit_softmax, bf16_all, None, True)
         # a4: ques_proj1                                                     mfb.py:92-93
         qp = LinearFn.apply(qa, self.ques_proj1.weight, self.ques_proj1.bias, False, bf16_all)
         # a5+a6: image projection + MFB fusion over the regions             mfb.py:95-106

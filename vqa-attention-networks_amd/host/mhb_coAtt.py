@@ -8,7 +8,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .functions import (LinearFn, AttHeadFn, ImgFuseFn, MfbFuseFn, FinalMfbFn, LstmSeqFn, LstmBatchFn, LogSoftmaxRowsFn,
+from .functions import (LinearFn, Linear2Fn, AttHeadFn, ImgFuseFn, MfbFuseFn, FinalMfbFn, LstmSeqFn, LstmBatchFn, LogSoftmaxRowsFn,
                         NormLink, embed_tanh, embed, lstm_out_dropout)
 from .mfb import _DropSeeds, _image_is_data, _SideStream, _lstm_bf16, batch_first_lstm, warn_once
 
@@ -90,7 +90,7 @@ class MHBCoAtt(nn.Module):
 
         qa = AttHeadFn.apply(ques_feature.view(N * T, H), ques_feature,
                              self.ques_att_conv1.weight, self.ques_att_conv1.bias, None, None,
-                             self.ques_att_conv2.weight, self.ques_att_conv2.bias, False, bf16_all)
+                             self.ques_att_conv2.weight, self.ques_att_conv2.bias, False, bf16_all, None, True)
         qp = LinearFn.apply(qa, self.ques_proj1.weight, self.ques_proj1.bias, False, bf16_all)
         pm = self.dropout_m.p
         seed, p = self._seeds.next(self.training, pm)
@@ -111,8 +111,8 @@ class MHBCoAtt(nn.Module):
             kk = keep.get(tag)
             ys.append(FinalMfbFn.apply(qa, va, qpj.weight, qpj.bias, ipj.weight, ipj.bias, kk, seed,
                                        pm if kk is not None else p, None, False, bf16_all))
-        att_normed_23 = torch.cat(ys, 1)                                     # (N,2000)  :147
-        logits = LinearFn.apply(att_normed_23, self.linear_pred.weight, self.linear_pred.bias)
+        # :147-148  linear_pred(cat((att_normed_2, att_normed_3), 1)): the concatenation is never materialised
+        logits = Linear2Fn.apply(ys[0], ys[1], self.linear_pred.weight, self.linear_pred.bias)
         return LogSoftmaxRowsFn.apply(logits)                                # :149-151 (implicit dim = 1 on the 2-D logits)
 
 
@@ -180,6 +180,6 @@ class MHB(nn.Module):
         mhb_2 = FinalMfbFn.apply(lstm_out, i_mean, self.linear_q_2.weight, self.linear_q_2.bias,
                                  self.linear_i_2.weight, self.linear_i_2.bias, k2, seed,
                                  pm if k2 is not None else p, z1, False)             # :201-211
-        mhb_12 = torch.cat((mhb_1, mhb_2), 1)
-        logits = LinearFn.apply(mhb_12, self.linear_out.weight, self.linear_out.bias)
+        # :213-214  linear_out(cat((mhb_1, mhb_2), 1)) without the concatenated tensor (:214 names mhb_22: see the class docstring)
+        logits = Linear2Fn.apply(mhb_1, mhb_2, self.linear_out.weight, self.linear_out.bias)
         return LogSoftmaxRowsFn.apply(logits)                                # :215-217

@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .functions import LinearFn, BmmFn, AttPoolFn, SoftmaxRowsFn
+from .functions import LinearFn, BmmFn, AttPoolFn, SoftmaxRowsFn, GateFn
 
 
 class Attention_1(nn.Module):
@@ -81,4 +81,6 @@ class Nonlinear_layer(nn.Module):
         x = inputs.reshape(-1, shp[-1])
         o_1 = LinearFn.apply(x, self.fc1.weight, self.fc1.bias)
         o_2 = LinearFn.apply(x, self.fc2.weight, self.fc2.bias)
+        if o_1.is_cuda and o_1.dtype == torch.float32 and o_1.numel() % 4 == 0:
+            return GateFn.apply(o_1, o_2).view(shp)                                      # :108: one launch (csrc/elementwise.hip)
         return (torch.tanh(o_1) * torch.sigmoid(o_2)).view(shp)

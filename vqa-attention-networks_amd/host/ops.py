@@ -405,6 +405,24 @@ def tanh_dropout_bwd(dy, y, keep=None, seed=0, p_drop=0.5, out=None):
     return dx
 
 
+def gate_tanh_sigmoid_fwd(a, b):
+    """y = tanh(a) * sigmoid(b)   (modules.py:103-109)"""
+    _chk(a, b)
+    if a.shape != b.shape:
+        raise _l.VqfError("gate_tanh_sigmoid: shapes differ")
+    y = torch.empty_like(a)
+    _l.check(_lib().vqf_gate_tanh_sigmoid_fwd(_ptr(a), _ptr(b), a.numel(), _ptr(y), _stream()), "vqf_gate_tanh_sigmoid_fwd")
+    return y
+
+
+def gate_tanh_sigmoid_bwd(dy, a, b):
+    _chk(dy, a, b)
+    da, db = torch.empty_like(a), torch.empty_like(b)
+    _l.check(_lib().vqf_gate_tanh_sigmoid_bwd(_ptr(dy), _ptr(a), _ptr(b), a.numel(), _ptr(da), _ptr(db), _stream()),
+             "vqf_gate_tanh_sigmoid_bwd")
+    return da, db
+
+
 def _chk2s(*ts):
     for t in ts:
         if t is None:
