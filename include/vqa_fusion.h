@@ -382,8 +382,11 @@ int vqf_tanh_dropout_bwd2d(const float* dy, int lddy, const float* y, int ldy, c
  * HieCoAtten's co-attention ladder (hieCoAtten.py:32-49): the stages with a tiny inner / outer extent T (words per question)
  * as single streaming passes over the rows of the (N*L, E) tensors (csrc/hie.hip), neighbouring element-wise stage fused in.
  * Rows m = n*L + l of a / z / out may be strided (lda / ldz / ldo; column blocks of the concatenated-weight products);
- * C, U: (N, T, L) contiguous; V: rows n*T + t, stride ldv.  part: (S, N*T, E) partial sums over the S = vqf_hie_chunks(N, L)
- * row chunks of a sample -- add them up with vqf_hie_slab_sum (fixed order, no atomics).  Supported (vqf_hie_stream_supported):
+ * C, U: (N, T, L) contiguous; V: rows n*T + t, stride ldv.  part: the T-row sums of a sample.  S = vqf_hie_chunks(N, L) row
+ * chunks per sample (1 once N reaches the CU count: one 1024-thread workgroup per sample): with S > 1 `part` is (S, N*T, E)
+ * contiguous partial slabs (ldp == E, padd == NULL) to be added up by vqf_hie_slab_sum (fixed order, no atomics); with S == 1
+ * the sums are FINAL and go to rows n*T + t of pitch ldp, on top of padd's rows (pitch ldpa) when padd != NULL -- no slab-sum
+ * launch (ABI 6).  Supported (vqf_hie_stream_supported):
  * T <= 16, E % 4 == 0, E / 4 divides 256, T * E small enough for LDS; else VQF_E_UNSUPPORTED (the caller uses the batched GEMMs).
  *   vqf_hie_hv_fwd     out = dropout(tanh(a + C^T V)) (:38-39, Hv; a = img_, V = que_);  part[t] += C[t,l] a[l]  (:45, ti = C img_)
  *   vqf_hie_head_bwd   out = dl[l] w sc (1 - (hv/sc)^2): gradient of :38-40 w.r.t. img_ + tq from the logit gradient dl (N*L) of
@@ -395,14 +398,14 @@ int vqf_tanh_dropout_bwd2d(const float* dy, int lddy, const float* y, int ldy, c
 int vqf_hie_stream_supported(int N, int L, int E, int T);
 int vqf_hie_chunks(int N, int L);
 int vqf_hie_hv_fwd(const float* a, int lda, const float* C, const float* V, int ldv, const uint8_t* keep, uint64_t seed,
-                   float p_drop, int N, int L, int E, int T, float* out, int ldo, float* part, void* stream);
+                   float p_drop, int N, int L, int E, int T, float* out, int ldo, float* part, int ldp, void* stream);
 int vqf_hie_head_bwd(const float* hv, int ldh, const float* dl, const float* w, const float* C, const uint8_t* keep,
-                     uint64_t seed, float p_drop, int N, int L, int E, int T, float* out, int ldo, float* part, float* wpart,
-                     void* stream);
+                     uint64_t seed, float p_drop, int N, int L, int E, int T, float* out, int ldo, float* part, int ldp,
+                     const float* padd, int ldpa, float* wpart, void* stream);
 int vqf_hie_rank_add(const float* a, int lda, const float* U, const float* V, int ldv, int N, int L, int E, int T, float* out,
                      int ldo, void* stream);
 int vqf_hie_rank_left(const float* U, const float* V, int ldv, const float* z, int ldz, int N, int L, int E, int T, float* out,
-                      int ldo, float* part, void* stream);
+                      int ldo, float* part, int ldp, void* stream);
 int vqf_hie_slab_sum(const float* part, int S, int R, int W, const float* add, int lda, float* out, int ldo, void* stream);
 
 /* softmax over the last axis of (R,W) and its backward   modules.py:91-92 */

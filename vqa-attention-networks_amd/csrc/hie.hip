@@ -19,8 +19,13 @@
 
 namespace {
 
-constexpr int HT = 256;        // threads per workgroup
-constexpr int TMAX = 16;
+// Threads per workgroup: 1024.  Round 4 ran 256-thread workgroups on quarter-sample chunks: every workgroup re-loaded its
+// sample's (T, E) operand (28 KB for 98 KB of streamed rows: the 18-31 % over-fetch of profiles/r04_pmc_hie.txt), wrote a partial
+// slab the slab-sum launch read back, and a CU held 32 KB of loads in flight.  One 1024-thread workgroup per SAMPLE (N >= the CU
+// count; smaller batches cut the sample into chunks as before) loads the operand once, needs no partial slabs (S == 1: the T-row
+// sums go straight to their destination, optionally on top of another tensor) and keeps the same 16 waves per CU.
+constexpr int HT = 1024;
+constexpr int TMAX_ALL = 16;
 
 enum { MODE_FWD = 0, MODE_HEAD = 1, MODE_ADD = 2, MODE_LEFT = 3 };
 
@@ -30,7 +35,8 @@ struct HieArgs {
   float* out; int ldo;
   const float* U;
   const float* V; int ldv;
-  float* part;
+  float* part; int ldp;                              // partial sums: (S, N*T) rows of pitch ldp (S > 1: ldp == E, contiguous slabs)
+  const float* padd; int ldpa;                       // S == 1 only: the sums are written ON TOP of these rows (or nullptr)
   const uint8_t* keep; uint64_t seed; uint32_t thr; float inv_keep;
   const float* dl; const float* w; float* wpart;     // HEAD: logit gradient (N*L), head weight (E), partial rows (S*N, E + 4)
   int N, L, E, T, S, Lc;
@@ -53,8 +59,11 @@ __device__ __forceinline__ void keep4v(const uint8_t* __restrict__ keep, uint64_
   }
 }
 
-template <int MODE>
+// TMAX: compile-time bound of T (8, 14 or 16: the T-row accumulators are 4 TMAX registers; at 16 the HEAD mode spilled under the
+// 128-register budget of a 1024-thread workgroup)
+template <int MODE, int TMAX>
 __global__ void __launch_bounds__(HT) hie_stream_kernel(const HieArgs g) {
+  const int HT = blockDim.x;                                // (shadows the constant: small problems launch narrower workgroups)
   constexpr bool RANK = MODE != MODE_HEAD;                  // out has the rank-T term sum_t U[t,l] V[t,:]
   constexpr bool ACC = MODE != MODE_ADD;                    // part[t,:] += U[t,l] (a | out | z)[l,:]
   extern __shared__ float smem[];
@@ -86,76 +95,79 @@ __global__ void __launch_bounds__(HT) hie_stream_kernel(const HieArgs g) {
   f32x4 wv = {0.f, 0.f, 0.f, 0.f};
   if (MODE == MODE_HEAD) wv = *reinterpret_cast<const f32x4*>(g.w + 4 * c4);
 
-  // two rows per trip: both rows' loads are issued before either is consumed
-  for (int r = rs; r < rows; r += 2 * RS) {
-    const int rA = r, rB = r + RS;
-    const bool hasB = rB < rows;
-    const long long mA = (long long)n * L + l0 + rA, mB = hasB ? mA + RS : mA;
-    f32x4 xA = {0.f, 0.f, 0.f, 0.f}, xB = xA, zA = xA, zB = xA;
-    if (MODE != MODE_LEFT) {
-      xA = *reinterpret_cast<const f32x4*>(g.a + mA * g.lda + 4 * c4);
-      xB = *reinterpret_cast<const f32x4*>(g.a + mB * g.lda + 4 * c4);
-    } else {
-      zA = *reinterpret_cast<const f32x4*>(g.z + mA * g.ldz + 4 * c4);
-      zB = *reinterpret_cast<const f32x4*>(g.z + mB * g.ldz + 4 * c4);
+  // NR rows per trip: every row's load is issued before any is consumed.  The pass is latency-bound, not VALU- or LDS-bound (28
+  // FMAs and one 16-byte LDS read per element and t are a tenth of the pass): with two rows per trip a CU's 16 waves kept 32 KB
+  // in flight, 2.3-2.7 TB/s over the (N*L, E) tensors (profiles/r04_pmc_hie.txt); four rows double that.
+  constexpr int NR = 2;        // (four rows per trip: 133-154 VGPRs, fewer waves, measured slower: gpurun_out/r05/b_c4_a.json)
+  for (int r = rs; r < rows; r += NR * RS) {
+    long long m[NR];
+    bool has[NR];
+    f32x4 x[NR], o[NR];
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+      has[q] = r + q * RS < rows;
+      m[q] = (long long)n * L + l0 + (has[q] ? r + q * RS : r);
     }
-    f32x4 oA, oB;
+#pragma unroll
+    for (int q = 0; q < NR; ++q)
+      x[q] = MODE != MODE_LEFT ? vqf_ld_stream(reinterpret_cast<const f32x4*>(g.a + m[q] * g.lda + 4 * c4)) : vqf_ld_stream(reinterpret_cast<const f32x4*>(g.z + m[q] * g.ldz + 4 * c4));
     if (MODE == MODE_HEAD) {
-      const float dA = g.dl[mA], dB = g.dl[mB];
       const float keep_q = 1.0f / g.inv_keep;
-      f32x4 scA, scB;
-      keep4v(g.keep, g.seed, g.thr, g.inv_keep, mA * CT + c4, scA);
-      keep4v(g.keep, g.seed, g.thr, g.inv_keep, mB * CT + c4, scB);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float tA = scA[j] > 0.f ? xA[j] * keep_q : 0.f;       // tanh value back from the stored tanh * keep / (1 - p)
-        const float tB = scB[j] > 0.f ? xB[j] * keep_q : 0.f;
-        oA[j] = dA * wv[j] * scA[j] * (1.0f - tA * tA);
-        oB[j] = dB * wv[j] * scB[j] * (1.0f - tB * tB);
-      }
-      wacc += xA * dA;
-      if (c4 == 0) dlsum += dA;
-      if (hasB) {
-        wacc += xB * dB;
-        if (c4 == 0) dlsum += dB;
-      }
-#pragma unroll
-      for (int t = 0; t < TMAX; ++t)
-        if (t < T) {
-          tacc[t] += oA * Us[t * g.Lc + rA];
-          if (hasB) tacc[t] += oB * Us[t * g.Lc + rB];
-        }
-    } else {
-      oA = xA;
-      oB = xB;
-#pragma unroll
-      for (int t = 0; t < TMAX; ++t)
-        if (t < T) {
-          const float uA = Us[t * g.Lc + rA], uB = hasB ? Us[t * g.Lc + rB] : 0.f;
-          const f32x4 v = *reinterpret_cast<const f32x4*>(Vs + t * E + 4 * c4);
-          oA += v * uA;
-          oB += v * uB;
-          if (MODE == MODE_FWD) { tacc[t] += xA * uA; tacc[t] += xB * uB; }       // (uB == 0 when the row does not exist)
-          if (MODE == MODE_LEFT) { tacc[t] += zA * uA; tacc[t] += zB * uB; }
-        }
-      if (MODE == MODE_FWD) {
-        f32x4 scA, scB;
-        keep4v(g.keep, g.seed, g.thr, g.inv_keep, mA * CT + c4, scA);
-        keep4v(g.keep, g.seed, g.thr, g.inv_keep, mB * CT + c4, scB);
+      for (int q = 0; q < NR; ++q) {
+        const float d = g.dl[m[q]];
+        f32x4 sc;
+        keep4v(g.keep, g.seed, g.thr, g.inv_keep, m[q] * CT + c4, sc);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          oA[j] = vqf_tanh_fast(oA[j]) * scA[j];
-          oB[j] = vqf_tanh_fast(oB[j]) * scB[j];
+          const float t = sc[j] > 0.f ? x[q][j] * keep_q : 0.f;       // tanh value back from the stored tanh * keep / (1 - p)
+          o[q][j] = d * wv[j] * sc[j] * (1.0f - t * t);
+        }
+        if (has[q]) {
+          wacc += x[q] * d;
+          if (c4 == 0) dlsum += d;
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < TMAX; ++t)
+        if (t < T) {
+#pragma unroll
+          for (int q = 0; q < NR; ++q)
+            if (has[q]) tacc[t] += o[q] * Us[t * g.Lc + r + q * RS];
+        }
+    } else {
+#pragma unroll
+      for (int q = 0; q < NR; ++q) o[q] = MODE == MODE_LEFT ? f32x4{0.f, 0.f, 0.f, 0.f} : x[q];
+#pragma unroll
+      for (int t = 0; t < TMAX; ++t)
+        if (t < T) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(Vs + t * E + 4 * c4);
+#pragma unroll
+          for (int q = 0; q < NR; ++q) {
+            const float u = has[q] ? Us[t * g.Lc + r + q * RS] : 0.f;      // (u == 0 when the row does not exist)
+            o[q] += v * u;
+            if (MODE == MODE_FWD || MODE == MODE_LEFT) tacc[t] += x[q] * u;
+          }
+        }
+      if (MODE == MODE_FWD) {
+#pragma unroll
+        for (int q = 0; q < NR; ++q) {
+          f32x4 sc;
+          keep4v(g.keep, g.seed, g.thr, g.inv_keep, m[q] * CT + c4, sc);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[q][j] = vqf_tanh_fast(o[q][j]) * sc[j];
         }
       }
     }
-    *reinterpret_cast<f32x4*>(g.out + mA * g.ldo + 4 * c4) = oA;
-    if (hasB) *reinterpret_cast<f32x4*>(g.out + mB * g.ldo + 4 * c4) = oB;
+#pragma unroll
+    for (int q = 0; q < NR; ++q)
+      if (has[q]) *reinterpret_cast<f32x4*>(g.out + m[q] * g.ldo + 4 * c4) = o[q];
   }
 
   if (ACC) {
     // fold the RS row slots of the workgroup (fixed order), one t at a time through 4 KB of LDS
-    float* dst = g.part + (((long long)s * g.N + n) * T) * E;
+    float* dst = g.part + (((long long)s * g.N + n) * T) * g.ldp;
+    const float* add = g.padd ? g.padd + (long long)n * T * g.ldpa : nullptr;
     for (int t = 0; t < T; ++t) {
       f32x4 v = tacc[0];
 #pragma unroll
@@ -167,7 +179,8 @@ __global__ void __launch_bounds__(HT) hie_stream_kernel(const HieArgs g) {
       if (rs == 0) {
         f32x4 sum = *reinterpret_cast<const f32x4*>(red + 4 * c4);
         for (int q = 1; q < RS; ++q) sum += *reinterpret_cast<const f32x4*>(red + q * E + 4 * c4);
-        *reinterpret_cast<f32x4*>(dst + (long long)t * E + 4 * c4) = sum;
+        if (add) sum = *reinterpret_cast<const f32x4*>(add + (long long)t * g.ldpa + 4 * c4) + sum;
+        *reinterpret_cast<f32x4*>(dst + (long long)t * g.ldp + 4 * c4) = sum;
       }
     }
   }
@@ -206,19 +219,28 @@ __global__ void slab_sum_kernel(const float* __restrict__ part, int S, int R, in
 }
 
 bool shape_ok(int N, int L, int E, int T) {
-  if (N <= 0 || L <= 0 || E <= 0 || T <= 0 || N > 65535 || T > TMAX || (E % 4)) return false;
+  if (N <= 0 || L <= 0 || E <= 0 || T <= 0 || N > 65535 || T > TMAX_ALL || (E % 4)) return false;
   const int CT = E / 4;
-  return CT <= HT && HT % CT == 0;
+  return CT <= 256 && 256 % CT == 0;
+}
+
+// threads per workgroup: 1024, or fewer when a chunk has too few rows to give every row slot two rows per trip
+int threads_for(int E, int Lc) {
+  const int CT = E / 4;
+  int nt = HT;
+  while (nt > 256 && (nt / CT) * 2 > Lc) nt >>= 1;
+  return nt;
 }
 
 int chunks_for(int N, int L) {
-  int S = (1024 + N - 1) / N;                 // >= ~1024 workgroups: four per CU
+  const int cus = vqf_cu_count() > 0 ? vqf_cu_count() : 256;
+  int S = (cus + N - 1) / N;                  // one workgroup per CU; a whole sample per workgroup once N >= the CU count
   if (S > (L + 7) / 8) S = (L + 7) / 8;       // at least 8 rows per chunk
   return S < 1 ? 1 : S;
 }
 
 size_t lds_bytes(int mode, int E, int T, int Lc) {
-  const int RS = HT / (E / 4);
+  const int RS = threads_for(E, Lc) / (E / 4);
   return sizeof(float) * ((size_t)(mode != MODE_HEAD ? T * E : 0) + (size_t)T * Lc + (size_t)RS * E + 16);
 }
 
@@ -229,16 +251,21 @@ int launch(int mode, HieArgs& g, const uint8_t* keep, uint64_t seed, float p, hi
   g.S = (g.L + g.Lc - 1) / g.Lc;
   const size_t lds = lds_bytes(mode, g.E, g.T, g.Lc);
   if (lds > 64 * 1024) return VQF_E_UNSUPPORTED;
+  if (g.S > 1 && (g.padd || (g.part && g.ldp != g.E))) return VQF_E_BADARG;     // several chunks: contiguous slabs, summed by vqf_hie_slab_sum
+  const int nt = threads_for(g.E, g.Lc);
   g.keep = keep; g.seed = seed;
   g.thr = (keep || p == 0.f) ? 0u : drop_threshold_host(p);
   g.inv_keep = (keep || p > 0.f) ? 1.0f / (1.0f - p) : 1.0f;
   const dim3 grid(g.S, g.N);
-  switch (mode) {
-    case MODE_FWD:  VQF_LAUNCH(KID_HIE_FWD, hie_stream_kernel<MODE_FWD>, grid, dim3(HT), lds, s, g); break;
-    case MODE_HEAD: VQF_LAUNCH(KID_HIE_HEAD, hie_stream_kernel<MODE_HEAD>, grid, dim3(HT), lds, s, g); break;
-    case MODE_ADD:  VQF_LAUNCH(KID_HIE_ADD, hie_stream_kernel<MODE_ADD>, grid, dim3(HT), lds, s, g); break;
-    default:        VQF_LAUNCH(KID_HIE_LEFT, hie_stream_kernel<MODE_LEFT>, grid, dim3(HT), lds, s, g); break;
+#define HIE_GO(TM)                                                                                              \
+  switch (mode) {                                                                                               \
+    case MODE_FWD:  VQF_LAUNCH(KID_HIE_FWD, (hie_stream_kernel<MODE_FWD, TM>), grid, dim3(nt), lds, s, g); break;   \
+    case MODE_HEAD: VQF_LAUNCH(KID_HIE_HEAD, (hie_stream_kernel<MODE_HEAD, TM>), grid, dim3(nt), lds, s, g); break; \
+    case MODE_ADD:  VQF_LAUNCH(KID_HIE_ADD, (hie_stream_kernel<MODE_ADD, TM>), grid, dim3(nt), lds, s, g); break;   \
+    default:        VQF_LAUNCH(KID_HIE_LEFT, (hie_stream_kernel<MODE_LEFT, TM>), grid, dim3(nt), lds, s, g); break; \
   }
+  if (g.T <= 8) { HIE_GO(8) } else if (g.T <= 14) { HIE_GO(14) } else { HIE_GO(16) }
+#undef HIE_GO
   return vqf_last_error();
 }
 
@@ -271,23 +298,25 @@ int vqf_hie_slab_sum(const float* part, int S, int R, int W, const float* add, i
 }
 
 int vqf_hie_hv_fwd(const float* a, int lda, const float* C, const float* V, int ldv, const uint8_t* keep, uint64_t seed,
-                   float p_drop, int N, int L, int E, int T, float* out, int ldo, float* part, void* stream) {
-  if (!C || !part || !rows_ok(a, lda, E) || !rows_ok(V, ldv, E) || !rows_ok(out, ldo, E) || p_drop < 0.f || p_drop >= 1.f)
+                   float p_drop, int N, int L, int E, int T, float* out, int ldo, float* part, int ldp, void* stream) {
+  if (!C || !rows_ok(part, ldp, E) || !rows_ok(a, lda, E) || !rows_ok(V, ldv, E) || !rows_ok(out, ldo, E) || p_drop < 0.f ||
+      p_drop >= 1.f)
     return VQF_E_BADARG;
   HieArgs g = {};
-  g.a = a; g.lda = lda; g.out = out; g.ldo = ldo; g.U = C; g.V = V; g.ldv = ldv; g.part = part;
+  g.a = a; g.lda = lda; g.out = out; g.ldo = ldo; g.U = C; g.V = V; g.ldv = ldv; g.part = part; g.ldp = ldp;
   g.N = N; g.L = L; g.E = E; g.T = T;
   return launch(MODE_FWD, g, keep, seed, p_drop, (hipStream_t)stream);
 }
 
 int vqf_hie_head_bwd(const float* hv, int ldh, const float* dl, const float* w, const float* C, const uint8_t* keep,
-                     uint64_t seed, float p_drop, int N, int L, int E, int T, float* out, int ldo, float* part, float* wpart,
-                     void* stream) {
-  if (!C || !dl || !w || !part || !wpart || !rows_ok(hv, ldh, E) || !rows_ok(out, ldo, E) || !aligned16(w) || p_drop < 0.f ||
-      p_drop >= 1.f)
+                     uint64_t seed, float p_drop, int N, int L, int E, int T, float* out, int ldo, float* part, int ldp,
+                     const float* padd, int ldpa, float* wpart, void* stream) {
+  if (!C || !dl || !w || !rows_ok(part, ldp, E) || (padd && !rows_ok(padd, ldpa, E)) || !wpart || !rows_ok(hv, ldh, E) ||
+      !rows_ok(out, ldo, E) || !aligned16(w) || p_drop < 0.f || p_drop >= 1.f)
     return VQF_E_BADARG;
   HieArgs g = {};
-  g.a = hv; g.lda = ldh; g.out = out; g.ldo = ldo; g.U = C; g.part = part; g.dl = dl; g.w = w; g.wpart = wpart;
+  g.a = hv; g.lda = ldh; g.out = out; g.ldo = ldo; g.U = C; g.part = part; g.ldp = ldp; g.padd = padd; g.ldpa = ldpa;
+  g.dl = dl; g.w = w; g.wpart = wpart;
   g.N = N; g.L = L; g.E = E; g.T = T;
   return launch(MODE_HEAD, g, keep, seed, p_drop, (hipStream_t)stream);
 }
@@ -302,10 +331,10 @@ int vqf_hie_rank_add(const float* a, int lda, const float* U, const float* V, in
 }
 
 int vqf_hie_rank_left(const float* U, const float* V, int ldv, const float* z, int ldz, int N, int L, int E, int T, float* out,
-                      int ldo, float* part, void* stream) {
-  if (!U || !part || !rows_ok(z, ldz, E) || !rows_ok(V, ldv, E) || !rows_ok(out, ldo, E)) return VQF_E_BADARG;
+                      int ldo, float* part, int ldp, void* stream) {
+  if (!U || !rows_ok(part, ldp, E) || !rows_ok(z, ldz, E) || !rows_ok(V, ldv, E) || !rows_ok(out, ldo, E)) return VQF_E_BADARG;
   HieArgs g = {};
-  g.z = z; g.ldz = ldz; g.out = out; g.ldo = ldo; g.U = U; g.V = V; g.ldv = ldv; g.part = part;
+  g.z = z; g.ldz = ldz; g.out = out; g.ldo = ldo; g.U = U; g.V = V; g.ldv = ldv; g.part = part; g.ldp = ldp;
   g.N = N; g.L = L; g.E = E; g.T = T;
   return launch(MODE_LEFT, g, nullptr, 0, 0.f, (hipStream_t)stream);
 }

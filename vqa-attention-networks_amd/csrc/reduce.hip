@@ -81,6 +81,35 @@ __global__ void group_reduce_kernel(const float* __restrict__ in, int G, int J, 
   out[(long long)g * W + c] = a0 + a1;
 }
 
+// out[c] = sum_{j<J} in[j, c] in ONE launch for a few hundred partial rows (the tail of every bias-gradient reduction: two launches
+// before round 5): a workgroup = 16 columns x 16 row slots, slot q folds rows q, q + 16, ... (eight loads in flight), the slots are
+// added through LDS in slot order.  Deterministic; W / 16 workgroups.
+__global__ void __launch_bounds__(256) colreduce_one_kernel(const float* __restrict__ in, int J, int W, float* __restrict__ out) {
+  __shared__ float red[16][17];
+  const int cl = threadIdx.x & 15, q = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  float a[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < W) {
+    int j = q;
+    for (; j + 7 * 16 < J; j += 8 * 16) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = in[(long long)(j + 16 * u) * W + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u & 3] += v[u];
+    }
+    for (; j < J; j += 16) a[0] += in[(long long)j * W + c];
+  }
+  red[q][cl] = (a[0] + a[1]) + (a[2] + a[3]);
+  __syncthreads();
+  if (q == 0 && c < W) {
+    float sum = red[0][cl];
+#pragma unroll
+    for (int u = 1; u < 16; ++u) sum += red[u][cl];
+    out[c] = sum;
+  }
+}
+
 // stage 1 of the two-stage column reduction: block (x, y) folds rows [y*chunk, (y+1)*chunk)
 __global__ void group_reduce_stage1_kernel(const float* __restrict__ in, int J, int W, int chunk,
                                            float* __restrict__ part) {
@@ -276,6 +305,10 @@ __global__ void l2_norm_bwd_coef_kernel(const float* __restrict__ rowdot,
 int vqf_colreduce_2stage(const float* in, int J, int W, float* out, float* scratch, hipStream_t s) {
   if (J <= 2 * VQF_REDUCE_SPLITS)
     return vqf_group_reduce_f32(in, 1, J, W, out, (void*)s);
+  if (J <= 4096) {       // a few hundred partial rows: one launch (16 row slots per column) instead of two
+    VQF_LAUNCH(KID_GROUP_REDUCE, colreduce_one_kernel, dim3((W + 15) / 16), dim3(256), 0, s, in, J, W, out);
+    return vqf_last_error();
+  }
   const int chunk = (J + VQF_REDUCE_SPLITS - 1) / VQF_REDUCE_SPLITS;
   const int ny = (J + chunk - 1) / chunk;
   dim3 grid((W + 255) / 256, ny);

@@ -738,9 +738,14 @@ class HieCoreFn(torch.autograd.Function):
         stream = HieCoreFn.STREAM and ops.hie_stream_supported(N, L, E, T)
         if stream:
             # ONE pass over img_: the rank-T update, tanh, dropout, and the T-row sums of ti in registers (csrc/hie.hip)
-            part = new(ops.hie_chunks(N, L), MT, E)
-            Hv = ops.hie_hv_fwd(CI[:, E:], C3, CQ[:, E:], drops["Hv"], N, L, T, new(M, E), part)
-            ti = ops.hie_slab_sum(part, new(MT, E))
+            S = ops.hie_chunks(N, L)
+            if S == 1:           # one workgroup per sample: the T-row sums are final, no partial slabs, no slab-sum launch
+                ti = new(MT, E)
+                Hv = ops.hie_hv_fwd(CI[:, E:], C3, CQ[:, E:], drops["Hv"], N, L, T, new(M, E), ti)
+            else:
+                part = new(S, MT, E)
+                Hv = ops.hie_hv_fwd(CI[:, E:], C3, CQ[:, E:], drops["Hv"], N, L, T, new(M, E), part)
+                ti = ops.hie_slab_sum(part, new(MT, E))
         else:
             tq = ops.bgemm(C3, que_3, ta=True, tb=True).view(M, E)
             Hv = ops.tanh_dropout_fwd2d(CI[:, E:], tq, *drops["Hv"], out=tq)
@@ -752,6 +757,9 @@ class HieCoreFn(torch.autograd.Function):
         aq, _ = ops.glimpse_pool_fwd(que.view(N, T, E), ops.att_logits_fwd(Hq, _w2d(whq), bhq), False, pooled_out=xcat[N:])
         ctx.save_for_backward(imgf, ids, img, que, Wi, Wq2, CI, CQ, C3, Hv, Hq, av, aq, whv, whq)
         ctx.drops, ctx.dims, ctx.V, ctx.stream = drops, (N, L, T, D, E), w_que.shape[0], stream
+        # an output nobody differentiates (av / aq under a loss on x: solver.py:84-91) arrives as None in the backward, not as a
+        # zero tensor torch has to fill and the pooling kernels have to read
+        ctx.set_materialize_grads(False)
         return xcat.view(N, 2 * E), av, aq                    # :52-53: cat((v, q), 0).view(N, -1) is a view of xcat
 
     @staticmethod
@@ -762,6 +770,8 @@ class HieCoreFn(torch.autograd.Function):
         drops = ctx.drops
         dev = imgf.device
         new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        if dx is None:
+            dx = torch.zeros((N, 2 * E), dtype=torch.float32, device=dev)
         dxcat = _c(dx).view(2 * N, E)
         dv, dq = dxcat[:N], dxcat[N:]
         Cv3, img_3 = CI[:, :E].view(N, L, E), CI[:, E:].view(N, L, E)
@@ -779,18 +789,25 @@ class HieCoreFn(torch.autograd.Function):
         if ctx.stream:
             # dtq = d(img_ + tq) straight from the logit gradient (dHv = dlv (x) whv is never written), C dtq and dlv^T Hv on the way
             S = ops.hie_chunks(N, L)
-            part, wpart = new(S, MT, E), new(S * N, E + 4)
-            ops.hie_head_bwd(Hv, dlv.view(M), whv.view(E), C3, drops["Hv"], N, L, T, dCI[:, E:], part, wpart)
+            part, wpart = (None if S == 1 else new(S, MT, E)), new(S * N, E + 4)
+            if S == 1:           # dque_ = dti + C dtq written by the pass itself (one workgroup per sample)
+                ops.hie_head_bwd(Hv, dlv.view(M), whv.view(E), C3, drops["Hv"], N, L, T, dCI[:, E:], dCQ[:, E:], wpart, part_add=dti)
+            else:
+                ops.hie_head_bwd(Hv, dlv.view(M), whv.view(E), C3, drops["Hv"], N, L, T, dCI[:, E:], part, wpart)
             wsum = ops.colsum(wpart)
             dwhv, dbhv = wsum[:E], wsum[E:E + 1]
             dC3 = ops.bgemm(dti3, img_3)                                           # dC = dti img_^T + que_ dtq^T
             ops.bgemm(que_3, dtq3, out=dC3, accumulate=True)
-            ops.hie_slab_sum(part, dCQ[:, E:], add=dti)                            # dque_ = dti + C dtq
+            if S > 1:
+                ops.hie_slab_sum(part, dCQ[:, E:], add=dti)                        # dque_ = dti + C dtq
             ops.hie_rank_add(dCI[:, E:], C3, dti, N, L, T, dCI[:, E:])             # dimg_ = dtq + C^T dti (dtq's own uses are above)
             # C = dropout(tanh(Cq Cv^T)):  dCv = daff^T Cq,  dCq = daff Cv   (one pass over Cv)
             ops.tanh_dropout_bwd(dC3.view(MT, L), C3.view(MT, L), *drops["C"], out=dC3.view(MT, L))
-            ops.hie_rank_left(dC3, CQ[:, :E], CI[:, :E], N, L, T, dCI[:, :E], part)
-            ops.hie_slab_sum(part, dCQ[:, :E])
+            if S == 1:
+                ops.hie_rank_left(dC3, CQ[:, :E], CI[:, :E], N, L, T, dCI[:, :E], dCQ[:, :E])      # dCq straight into its column block
+            else:
+                ops.hie_rank_left(dC3, CQ[:, :E], CI[:, :E], N, L, T, dCI[:, :E], part)
+                ops.hie_slab_sum(part, dCQ[:, :E])
         else:
             dHv, dwhv, dbhv, _ = ops.att_logits_bwd(dlv, Hv, _w2d(whv), relu_mask=False)
             ops.tanh_dropout_bwd2d(dHv, Hv, *drops["Hv"], out=dCI[:, E:])          # d(img_ + tq), first term of dimg_

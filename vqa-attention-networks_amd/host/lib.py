@@ -74,10 +74,11 @@ SIGNATURES = {
     "vqf_multi_copy_f32": (c_i, [c_p, c_p, c_p, c_i, c_p]),
     "vqf_hie_stream_supported": (c_i, [c_i, c_i, c_i, c_i]),
     "vqf_hie_chunks": (c_i, [c_i, c_i]),
-    "vqf_hie_hv_fwd": (c_i, [c_f, c_i, c_f, c_f, c_i, c_p, c_u64, ctypes.c_float, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_p]),
-    "vqf_hie_head_bwd": (c_i, [c_f, c_i, c_f, c_f, c_f, c_p, c_u64, ctypes.c_float, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_f, c_p]),
+    "vqf_hie_hv_fwd": (c_i, [c_f, c_i, c_f, c_f, c_i, c_p, c_u64, ctypes.c_float, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_i, c_p]),
+    "vqf_hie_head_bwd": (c_i, [c_f, c_i, c_f, c_f, c_f, c_p, c_u64, ctypes.c_float, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_i, c_f, c_i,
+                               c_f, c_p]),
     "vqf_hie_rank_add": (c_i, [c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_p]),
-    "vqf_hie_rank_left": (c_i, [c_f, c_f, c_i, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_p]),
+    "vqf_hie_rank_left": (c_i, [c_f, c_f, c_i, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_i, c_p]),
     "vqf_hie_slab_sum": (c_i, [c_f, c_i, c_i, c_i, c_f, c_i, c_f, c_i, c_p]),
     "vqf_softmax_rows_fwd": (c_i, [c_f, c_i, c_i, c_f, c_p]),
     "vqf_softmax_rows_bwd": (c_i, [c_f, c_f, c_i, c_i, c_f, c_p]),

@@ -521,26 +521,38 @@ def _chk_ntl(u, N, T, L):
         raise _l.VqfError("hie: the (N, T, L) coefficient tensor has the wrong size")
 
 
+def _part_ld(part, E):
+    """`part` of the streaming passes: (S, N*T, E) contiguous partial slabs, or -- one chunk per sample -- the 2-D destination
+    of the final sums itself (rows may be strided) -> row pitch"""
+    if part.dim() == 3:
+        _chk(part)
+        return E
+    _chk2s(part)
+    return part.stride(0)
+
+
 def hie_hv_fwd(a, C, V, drop, N, L, T, out, part):
-    """out = dropout(tanh(a + C^T V)); part (S, N*T, E) = per-chunk sums of C[t,l] a[l,:]"""
+    """out = dropout(tanh(a + C^T V)); part = the sums of C[t,l] a[l,:] over l: (S, N*T, E) per-chunk slabs, or (S == 1) the
+    final (N*T, E) rows"""
     _chk2s(a, V, out)
-    _chk(part)
     _chk_ntl(C, N, T, L)
     E = a.shape[1]
     keep, seed, p = drop
     _l.check(_lib().vqf_hie_hv_fwd(_ptr(a), a.stride(0), _ptr(C), _ptr(V), V.stride(0), _keep_ptr(keep), int(seed), float(p),
-                                   N, L, E, T, _ptr(out), out.stride(0), _ptr(part), _stream()), "vqf_hie_hv_fwd")
+                                   N, L, E, T, _ptr(out), out.stride(0), _ptr(part), _part_ld(part, E), _stream()), "vqf_hie_hv_fwd")
     return out
 
 
-def hie_head_bwd(hv, dl, w, C, drop, N, L, T, out, part, wpart):
-    _chk2s(hv, out)
-    _chk(dl, w, part, wpart)
+def hie_head_bwd(hv, dl, w, C, drop, N, L, T, out, part, wpart, part_add=None):
+    """part_add (one chunk per sample only): the T-row sums are written on top of these (N*T, E) rows"""
+    _chk2s(hv, out, part_add)
+    _chk(dl, w, wpart)
     _chk_ntl(C, N, T, L)
     E = hv.shape[1]
     keep, seed, p = drop
     _l.check(_lib().vqf_hie_head_bwd(_ptr(hv), hv.stride(0), _ptr(dl), _ptr(w), _ptr(C), _keep_ptr(keep), int(seed), float(p),
-                                     N, L, E, T, _ptr(out), out.stride(0), _ptr(part), _ptr(wpart), _stream()), "vqf_hie_head_bwd")
+                                     N, L, E, T, _ptr(out), out.stride(0), _ptr(part), _part_ld(part, E), _ptr(part_add),
+                                     part_add.stride(0) if part_add is not None else 0, _ptr(wpart), _stream()), "vqf_hie_head_bwd")
     return out
 
 
@@ -554,10 +566,9 @@ def hie_rank_add(a, U, V, N, L, T, out):
 
 def hie_rank_left(U, V, z, N, L, T, out, part):
     _chk2s(V, z, out)
-    _chk(part)
     _chk_ntl(U, N, T, L)
     _l.check(_lib().vqf_hie_rank_left(_ptr(U), _ptr(V), V.stride(0), _ptr(z), z.stride(0), N, L, z.shape[1], T, _ptr(out),
-                                      out.stride(0), _ptr(part), _stream()), "vqf_hie_rank_left")
+                                      out.stride(0), _ptr(part), _part_ld(part, z.shape[1]), _stream()), "vqf_hie_rank_left")
     return out
 
 
