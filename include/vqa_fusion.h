@@ -87,7 +87,12 @@ const char* vqf_build_info(void);
 #define VQF_OPT_GEMM_F32_STREAMK 14   /* 1 = stream-K tail in the large-tile fp32 GEMM: the K slabs of a mid-size product's partial last round are
                                         shared out evenly over the CUs, 2-3 part images per tail tile combined in the launch (opt-in:
                                         measured a wash against the default, the whole-rounds row split; csrc/gemm_f32_big.hip) */
-#define VQF_OPT_COUNT 15
+#define VQF_OPT_GEMM_SPLITK_ORDER 15  /* 1 = split-K launches of the large-tile kernels remap work items to XCDs over all (split, tile) items
+                                        jointly: the 32 CUs of an XCD take 32 / tiles_n row tiles x ALL column tiles of one split at a time.
+                                        Same bits.  Measured (profiles/r05_splitk_order_pmc.txt): the image projection's fp32 weight
+                                        gradient moves 6.86 instead of 10.34 GB beyond L2 (bf16: 4.35 / 4.86) and takes 1.4 % LONGER
+                                        (14.68 vs 14.48 ms; bf16 2.29 vs 2.27): opt-in, for a fabric that has something else to carry */
+#define VQF_OPT_COUNT 16
 int vqf_set_option(int option, int value, int* previous);
 int vqf_get_option(int option, int* value);
 /* the environment variable read for `option` at load time: "VQF_" + the name of its VQF_OPT_* constant ("" if unknown) */

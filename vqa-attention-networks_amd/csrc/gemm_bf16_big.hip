@@ -37,6 +37,7 @@
 // Preconditions (else the caller falls back to gemm_bf16.hip): K % 32 == 0, M >= 256, N >= 128, no
 // accumulate flag, a K-major operand's row extent % 8 == 0; 16-byte aligned bases, lda/ldb % 8 == 0.
 #include "common.h"
+#include <algorithm>
 #include <stdlib.h>
 
 namespace {
@@ -72,6 +73,7 @@ struct BigArgs {
   int M, N, K, lda, ldb, ldc, flags;
   int tiles_m, tiles_n, kchunk, splits;
   int group_m;           // row tiles per group of the tile order (pick_group_m)
+  int joint;             // split-K launches: the XCD remap runs over ALL (split, tile) items jointly (tile_coord)
   // split-K combined in the launch (common.h vqf_splitk_combine): arrival counters (one per output tile) and the real
   // destination -- C / ldc above then describe the slabs; cnt == nullptr: the caller runs vqf_splitk_reduce
   int* cnt;
@@ -153,11 +155,23 @@ __device__ __forceinline__ bf16x8 read_frag(const char* s, int row0, int ks, int
 // ---- tile order: split index slowest; bijective XCD remap (blocks b and b + 8 share an XCD's L2: each XCD walks a
 // contiguous run of the linear order), then groups of GROUP_M row tiles x all column tiles, row tile fastest
 struct TileCoord { int z, m0, n0, kbeg; };
+// JOINT form (split-K launches, round 5): the remap runs over all splits x tiles items, so an XCD's contiguous run walks whole
+// groups of group_m = 32 / tiles_n row tiles x ALL column tiles of ONE split -- 32 tiles, one per CU of the XCD, that share
+// group_m A panels and every B panel of that K range (the per-split remap handed an XCD 20 of a split's 160 tiles and 12 of the
+// next split's: a 5 x 4 rectangle, each A panel fetched by two XCDs and each B panel by four: 5.8 GB beyond L2 for 1.46 GB of
+// operands in the image projection's bf16 weight gradient, profiles/r04_pmc_gemm.txt).
 __device__ __forceinline__ TileCoord tile_coord(const BigArgs& g, int w) {    // w: work item (tile x split)
   const int ntiles = g.tiles_m * g.tiles_n;
-  const int z = w / ntiles;
-  int id = w % ntiles;
-  {
+  int z, id;
+  if (g.joint) {
+    const int ntot = ntiles * g.splits;
+    const int q8 = ntot / 8, r8 = ntot % 8, xcd = w % 8, k = w / 8;
+    id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
+    z = id / ntiles;
+    id -= z * ntiles;
+  } else {
+    z = w / ntiles;
+    id = w % ntiles;
     const int q8 = ntiles / 8, r8 = ntiles % 8, xcd = id % 8, k = id / 8;
     id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
   }
@@ -785,6 +799,11 @@ int vqf_gemm_bf16_big_try(int ta, int tb, int M, int N, int K, const void* A, in
     if (tiles >= 64 && vqf_opt(VQF_OPT_GEMM_SPLITK_FUSED, 1) != 0) g.cnt = vqf_splitk_counters(tiles);   // (as gemm_f32_big.hip)
   }
   g.group_m = pick_group_m(g.tiles_m, g.tiles_n, splits);
+  g.joint = 0;
+  if (splits > 1 && g.tiles_n <= 32 && 32 % g.tiles_n == 0 && vqf_opt(VQF_OPT_GEMM_SPLITK_ORDER, 0) == 1) {
+    g.joint = 1;                                        // an XCD's 32 CUs take group_m row tiles x all column tiles of one split
+    g.group_m = std::min(g.tiles_m, 32 / g.tiles_n);
+  }
 #ifdef VQF_PP_STAMPS
   g.dbg = (splits == 1 && ws && ws_bytes >= (size_t)tiles * 8 * 8 * 8) ? (unsigned long long*)ws : nullptr;
 #endif

@@ -68,6 +68,7 @@ struct BigArgs {
   int M, N, K, lda, ldb, ldc, flags;
   int tiles_m, tiles_n, kchunk, splits;
   int group_m;           // row tiles per group of the tile order (pick_group_m)
+  int joint;             // split-K launches: XCD remap over all (split, tile) items jointly (gemm_bf16_big.hip tile_coord has the argument)
   // two-phase work order (see gemm_f32_big_kernel): phase 1 walks the column tiles 0 .. tiles_n_full-1 (all of them, or all
   // but a SHORT last one), phase 2 deals the short edge tiles e = 0 .. tiles_m-1 (column tile tiles_n-1) to the workgroups
   // (edge_w0 + e % edge_wn) % gridDim.x
@@ -494,13 +495,19 @@ __global__ void __launch_bounds__(NT, 2) gemm_f32_big_kernel(const BigArgs g) {
 #ifdef VQF_F32BIG_CLOCK
       w_dbg = cur_w;
 #endif
-      z = cur_w / ntiles1;
-      int id = cur_w % ntiles1;
-      cur_w += G;
-      {
+      int id;
+      if (g.joint) {                                   // split-K: an XCD's run walks whole (split, row group) units of 32 tiles
+        const int q8 = F / 8, r8 = F % 8, xcd = cur_w % 8, k = cur_w / 8;
+        id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
+        z = id / ntiles1;
+        id -= z * ntiles1;
+      } else {
+        z = cur_w / ntiles1;
+        id = cur_w % ntiles1;
         const int q8 = ntiles1 / 8, r8 = ntiles1 % 8, xcd = id % 8, k = id / 8;
         id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
       }
+      cur_w += G;
       const int per_group = g.group_m * g.tiles_n_full;
       const int grp = id / per_group, in = id % per_group;
       const int gm0 = grp * g.group_m;
@@ -915,6 +922,11 @@ int vqf_gemm_f32_big_try(int ta, int tb, int M, int N, int K, const float* A, in
   g.tiles_n_full = edge_opt ? g.tiles_n - 1 : g.tiles_n;
   g.edge_w0 = 0; g.edge_wn = 1;
   g.group_m = pick_group_m(g.tiles_m, g.tiles_n_full, splits);
+  g.joint = 0;
+  if (splits > 1 && g.sk_tail == 0 && g.tiles_n <= 32 && 32 % g.tiles_n == 0 && vqf_opt(VQF_OPT_GEMM_SPLITK_ORDER, 0) == 1) {
+    g.joint = 1;                                        // an XCD's 32 CUs take group_m row tiles x all column tiles of one split
+    g.group_m = std::min(g.tiles_m, 32 / g.tiles_n);
+  }
 #ifdef VQF_F32BIG_CLOCK
   g.dbg = (splits == 1 && ws && ws_bytes >= (size_t)tiles * 2 * 8 * 8) ? (unsigned long long*)ws : nullptr;
 #endif

@@ -68,7 +68,8 @@ def workspace(device, nbytes):
 # library options (include/vqa_fusion.h VQF_OPT_*): process-wide launch policy, cached in the library
 OPTIONS = {"gemm_f32_persist": 0, "gemm_bf16_persist": 1, "gemm_f32_loop": 2, "gemm_bf16_loop": 3, "gemm_f32_big": 4,
            "gemm_bf16_big": 5, "gemm_f32_wave": 6, "fuse_coal": 7, "fuse_ls": 8, "fuse_ls_bwd": 9, "gemm_cu_limit": 10,
-           "gemm_f32_edge": 11, "gemm_f32_rounds": 12, "gemm_splitk_fused": 13, "gemm_f32_streamk": 14}
+           "gemm_f32_edge": 11, "gemm_f32_rounds": 12, "gemm_splitk_fused": 13, "gemm_f32_streamk": 14,
+           "gemm_splitk_order": 15}
 
 
 def set_option(name, value):
