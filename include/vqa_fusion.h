@@ -92,7 +92,10 @@ const char* vqf_build_info(void);
                                         Same bits.  Measured (profiles/r05_splitk_order_pmc.txt): the image projection's fp32 weight
                                         gradient moves 6.86 instead of 10.34 GB beyond L2 (bf16: 4.35 / 4.86) and takes 1.4 % LONGER
                                         (14.68 vs 14.48 ms; bf16 2.29 vs 2.27): opt-in, for a fabric that has something else to carry */
-#define VQF_OPT_COUNT 16
+#define VQF_OPT_GEMM_F32_SAMPLE 16    /* 0 = vqf_gemm_f32_sample reports every shape unsupported, i.e. HieCoAtten's per-sample products run on the
+                                        256x256 / 128x128 kernels as in round 4 (A/B); 2 = it takes every shape it can run, also batches whose
+                                        NS * N / 256 work items fill less than half of the CUs (default: those stay on vqf_gemm_f32) */
+#define VQF_OPT_COUNT 17
 int vqf_set_option(int option, int value, int* previous);
 int vqf_get_option(int option, int* value);
 /* the environment variable read for `option` at load time: "VQF_" + the name of its VQF_OPT_* constant ("" if unknown) */
@@ -106,7 +109,8 @@ const char* vqf_option_env_name(int option);
 #define VQF_STAT_GEMM_F32_WAVE 2     /* csrc/gemm_f32_wave.hip, one tile per wave (small M)        */
 #define VQF_STAT_GEMM_BF16_TILE128 3 /* csrc/gemm_bf16.hip                                         */
 #define VQF_STAT_GEMM_BF16_BIG 4     /* csrc/gemm_bf16_big.hip                                     */
-#define VQF_STAT_COUNT 5
+#define VQF_STAT_GEMM_F32_SAMPLE 5   /* csrc/gemm_f32_sample.hip, one sample's rows x 256 columns per workgroup */
+#define VQF_STAT_COUNT 6
 int vqf_stat_get(int stat, long long* value);
 
 /* --------------------------------------------------------------------------
@@ -149,6 +153,17 @@ int vqf_gemm_f32_rowscale(int ta, int tb, int M, int N, int K, const float* A, i
  * of 256 rows); the remaining M - rows rows are a second launch on the other kernels.  Depends on the library options
  * gemm_f32_big / gemm_f32_rounds and the device's CU count only. */
 int vqf_gemm_f32_big_rows(int ta, int tb, int M, int N, int K);
+/* Per-sample-tile product (csrc/gemm_f32_sample.hip; hieCoAtten.py:25,30,35 and their input gradients at BASELINE config 4):
+ * C (NS*L, N) = A (NS*L, K) * Bop^T (+ bias) (VQF_GEMM_RELU), A row-major with the rows of sample n at n*L .. n*L + L - 1,
+ * B (N, K) (tb = 0) or (K, N) (tb = 1).  One workgroup owns a sample's L rows x 256 columns: NS * N / 256 work items, a whole
+ * number of rounds of the CUs for NS = 256 where 256x256 tiles leave 1.53; L = 192 + 4e rows = six 32-row MFMA tiles + e
+ * four-row groups on v_mfma_f32_4x4x1_16B_f32 (no padded rows).  Same bits as vqf_gemm_f32 on the same operands.
+ * Supported (vqf_gemm_f32_sample_supported): 192 <= L <= 220, L % 4 == 0, N % 256 == 0, K % 16 == 0, K >= 64; only the
+ * VQF_GEMM_RELU flag, and (unless option gemm_f32_sample = 2) NS * N / 256 >= half the CU count; else VQF_E_UNSUPPORTED (the
+ * caller uses vqf_gemm_f32). */
+int vqf_gemm_f32_sample_supported(int NS, int L, int N, int K);
+int vqf_gemm_f32_sample(int tb, int NS, int L, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                        const float* bias, int flags, void* stream);
 
 /* Batched form: for b < batch, C_b = Aop_b * Bop_b^T with A_b = A + b*strideA etc.
  * (element strides).  No bias, no split-K.  Per-sample products of

@@ -452,3 +452,44 @@ def test_stream_k_tail_of_the_large_tile_kernel(ops, ta, tb, M, N, K, extras):
     d = (out - old).abs().max().item()
     assert d <= 4e-6 * float(ref.abs().max())       # whole tiles are bit-equal, tail tiles re-associate 2-3 partial sums
     assert not torch.equal(out, old)
+
+
+@pytest.mark.parametrize("NS,L,N,K,tb", [(20, 196, 512, 2048, False), (7, 196, 256, 64, False), (9, 200, 512, 512, False),
+                                         (5, 192, 256, 128, False), (3, 220, 256, 96, False),
+                                         (20, 196, 512, 1024, True), (6, 204, 256, 64, True), (256, 196, 512, 512, True)])
+def test_per_sample_tile_gemm_vs_fp64_and_the_other_kernels(NS, L, N, K, tb):
+    """vqf_gemm_f32_sample (csrc/gemm_f32_sample.hip: a sample's L = 192 + 4 e rows x 256 columns per workgroup, the ragged rows on
+    v_mfma_f32_4x4x1_16B_f32; hieCoAtten.py:25,30,35 and their input gradient at config 4's shapes): both B layouts, bias, ReLU,
+    row-strided operands and output, 0 .. 7 ragged row groups -- against fp64 (2e-6 * max(1, sqrt(K) / 8), norm-relative and
+    per-row for the ragged rows), and against vqf_gemm_f32 on the same operands: the k order is the same, so the bits are."""
+    import vqa_amd
+    ops = vqa_amd.ops
+    g = torch.Generator().manual_seed(NS * 1000 + L + N + K)
+    M = NS * L
+    A = torch.randn((M, K + 8), generator=g).cuda()[:, :K]                       # row stride K + 8
+    Bm = (torch.randn((K, N) if tb else (N, K), generator=g) * 0.05).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    n0 = ops.stat("gemm_f32_sample")
+    for relu in (False, True):
+        outbuf = torch.full((M, N + 4), 7.0, device="cuda")                      # strided output, canary columns
+        with ops.options(gemm_f32_sample=2):                                     # also the batches too small for it to pay
+            C = ops.gemm_rows(A, Bm, L, tb=tb, bias=bias, relu=relu, out=outbuf[:, :N])
+        ref = A.double() @ (Bm.double() if tb else Bm.double().t()) + bias.double()
+        if relu:
+            ref = torch.relu(ref)
+        tol = 2e-6 * max(1.0, K ** 0.5 / 8)
+        assert float((C.double() - ref).norm() / ref.norm()) <= tol
+        rag = torch.cat([torch.arange(n * L + 192, (n + 1) * L) for n in range(NS)]).cuda() if L > 192 else None
+        if rag is not None:                                                      # the 4x4x1 rows on their own
+            assert float((C[rag].double() - ref[rag]).norm() / ref[rag].norm()) <= tol
+        assert float((outbuf[:, N:] - 7.0).abs().max()) == 0.0                   # nothing written past the N columns
+        C2 = ops.gemm(A.contiguous(), Bm, tb=tb, bias=bias, relu=relu, splitk=False)     # (an unsplit launch: one k-ordered chain per element)
+        diff = (C.contiguous() != C2)
+        assert not bool(diff.any()), ("per-sample tiles and vqf_gemm_f32 add k in the same order; rows that differ: %s"
+                                      % sorted(set((diff.any(1).nonzero().flatten() % L).tolist()))[:12])
+    assert ops.stat("gemm_f32_sample") == n0 + 2
+    with ops.options(gemm_f32_sample=0):                                         # the A/B switch routes back to vqf_gemm_f32
+        ops.gemm_rows(A, Bm, L, tb=tb, bias=bias)
+    assert ops.stat("gemm_f32_sample") == n0 + 2
+    ops.gemm_rows(A, Bm, L, tb=tb, bias=bias)                                    # default: only where the items fill half the chip
+    assert ops.stat("gemm_f32_sample") == n0 + 2 + (1 if NS * (N // 256) >= 128 else 0)

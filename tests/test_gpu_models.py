@@ -556,6 +556,7 @@ def test_config3_mhbcoatt_batch_512_bf16_mode(bf16_mode):
         torch.nn.KLDivLoss()(out, soft_d).backward()
         torch.cuda.synchronize()
         res[mode] = (out.detach().clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters()})
+        del out                              # (no graph of the previous mode alive across the switch: tests/test_gpu_bf16.py)
     out, gb = res[bf16_mode]
     assert torch.allclose(out.exp().sum(1).cpu(), torch.ones(512), atol=1e-4)
     assert all(torch.isfinite(v).all() for v in gb.values())

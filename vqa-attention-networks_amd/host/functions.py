@@ -718,7 +718,8 @@ class HieCoreFn(torch.autograd.Function):
         dev = imgf.device
         new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
         # :25-26  img = dropout(relu(img_emb(img_features)))   (ReLU in the GEMM epilogue, the dropout in place)
-        img = ops.gemm(imgf.view(M, D), _c(w_emb), bias=b_emb, relu=True)
+        # (per-sample tiles where the library takes the shape: 256 samples x 196 regions = one workgroup per CU, csrc/gemm_f32_sample.hip)
+        img = ops.gemm_rows(imgf.view(M, D), _c(w_emb), L, bias=b_emb, relu=True)
         ops.dropout(img, *drops["img"], out=img)
         # :27-28  que = dropout(que_emb(que_features))
         que = ops.embed_tanh_fwd(_c(w_que), ids, False).view(MT, E)
@@ -727,7 +728,7 @@ class HieCoreFn(torch.autograd.Function):
         Wi, bi, Wq2, bq2 = new(2 * E, E), new(2 * E), new(2 * E, E), new(2 * E)
         ops.multi_copy([(_c(wbv), Wi[:E]), (_c(wv), Wi[E:]), (bbv, bi[:E]), (bv, bi[E:]),
                         (_c(wbv), Wq2[:E]), (_c(wq), Wq2[E:]), (bbv, bq2[:E]), (bq, bq2[E:])])
-        CI = ops.gemm(img, Wi, bias=bi)                       # (M, 2E)  = [Cv | img_]
+        CI = ops.gemm_rows(img, Wi, L, bias=bi)               # (M, 2E)  = [Cv | img_]
         CQ = ops.gemm(que, Wq2, bias=bq2)                     # (MT, 2E) = [Cq | que_]
         Cv3, img_3 = CI[:, :E].view(N, L, E), CI[:, E:].view(N, L, E)
         Cq3, que_3 = CQ[:, :E].view(N, T, E), CQ[:, E:].view(N, T, E)
@@ -822,7 +823,7 @@ class HieCoreFn(torch.autograd.Function):
             ops.bgemm(dC3, Cv3, ta=False, tb=True, out=dCQ[:, :E].view(N, T, E))
             ops.bgemm(dC3, Cq3, ta=True, tb=True, out=dCI[:, :E].view(N, L, E))
         # the concatenated layers: one input-gradient product (K = 2E), one weight-gradient product and one column sum per side
-        dimg = ops.gemm(dCI, Wi, tb=True)                                      # (M, E); the pool's rank-1 term is added below
+        dimg = ops.gemm_rows(dCI, Wi, L, tb=True)                              # (M, E); the pool's rank-1 term is added below
         ops.gemm(dCQ, Wq2, tb=True, out=dque.view(MT, E), accumulate=True)     # on top of the pool's gradient into que
         dWi, dWq2 = ops.gemm(dCI, img, ta=True, tb=True), ops.gemm(dCQ, que, ta=True, tb=True)
         dbi, dbq2 = ops.colsum(dCI), ops.colsum(dCQ)

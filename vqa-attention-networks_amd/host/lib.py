@@ -40,6 +40,8 @@ SIGNATURES = {
     "vqf_gemm_f32_ws_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i]),
     "vqf_gemm_f32": (c_i, [c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_i, c_f, c_i, c_f, c_i, c_p, c_sz, c_p]),
     "vqf_gemm_f32_big_rows": (c_i, [c_i, c_i, c_i, c_i, c_i]),
+    "vqf_gemm_f32_sample_supported": (c_i, [c_i, c_i, c_i, c_i]),
+    "vqf_gemm_f32_sample": (c_i, [c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_i, c_f, c_i, c_f, c_i, c_p]),
     "vqf_gemm_f32_rowscale": (c_i, [c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_i, c_f, c_i, c_f, c_i, c_f, c_i, c_p]),
     "vqf_gemm_f32_batched": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, ctypes.c_longlong,
                                    c_f, c_i, ctypes.c_longlong, c_f, c_i, ctypes.c_longlong, c_i, c_p]),

@@ -69,7 +69,7 @@ def workspace(device, nbytes):
 OPTIONS = {"gemm_f32_persist": 0, "gemm_bf16_persist": 1, "gemm_f32_loop": 2, "gemm_bf16_loop": 3, "gemm_f32_big": 4,
            "gemm_bf16_big": 5, "gemm_f32_wave": 6, "fuse_coal": 7, "fuse_ls": 8, "fuse_ls_bwd": 9, "gemm_cu_limit": 10,
            "gemm_f32_edge": 11, "gemm_f32_rounds": 12, "gemm_splitk_fused": 13, "gemm_f32_streamk": 14,
-           "gemm_splitk_order": 15}
+           "gemm_splitk_order": 15, "gemm_f32_sample": 16}
 
 
 def set_option(name, value):
@@ -86,7 +86,8 @@ def get_option(name):
     return v.value
 
 
-STATS = {"gemm_f32_tile128": 0, "gemm_f32_big": 1, "gemm_f32_wave": 2, "gemm_bf16_tile128": 3, "gemm_bf16_big": 4}
+STATS = {"gemm_f32_tile128": 0, "gemm_f32_big": 1, "gemm_f32_wave": 2, "gemm_bf16_tile128": 3, "gemm_bf16_big": 4,
+         "gemm_f32_sample": 5}
 
 
 def stat(name):
@@ -146,6 +147,28 @@ def gemm(a, b, ta=False, tb=False, bias=None, relu=False, out=None, accumulate=F
                              _ptr(out), out.stride(0), _ptr(bias), flags,
                              _ptr(ws), ws.numel() if ws is not None else 0, _stream())
     _l.check(rc, "vqf_gemm_f32")
+    return out
+
+
+def gemm_rows(a, b, L, tb=False, bias=None, relu=False, out=None):
+    """C = a @ bop^T (+ bias) (relu) for a (NS*L, K) whose rows come in samples of L rows (the image regions of a sample): the
+    per-sample-tile kernel (include/vqa_fusion.h vqf_gemm_f32_sample) where it takes the shape, vqf_gemm_f32 otherwise.
+    b: (N, K), or (K, N) with tb; rows of a / b / out may be strided."""
+    M, K = a.shape
+    N = b.shape[1] if tb else b.shape[0]
+    ok = (L > 0 and M % L == 0 and a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.dim() == 2 and b.dim() == 2
+          and a.stride(1) == 1 and b.stride(1) == 1 and (b.shape[0] if tb else b.shape[1]) == K
+          and _lib().vqf_gemm_f32_sample_supported(M // L, L, N, K)
+          and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0 and a.stride(0) % 4 == 0 and b.stride(0) % 4 == 0)
+    if out is not None:
+        ok = ok and out.dtype == torch.float32 and out.dim() == 2 and out.stride(1) == 1 and out.stride(0) % 2 == 0 and out.data_ptr() % 8 == 0
+    if not ok:
+        return gemm(a, b, tb=tb, bias=bias, relu=relu, out=out)
+    _chk(bias)
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    _l.check(_lib().vqf_gemm_f32_sample(int(bool(tb)), M // L, int(L), N, K, _ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(out),
+                                        out.stride(0), _ptr(bias), GEMM_RELU if relu else 0, _stream()), "vqf_gemm_f32_sample")
     return out
 
 
