@@ -281,11 +281,13 @@ def pmc_kernel_lookup(name):
     return None, None
 
 
-def gemm_roofline(ops, kernel_id, dtype, M, N, K, what, peak, ta=0, tb=0):
+def gemm_roofline(ops, kernel_id, dtype, M, N, K, what, peak, ta=0, tb=0, sample_rows=0):
     """roofline object of one GEMM of the step, timed by the library's hipEvent profiler (shape-tagged launches).  A mid-size
     fp32 product is TWO launches (vqf_gemm_f32_big_rows: whole rounds of the 256x256-tile kernel + the remaining rows on the
     128x128 kernel): the object then covers both -- all of the product's FLOPs over the sum of the two durations."""
     rows = ops.gemm_big_rows(ta, tb, M, N, K) if dtype == "f32" else M
+    if sample_rows and not ta and ops.gemm_rows_supported(M // sample_rows, sample_rows, N, K):
+        rows = M                     # one launch of the per-sample-tile kernel (csrc/gemm_f32_sample.hip)
     parts = [M] if rows in (0, M) else [rows, M - rows]
     n, ms, per = None, 0.0, []
     for m in parts:
@@ -502,8 +504,9 @@ def secondary_config(vqa_amd, which, dev, steps, warmup):
     else:
         M, N, K = B * 196, 512, 2048
         roof = gemm_roofline(ops, "gemm_f32_a0b0(fwd)", "f32", M, N, K,
-                             "img_emb forward GEMM + bias + ReLU (M=%d,N=%d,K=%d; hieCoAtten.py:25; profiler id "
-                             "gemm_f32_a0b0)" % (M, N, K), FP32_MFMA_PEAK_TFLOPS)
+                             "img_emb forward GEMM + bias + ReLU (M=%d,N=%d,K=%d; hieCoAtten.py:25; gemm_f32_sample.hip: one workgroup "
+                             "per sample x 256 columns, 6 row tiles of 32x32x2 + 4 rows on 4x4x1; profiler id gemm_f32_a0b0)" % (M, N, K),
+                             FP32_MFMA_PEAK_TFLOPS, sample_rows=196)
         if roof is not None:
             w = gemm_roofline(ops, "gemm_f32_a1b1(wgrad)", "f32", N, K, M, "its weight gradient (M=%d,N=%d,K=%d)" % (N, K, M),
                               FP32_MFMA_PEAK_TFLOPS, ta=1, tb=1)
@@ -949,6 +952,7 @@ def main():
     is_bf16 = args.dtype != "f32" and args.model != "hieCoAtten"
     Nn = 512 if args.model == "hieCoAtten" else 5000
     M, N, K = B * 196, Nn, 2048
+    sample_rows = 196 if args.model == "hieCoAtten" else 0
     peak = BF16_MFMA_PEAK_TFLOPS if is_bf16 else FP32_MFMA_PEAK_TFLOPS
     fam = ("gemm_bf16", "gemm_bf16") if is_bf16 else ("gemm_f32_a0b0(fwd)", "gemm_f32_a1b1(wgrad)")
     proj = "img_emb" if args.model == "hieCoAtten" else "img_conv1d"
@@ -956,8 +960,8 @@ def main():
             "accumulate; profiler id gemm_bf16)" % (proj, M, N, K)) if is_bf16 else (
         "%s forward GEMM (M=%d,N=%d,K=%d; %s; profiler id gemm_f32_a0b0)"
         % (proj, M, N, K, "gemm_f32_big.hip, 256x256 tiles, LDS-DMA, staggered wave halves" if Nn == 5000
-           else "gemm_f32_big.hip on whole rounds of 256x256 tiles + gemm_f32.hip 128x128 tiles on the remaining rows"))
-    roofline = gemm_roofline(ops, fam[0], "bf16" if is_bf16 else "f32", M, N, K, what, peak)
+           else "gemm_f32_sample.hip: one workgroup per sample x 256 columns"))
+    roofline = gemm_roofline(ops, fam[0], "bf16" if is_bf16 else "f32", M, N, K, what, peak, sample_rows=sample_rows)
     flops = 2.0 * M * N * K
     if roofline is not None:
         w = gemm_roofline(ops, fam[1], "bf16" if is_bf16 else "f32", N, K, M,

@@ -156,9 +156,9 @@ int vqf_gemm_f32_big_rows(int ta, int tb, int M, int N, int K);
 /* Per-sample-tile product (csrc/gemm_f32_sample.hip; hieCoAtten.py:25,30,35 and their input gradients at BASELINE config 4):
  * C (NS*L, N) = A (NS*L, K) * Bop^T (+ bias) (VQF_GEMM_RELU), A row-major with the rows of sample n at n*L .. n*L + L - 1,
  * B (N, K) (tb = 0) or (K, N) (tb = 1).  One workgroup owns a sample's L rows x 256 columns: NS * N / 256 work items, a whole
- * number of rounds of the CUs for NS = 256 where 256x256 tiles leave 1.53; L = 192 + 4e rows = six 32-row MFMA tiles + e
+ * number of rounds of the CUs for NS = 256 where 256x256 tiles leave 1.53; L = 192 + 4e rows = six 32-row MFMA tiles + e <= 1
  * four-row groups on v_mfma_f32_4x4x1_16B_f32 (no padded rows).  Same bits as vqf_gemm_f32 on the same operands.
- * Supported (vqf_gemm_f32_sample_supported): 192 <= L <= 220, L % 4 == 0, N % 256 == 0, K % 16 == 0, K >= 64; only the
+ * Supported (vqf_gemm_f32_sample_supported): L = 192 or 196, N % 256 == 0, K % 16 == 0, K >= 64; only the
  * VQF_GEMM_RELU flag, and (unless option gemm_f32_sample = 2) NS * N / 256 >= half the CU count; else VQF_E_UNSUPPORTED (the
  * caller uses vqf_gemm_f32). */
 int vqf_gemm_f32_sample_supported(int NS, int L, int N, int K);

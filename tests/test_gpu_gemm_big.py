@@ -454,13 +454,13 @@ def test_stream_k_tail_of_the_large_tile_kernel(ops, ta, tb, M, N, K, extras):
     assert not torch.equal(out, old)
 
 
-@pytest.mark.parametrize("NS,L,N,K,tb", [(20, 196, 512, 2048, False), (7, 196, 256, 64, False), (9, 200, 512, 512, False),
-                                         (5, 192, 256, 128, False), (3, 220, 256, 96, False),
-                                         (20, 196, 512, 1024, True), (6, 204, 256, 64, True), (256, 196, 512, 512, True)])
+@pytest.mark.parametrize("NS,L,N,K,tb", [(20, 196, 512, 2048, False), (7, 196, 256, 64, False), (9, 196, 512, 512, False),
+                                         (5, 192, 256, 128, False), (3, 196, 256, 96, False),
+                                         (20, 196, 512, 1024, True), (6, 192, 256, 64, True), (256, 196, 512, 512, True)])
 def test_per_sample_tile_gemm_vs_fp64_and_the_other_kernels(NS, L, N, K, tb):
     """vqf_gemm_f32_sample (csrc/gemm_f32_sample.hip: a sample's L = 192 + 4 e rows x 256 columns per workgroup, the ragged rows on
     v_mfma_f32_4x4x1_16B_f32; hieCoAtten.py:25,30,35 and their input gradient at config 4's shapes): both B layouts, bias, ReLU,
-    row-strided operands and output, 0 .. 7 ragged row groups -- against fp64 (2e-6 * max(1, sqrt(K) / 8), norm-relative and
+    row-strided operands and output, with and without the ragged row group -- against fp64 (2e-6 * max(1, sqrt(K) / 8), norm-relative and
     per-row for the ragged rows), and against vqf_gemm_f32 on the same operands: the k order is the same, so the bits are."""
     import vqa_amd
     ops = vqa_amd.ops

@@ -23,6 +23,11 @@ elif args.shape == "hie_fwd":  # HieCoAtten img_emb (hieCoAtten.py:25), B = 256:
     B = (torch.randn((512, 2048), generator=g) * 0.03).cuda()
     ta = tb = False
     bias = torch.zeros(512, device="cuda")
+elif args.shape == "hie_dgrad":  # d img = [dCv | dimg_] [Wbv; Wv]  (input gradient of hieCoAtten.py:30,35), B = 256, per-sample tiles
+    A = torch.randn((256 * 196, 1024), generator=g).cuda()
+    B = (torch.randn((1024, 512), generator=g) * 0.03).cuda()
+    ta, tb = False, True
+    bias = None
 elif args.shape == "hie_wgrad":
     A = ((torch.rand((256 * 196, 512), generator=g) - 0.5) * 0.1).cuda()
     B = torch.relu(torch.randn((256 * 196, 2048), generator=g)).cuda()
@@ -41,6 +46,8 @@ else:                          # dW = dP^T X            (autograd of mfb.py:96),
 if args.dtype == "bf16":
     A, B = A.to(torch.bfloat16), B.to(torch.bfloat16)
     fn = lambda: ops.gemm_bf16(A, B, ta=ta, tb=tb, bias=bias, out_bf16=args.out_bf16)
+elif args.shape in ("hie_fwd", "hie_dgrad"):      # per-sample tiles (csrc/gemm_f32_sample.hip) where the library takes the shape
+    fn = lambda: ops.gemm_rows(A, B, 196, tb=tb, bias=bias)
 else:
     fn = lambda: ops.gemm(A, B, ta=ta, tb=tb, bias=bias)
 for _ in range(args.reps):

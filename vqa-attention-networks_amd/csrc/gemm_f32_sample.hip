@@ -1,5 +1,5 @@
 // Per-sample-tile fp32 GEMM (gfx950): C[m, n] = sum_k A[m, k] * Bop[n, k] (+ bias[n]) (relu) for row-major A (M = NS * L rows,
-// K contiguous) whose rows come in SAMPLES of L = 192 + 4 e rows (e = 0 .. 7; HieCoAtten's 196 image regions,
+// K contiguous) whose rows come in SAMPLES of L = 192 + 4 e rows (e = 0 or 1; HieCoAtten's 196 image regions,
 // hieCoAtten.py:25,30,35 and the input gradient of :30,35).
 //
 // Why: BASELINE config 4 (B = 256) multiplies 50176 x 512 outputs.  On 256 x 256 tiles that is 392 tiles = 1.53 rounds of the
@@ -26,11 +26,12 @@ namespace {
 typedef const float __attribute__((address_space(1))) gfloat;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int TK = 16, NT = 512, TN = 256, RA = 256;     // RA: A rows staged per slab (a sample's L <= 220 rows + the next sample's first ones, unused)
+constexpr int TK = 16, NT = 512, TN = 256, RA = 256;     // RA: A rows staged per slab (a sample's L <= 200 rows + the next sample's first ones, unused)
 constexpr int ROW_B = TK * 4, CH = ROW_B / 16;           // K-contiguous image: 64-byte rows, 4 chunks of 16 bytes
 constexpr int OP_BYTES = 256 * ROW_B;                    // 16 KB per operand per slab (either layout)
 constexpr int SLOT_BYTES = 2 * OP_BYTES, NSLOT = 5, SMEM = NSLOT * SLOT_BYTES;
 constexpr int NG = OP_BYTES / (NT * 16);                 // 2 LDS-DMA instructions per thread per operand per slab
+constexpr int MAXRAG = 1;                                // ragged 4-row groups per sample: L = 192 or 196 (its operands stay in registers for a whole slab)
 
 struct SampleArgs {
   const float* A; const float* B; float* C; const float* bias;
@@ -113,18 +114,40 @@ __global__ void __launch_bounds__(NT, 2) gemm_f32_sample_kernel(const SampleArgs
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave & 1, wc = wave >> 1;                 // rows wr*96 .. +95 of the sample, columns wc*64 .. +63 of the tile
-  const int nrag = (g.L - 192) >> 2;                       // ragged 4-row groups (196 rows: one), all owned by waves 0-3 (column group = wave)
+  const int late = wave >> 2;                              // waves 4-7: the half that runs half a slab behind (they share SIMDs with waves 0-3)
+  const int nrag = (g.L - 192) >> 2;                       // ragged 4-row groups (196 rows: one) ...
+  // ... x four 64-column groups, one per SIMD and two per wave half: group rg on wave 0, 1 (early half), 6, 7 (late half)
+  const int rg = wave < 2 ? wave : wave - 4;
+  const bool ragged = nrag > 0 && (wave < 2 || wave >= 6);
   const int S = g.K / TK;
   const int items = g.NS * g.tiles_n;
 
+  // The slab ring runs on across a workgroup's items: when a wave leaves an item's K loop every wave has passed that loop's last
+  // barrier, i.e. has finished reading every slab but the last one, so the four slots that do not hold the last slab are free and
+  // the NEXT item's first four slabs are issued right behind this item's output stores (gemm_f32_big.hip has the argument); its
+  // fifth slab follows behind the next loop's first barrier, which every wave reaches with its K loop behind it.
+  int slot = 0;                                            // ring slot of the current item's slab 0, then of slab s
+  gfloat* qa[NG];
+  gfloat* qb[NG];
+  auto begin_item = [&](int w) {
+    const int tn = w / g.NS, n = w - tn * g.NS;
+    init_src<false, false>(qa, g.A, g.lda, n * g.L, g.M, 0, wave, lane);
+    init_src<TB, true>(qb, g.B, g.ldb, tn * TN, g.N, 0, wave, lane);
+    int sl = slot;
+#pragma unroll
+    for (int p = 0; p < NSLOT - 1; ++p) {
+      if (p < S) {
+        stage_operand<false>(qa, g.lda, smem + sl * SLOT_BYTES, wave);
+        stage_operand<TB>(qb, g.ldb, smem + sl * SLOT_BYTES + OP_BYTES, wave);
+      }
+      sl = (sl + 1 == NSLOT) ? 0 : sl + 1;
+    }
+  };
+  if ((int)blockIdx.x < items) begin_item(blockIdx.x);
   for (int w = blockIdx.x; w < items; w += gridDim.x) {
     // column tile slowest: with a whole number of rounds a workgroup meets the same sample again for its next column tile
     const int tn = w / g.NS, n = w - tn * g.NS;
     const int m0 = n * g.L, n0 = tn * TN;
-    gfloat* qa[NG];
-    gfloat* qb[NG];
-    init_src<false, false>(qa, g.A, g.lda, m0, g.M, 0, wave, lane);
-    init_src<TB, true>(qb, g.B, g.ldb, n0, g.N, 0, wave, lane);
     f32x16 acc[3][2];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -132,79 +155,111 @@ __global__ void __launch_bounds__(NT, 2) gemm_f32_sample_kernel(const SampleArgs
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    f32x4 rag[8];                                          // ragged rows: [4-row group] x (rows in the vector), column = 64 wave + lane
+    f32x4 rag[MAXRAG];                                          // ragged rows: [4-row group] x (rows in the vector), column = 64 rg + lane
 #pragma unroll
-    for (int u = 0; u < 8; ++u) rag[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < MAXRAG; ++u) rag[u] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0): the previous item's output stores are out of the counted copy waits below
-    __builtin_amdgcn_s_barrier();                          // every wave has left the previous item's K loop: the ring is free
+    // The ragged rows 192 + 4u .. +3 of the sample x the 64 columns of group rg on v_mfma_f32_4x4x1_16B_f32: lane l = block l / 4, A
+    // value = row l % 4 (the same four rows in every block), B value = column l of the group, D = 4 rows x column l; k in the order of
+    // the 32x32x2 chain (8 ks + e, 8 ks + 4 + e).  rag_load reads the slab's operands up front.
+    f32x4 bq[4], aq[MAXRAG][4];
+    auto rag_load = [&](const char* sA, const char* sB) {
+      if (TB) {
 #pragma unroll
-    for (int p = 0; p < NSLOT - 1; ++p)
-      if (p < S) {
-        stage_operand<false>(qa, g.lda, smem + p * SLOT_BYTES, wave);
-        stage_operand<TB>(qb, g.ldb, smem + p * SLOT_BYTES + OP_BYTES, wave);
-      }
-    int slot = 0;
-    for (int s = 0; s < S; ++s) {
-      wait_copies(min(NSLOT - 2, S - 1 - s));              // my copies of slab s; later slabs stay in flight
-      __builtin_amdgcn_s_barrier();
-      const char* sA = smem + slot * SLOT_BYTES;
-      const char* sB = sA + OP_BYTES;
-      FragA fa[2];
-      FragB<TB> fb[2];
-      fa[0].load(sA, wr * 96, 0, lane);
-      fb[0].load(sB, wc * 64, 0, lane);
-      if (s + NSLOT - 1 < S) {                             // refill the slot of slab s-1 (every read of it precedes this barrier)
-        const int sl = (slot == 0) ? NSLOT - 1 : slot - 1;
-        stage_operand<false>(qa, g.lda, smem + sl * SLOT_BYTES, wave);
-        stage_operand<TB>(qb, g.ldb, smem + sl * SLOT_BYTES + OP_BYTES, wave);
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bq[c][e] = *reinterpret_cast<const float*>(sB + (4 * c + e) * 1024 + (rg * 64 + lane) * 4);
+      } else {
+        const int rl = rg * 64 + 32 * (lane & 1) + (lane >> 1);              // LDS row of column `lane` of the group (interleaved strip)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bq[c] = *reinterpret_cast<const f32x4*>(sB + rl * ROW_B + ((c ^ swz(rl)) << 4));
       }
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        if (ks == 0) {
-          fa[1].load(sA, wr * 96, 1, lane);
-          fb[1].load(sB, wc * 64, 1, lane);
+      for (int u = 0; u < MAXRAG; ++u)
+        if (u < nrag) {
+          const int ra = 192 + 4 * u + (lane & 3);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) aq[u][c] = *reinterpret_cast<const f32x4*>(sA + ra * ROW_B + ((c ^ swz(ra)) << 4));
         }
+    };
+
+    // one k-step (8 k) of the wave's 3 x 2 MFMA tiles; RAG: the ragged rows' two 4x4x1 MFMAs of (ks, e) ride behind the six 32x32x2
+    // of the same (ks, e) -- each accumulates into the SAME four registers as the one before it, and issued back to back at the
+    // end of the slab the 16-deep dependent chain left the matrix pipe idle while the SIMD's other wave sat in the barrier
+    auto mma_kstep = [&](const FragA& fa, const FragB<TB>& fb, int ks, bool rag_on) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+      for (int e = 0; e < 4; ++e) {
 #pragma unroll
-          for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ks].f[i][e], fb[ks].v(j, e), acc[i][j], 0, 0, 0);
-      }
-      // the ragged rows 192 + 4u .. +3 of the sample x the 64 columns of group `wave` on v_mfma_f32_4x4x1_16B_f32: lane l = block
-      // l / 4, A value = row l % 4 (the same four rows in every block), B value = column l of the group, D = 4 rows x column l.
-      // k in the order of the 32x32x2 chain: 8 ks + e, 8 ks + 4 + e.
-      if (wave < 4 && nrag > 0) {
-        f32x4 bq[4];                                       // B[column][k = 4 c .. 4 c + 3], c = 0..3
-        if (TB) {
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.f[i][e], fb.v(j, e), acc[i][j], 0, 0, 0);
+        if (rag_on) {
 #pragma unroll
-          for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) bq[c][e] = *reinterpret_cast<const float*>(sB + (4 * c + e) * 1024 + (wave * 64 + lane) * 4);
-        } else {
-          const int rl = wave * 64 + 32 * (lane & 1) + (lane >> 1);          // LDS row of column `lane` of the group (interleaved strip)
-#pragma unroll
-          for (int c = 0; c < 4; ++c) bq[c] = *reinterpret_cast<const f32x4*>(sB + rl * ROW_B + ((c ^ swz(rl)) << 4));
+          for (int u = 0; u < MAXRAG; ++u)
+            if (u < nrag) {
+              rag[u] = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[u][2 * ks][e], bq[2 * ks][e], rag[u], 0, 0, 0);
+              rag[u] = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[u][2 * ks + 1][e], bq[2 * ks + 1][e], rag[u], 0, 0, 0);
+            }
         }
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-          if (u < nrag) {
-            const int ra = 192 + 4 * u + (lane & 3);
-            f32x4 aq[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) aq[c] = *reinterpret_cast<const f32x4*>(sA + ra * ROW_B + ((c ^ swz(ra)) << 4));
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                rag[u] = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[2 * ks][e], bq[2 * ks][e], rag[u], 0, 0, 0);
-                rag[u] = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[2 * ks + 1][e], bq[2 * ks + 1][e], rag[u], 0, 0, 0);
-              }
-          }
       }
-      slot = (slot + 1 == NSLOT) ? 0 : slot + 1;
+    };
+    // K loop, gemm_f32_big.hip's staggered form: waves 4-7 run HALF A SLAB behind waves 0-3, so that while one half of a SIMD's two
+    // waves sits in the per-slab barrier / its first fragment reads the other is in the middle of its MFMAs.  One barrier per slab:
+    // waves 0-3 execute it at the START of slab s (behind their vmcnt for slab s), waves 4-7 in the MIDDLE of slab s-1 (behind
+    // lgkmcnt(0) for all their reads of slab s-1 and their vmcnt for slab s).  Every wave's copies of slab s are waited for in front
+    // of that barrier and every read of slab s comes after it; the slot of slab s-1 is refilled (slab s+4) behind it, after every
+    // read of slab s-1 (waves 0-3: consumed by MFMAs issued before the barrier; waves 4-7: the lgkmcnt(0)).
+    if (!late) {
+      for (int s = 0; s < S; ++s) {
+        wait_copies(min(NSLOT - 2, S - 1 - s));            // my copies of slab s; later slabs stay in flight
+        __builtin_amdgcn_s_barrier();
+        const char* sA = smem + slot * SLOT_BYTES;
+        const char* sB = sA + OP_BYTES;
+        FragA fa[2];
+        FragB<TB> fb[2];
+        fa[0].load(sA, wr * 96, 0, lane);
+        fb[0].load(sB, wc * 64, 0, lane);
+        if (s + NSLOT - 1 < S) {                           // slab s+4 into the slot of slab s-1
+          const int sl = (slot == 0) ? NSLOT - 1 : slot - 1;
+          stage_operand<false>(qa, g.lda, smem + sl * SLOT_BYTES, wave);
+          stage_operand<TB>(qb, g.ldb, smem + sl * SLOT_BYTES + OP_BYTES, wave);
+        }
+        fa[1].load(sA, wr * 96, 1, lane);
+        fb[1].load(sB, wc * 64, 1, lane);
+        if (ragged) rag_load(sA, sB);
+        mma_kstep(fa[0], fb[0], 0, ragged);
+        mma_kstep(fa[1], fb[1], 1, ragged);
+        slot = (slot + 1 == NSLOT) ? 0 : slot + 1;
+      }
+      __builtin_amdgcn_s_barrier();                        // pairs with the mid-slab barrier of waves 4-7 in their last slab
+    } else {
+      wait_copies(min(NSLOT - 1, S) - 1);                  // my copies of slab 0
+      __builtin_amdgcn_s_barrier();                        // pairs with the slab-0 barrier of waves 0-3
+      for (int s = 0; s < S; ++s) {
+        const char* sA = smem + slot * SLOT_BYTES;
+        const char* sB = sA + OP_BYTES;
+        FragA fa[2];
+        FragB<TB> fb[2];
+        fa[0].load(sA, wr * 96, 0, lane);
+        fb[0].load(sB, wc * 64, 0, lane);
+        if (s + NSLOT - 1 < S) {                           // slab s+4 into the slot of slab s-1
+          const int sl = (slot == 0) ? NSLOT - 1 : slot - 1;
+          stage_operand<false>(qa, g.lda, smem + sl * SLOT_BYTES, wave);
+          stage_operand<TB>(qb, g.ldb, smem + sl * SLOT_BYTES + OP_BYTES, wave);
+        }
+        fa[1].load(sA, wr * 96, 1, lane);
+        fb[1].load(sB, wc * 64, 1, lane);
+        if (ragged) rag_load(sA, sB);
+        mma_kstep(fa[0], fb[0], 0, ragged);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);                // lgkmcnt(0): every read of slab s by this wave has returned
+        wait_copies(min(s + NSLOT - 1, S - 1) - (s + 1));  // my copies of slab s+1; later slabs stay in flight
+        __builtin_amdgcn_s_barrier();                      // pairs with the slab-(s+1) barrier of waves 0-3 (their final one for s = S-1)
+        __builtin_amdgcn_sched_barrier(0);
+        mma_kstep(fa[1], fb[1], 1, ragged);                // (ragged operands in registers: read before the lgkmcnt(0) above)
+        slot = (slot + 1 == NSLOT) ? 0 : slot + 1;
+      }
     }
 
     // ---- epilogue: accumulator tile (i, j), register e, lane (cm, h): row wr*96 + 32 i + (e & 3) + 8 (e >> 2) + 4 h, columns
@@ -226,11 +281,11 @@ __global__ void __launch_bounds__(NT, 2) gemm_f32_sample_kernel(const SampleArgs
           *reinterpret_cast<f32x2*>(g.C + (long long)row * g.ldc + col) = f32x2{v0, v1};
         }
     }
-    if (wave < 4 && nrag > 0) {
-      const int col = n0 + wave * 64 + lane;
+    if (ragged) {
+      const int col = n0 + rg * 64 + lane;
       const float bvr = g.bias ? g.bias[col] : 0.f;
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
+      for (int u = 0; u < MAXRAG; ++u)
         if (u < nrag) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -240,6 +295,7 @@ __global__ void __launch_bounds__(NT, 2) gemm_f32_sample_kernel(const SampleArgs
           }
         }
     }
+    if (w + (int)gridDim.x < items) begin_item(w + gridDim.x);      // behind this wave's output stores (the copy waits count them in)
   }
 }
 
@@ -250,7 +306,7 @@ extern "C" {
 // 1 when vqf_gemm_f32_sample takes this shape
 int vqf_gemm_f32_sample_supported(int NS, int L, int N, int K) {
   const int sw = vqf_opt(VQF_OPT_GEMM_F32_SAMPLE, 1);      // 0 = never, 2 = wherever the kernel CAN run (tests), default: where it pays
-  if (!(NS > 0 && L >= 192 && L <= 220 && (L % 4) == 0 && N >= TN && (N % TN) == 0 && K >= 4 * TK && (K % TK) == 0 &&
+  if (!(NS > 0 && L >= 192 && L <= 192 + 4 * MAXRAG && (L % 4) == 0 && N >= TN && (N % TN) == 0 && K >= 4 * TK && (K % TK) == 0 &&
         (long long)NS * L < (1LL << 31) && sw != 0))
     return 0;
   // one workgroup per (sample, 256 columns): worth it once the items fill at least half of the CUs (a small batch has more

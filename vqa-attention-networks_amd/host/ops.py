@@ -172,6 +172,11 @@ def gemm_rows(a, b, L, tb=False, bias=None, relu=False, out=None):
     return out
 
 
+def gemm_rows_supported(NS, L, N, K):
+    """whether gemm_rows runs (NS * L, K) x (N, K) products on the per-sample-tile kernel (include/vqa_fusion.h)"""
+    return bool(_lib().vqf_gemm_f32_sample_supported(int(NS), int(L), int(N), int(K)))
+
+
 def gemm_big_rows(ta, tb, M, N, K):
     """leading rows of an fp32 (ta, tb, M, N, K) product that run on the 256x256-tile kernel (M, 0, or the whole-rounds block of
     a mid-size shape: the other M - rows rows are a second launch): include/vqa_fusion.h vqf_gemm_f32_big_rows"""
