@@ -15,8 +15,13 @@
 
 // one block per sample, one wave per position: 16 waves per block keep 2 blocks x 16 waves on a CU when N is only
 // a few hundred (256 threads: 0.26 ms on the 822 MB image pass, 3.1 TB/s)
+#ifndef VQF_GLIMPSE_FWD_ROWS
+#define VQF_GLIMPSE_FWD_ROWS 4
+#endif
+// threads per sample of the pooling backward: 256 (four waves, eight 16-byte loads in flight per lane) streams the image grid at
+// 6.3-6.5 TB/s, 512: 6.1-6.3, 1024 (round 4): 5.9-6.0 -- few resident waves stream best (tools/hbm_kernels_ab.py, gpurun_out/r05)
 #ifndef VQF_GLIMPSE_BWD_THREADS
-#define VQF_GLIMPSE_BWD_THREADS 1024
+#define VQF_GLIMPSE_BWD_THREADS 256
 #endif
 
 namespace {
@@ -230,17 +235,15 @@ __global__ void glimpse_pool_fwd_kernel(const FT* __restrict__ feat,
   for (int g = 0; g < G; ++g) a[g] = f32x4{0, 0, 0, 0};
   if (vec) {
     int s = 0;
-    for (; s + 3 < S; s += 4) {
-      const f32x4 x0 = load4<FT>(f + (long long)s * C);
-      const f32x4 x1 = load4<FT>(f + (long long)(s + 1) * C);
-      const f32x4 x2 = load4<FT>(f + (long long)(s + 2) * C);
-      const f32x4 x3 = load4<FT>(f + (long long)(s + 3) * C);
+    // VQF_GLIMPSE_FWD_ROWS rows per trip, every load issued before the first is consumed (the sums keep the row order: same bits)
+    for (; s + VQF_GLIMPSE_FWD_ROWS - 1 < S; s += VQF_GLIMPSE_FWD_ROWS) {
+      f32x4 x[VQF_GLIMPSE_FWD_ROWS];
+#pragma unroll
+      for (int u = 0; u < VQF_GLIMPSE_FWD_ROWS; ++u) x[u] = load4<FT>(f + (long long)(s + u) * C);
 #pragma unroll
       for (int g = 0; g < G; ++g) {
-        a[g] += x0 * w[g][s];
-        a[g] += x1 * w[g][s + 1];
-        a[g] += x2 * w[g][s + 2];
-        a[g] += x3 * w[g][s + 3];
+#pragma unroll
+        for (int u = 0; u < VQF_GLIMPSE_FWD_ROWS; ++u) a[g] += x[u] * w[g][s + u];
       }
     }
     for (; s < S; ++s) {
