@@ -527,39 +527,36 @@ def secondary_config(vqa_amd, which, dev, steps, warmup):
     return out
 
 
-def dp_one_rank(vqa_amd, parallel, dev, steps, warmup, plain_ms=None, pg_timeout=None):
+def dp_one_rank_child(steps, warmup, pg_timeout=None, timeout_s=600.0):
     """The headline step with the whole data-parallel machinery of host/parallel.py in a ONE-rank RCCL group (solver.py:34-36's
     nn.DataParallel replaced): gradient hooks, bucket copies, asynchronous ncclAllReduce(AVG) on RCCL's high-priority stream,
     large-tile GEMMs launched one workgroup per tile instead of persistent.  What a rank pays for data parallelism before any
-    byte crosses xGMI, timed by the driver's own run: the expected N-GPU step is this `ms_per_step` plus the exposed tail of
-    the real all-reduce."""
-    import socket
-    ops = vqa_amd.ops
-    if not dist.is_initialized():
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
-        os.environ["MASTER_ADDR"] = "127.0.0.1"
-        parallel.init_distributed("nccl", force=True, timeout_s=pg_timeout)
-    wl = Workload(vqa_amd, "mfb", "f32", 512, 0, dev)
-    wl.reducer = parallel.GradientAllReducer(wl.model, single_rank=True)
-
-    def fence():
-        dist.barrier()
-        torch.cuda.synchronize()
-    elapsed, loss = timed_steps(wl, ops, warmup, steps, fence)
-    ms = 1e3 * elapsed / steps
-    exposed = exposed_allreduce_steps(wl, CENSUS_STEPS, fence)
-    out = {"what": "MFB-baseline headline step (B=512, fp32, faithful) under GradientAllReducer in a one-rank RCCL group: hooks, "
-                   "bucket copies, %d collectives per step, per-tile GEMM launches" % len(wl.reducer.buckets),
-           "ms_per_step": round(ms, 3), "value": round(512 * steps / elapsed, 2), "unit": "QA-pairs/s", "steps": steps,
-           "warmup": warmup, "plain_ms_per_step": plain_ms,
-           "overhead_frac": round(ms / plain_ms - 1.0, 4) if plain_ms else None,
-           "gemm_workgroups": wl.reducer.gemm_workgroups()["f32"], "backend": dist.get_backend(),
-           "allreduce_bucket_bytes": wl.reducer.bucket_bytes_list(), "allreduce_exposed_ms": exposed,
-           "loss": round(float(loss.item()), 5)}
-    wl.free()
-    return out
+    byte crosses xGMI, timed in the driver's own run: the expected N-GPU step is this `ms_per_step` plus the exposed tail of the
+    real all-reduce.
+    Runs `bench.py --one-rank-group` as a CHILD process, started and awaited BEFORE this process has touched the GPU (fresh
+    process: round 5 first timed it in-process behind the three secondary configurations and read 46.5 ms where the stand-alone
+    run of the same build gives 40.8 -- gpurun_out/r05/b_one_rank.json; the child's number is the stand-alone one)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--one-rank-group", "--no-cpu-baseline", "--no-secondary", "--steps", str(steps),
+           "--warmup", str(warmup)]
+    if pg_timeout:
+        cmd += ["--pg-timeout", str(pg_timeout)]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    try:
+        p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return {"error": "the one-rank child did not finish within %.0f s" % timeout_s}
+    lines = [l for l in p.stdout.splitlines() if l.lstrip().startswith("{")]
+    if p.returncode != 0 or len(lines) != 1:
+        return {"error": "one-rank child rc %d: %s" % (p.returncode, (p.stderr or "")[-300:])}
+    d = json.loads(lines[0])
+    c = d["config"]
+    return {"what": "MFB-baseline headline step (B=512, fp32, faithful) under GradientAllReducer in a one-rank RCCL group (hooks, bucket "
+                    "copies, %d collectives per step, per-tile GEMM launches), a fresh child process run before the headline" % len(c["allreduce_bucket_bytes"]),
+            "ms_per_step": d["ms_per_step"], "value": d["value"], "unit": d["unit"], "steps": d["steps"], "warmup": d["warmup"],
+            "gemm_workgroups": c["gemm_workgroups_by_family"]["f32"], "backend": c["backend"],
+            "allreduce_bucket_bytes": c["allreduce_bucket_bytes"], "allreduce_exposed_ms": c["allreduce_exposed_ms"],
+            "roofline_frac": (d.get("roofline") or {}).get("frac"), "loss": d["loss"]}
 
 
 def _short(x, n=160):
@@ -872,6 +869,12 @@ def main():
         sys.exit(spawn_ranks(args.gpus, args.launch_timeout))       # before anything here has initialised the GPU
 
     multi = int(os.environ.get("WORLD_SIZE", "1")) > 1
+    dp_one = None
+    if (not multi and args.gpus == 1 and args.model == "mfb" and args.dtype == "f32" and args.batch == 512 and not args.pruned
+            and not args.forward_only and not args.miopen_lstm and not args.no_secondary and not args.one_rank_group
+            and not args.no_dp_one_rank):
+        # the one-rank data-parallel rehearsal of a default run: a fresh child, finished before this process touches the GPU
+        dp_one = dp_one_rank_child(args.secondary_steps, args.secondary_warmup, args.pg_timeout)
     if multi:
         # In-rank watchdog for launches this file does not supervise (the driver's torchrun line): a C-level timer thread that
         # needs no GIL -- it fires inside a blocked rendezvous or RCCL bootstrap too --, dumps every thread's stack to the rank's
@@ -1064,12 +1067,11 @@ def main():
                 out["secondary"][which] = secondary_config(vqa_amd, which, dev, args.secondary_steps, args.secondary_warmup)
             except Exception as e:          # the headline line must survive a secondary failure; say what happened
                 out["secondary"][which] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
-        if not args.no_dp_one_rank:
-            try:
-                out["secondary"]["dp_one_rank"] = dp_one_rank(vqa_amd, parallel, dev, args.secondary_steps, args.secondary_warmup,
-                                                              plain_ms=round(ms_per_step, 3), pg_timeout=args.pg_timeout)
-            except Exception as e:
-                out["secondary"]["dp_one_rank"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        if dp_one is not None:
+            if "error" not in dp_one:
+                dp_one["plain_ms_per_step"] = round(ms_per_step, 3)
+                dp_one["overhead_frac"] = round(dp_one["ms_per_step"] / ms_per_step - 1.0, 4)
+            out["secondary"]["dp_one_rank"] = dp_one
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and not args.one_rank_group:
             out["cpu_baseline"] = cpu_baseline(batch=args.cpu_batch)

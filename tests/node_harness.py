@@ -270,6 +270,29 @@ def _check_linear(rec, out, grads, rep):
     rep.append("LinearFn%s %s: %.1e (err/bound %.2f)" % ("[bf16]" if use_bf16 else "", tuple(w2.shape), worst, ratio))
 
 
+def _check_linear2(rec, out, grads, rep):
+    """Linear2Fn: y = [x1 | x2] W^T + b without the concatenated tensor (mhb_coAtt.py:147-148,213-214)"""
+    x1, x2, w, b = rec["args"][:4]
+    w2 = w.reshape(w.shape[0], -1)
+    M, K1 = x1.shape
+    K = K1 + x2.shape[1]
+    dy = rec["dout"].double()
+    xc = torch.cat((x1.detach(), x2.detach()), 1).double()
+    y64 = xc @ w2.detach().double().t() + (b.detach().double() if b is not None else 0.0)
+    worst = _nrel(out, y64)
+    assert worst <= gemm_tol(K), ("Linear2Fn y", worst)
+    dx = dy @ w2.detach().double()
+    refs = {0: (dx[:, :K1], gemm_tol(w2.shape[0])), 1: (dx[:, K1:], gemm_tol(w2.shape[0])), 2: ((dy.t() @ xc).view_as(w), gemm_tol(M)),
+            3: (dy.sum(0), gemm_tol(M))}
+    ratio = worst / gemm_tol(K)
+    for i, (ref, tol) in refs.items():
+        if i in grads and grads[i] is not None:
+            e = _nrel(grads[i], ref)
+            assert e <= tol, ("Linear2Fn grad of arg %d" % i, e, tol)
+            worst, ratio = max(worst, e), max(ratio, e / tol)
+    rep.append("Linear2Fn %s: %.1e (err/bound %.2f)" % (tuple(w2.shape), worst, ratio))
+
+
 def _check_logsoftmax(rec, out, grads, rep):
     x = rec["args"][0].detach().double().requires_grad_(True)
     y = torch.log_softmax(x, dim=1)
@@ -617,6 +640,8 @@ def check_every_node(model, recd, label, min_links=3, skip_params=("word_embeddi
                 into.setdefault(id(base), []).append(_to_base(g, a, base))
         if name == "LinearFn":
             _check_linear(rec, out2, grads, rep)
+        elif name == "Linear2Fn":
+            _check_linear2(rec, out2, grads, rep)
         elif name == "LogSoftmaxRowsFn":
             _check_logsoftmax(rec, out2, grads, rep)
         elif name == "AttHeadFn":
@@ -667,5 +692,5 @@ def check_every_node(model, recd, label, min_links=3, skip_params=("word_embeddi
     return line, seen_params
 
 
-ALL_NODES = ["EmbedTanhFn", "LstmSeqFn", "LstmBatchFn", "DropoutBTFn", "AttHeadFn", "LinearFn", "ImgFuseFn", "ImgProjFn",
+ALL_NODES = ["EmbedTanhFn", "LstmSeqFn", "LstmBatchFn", "DropoutBTFn", "AttHeadFn", "LinearFn", "Linear2Fn", "ImgFuseFn", "ImgProjFn",
              "ImgProjLateFn", "ImgProjDeferFn", "MfbFuseFn", "FinalMfbFn", "LogSoftmaxRowsFn", "HieCoreFn"]

@@ -57,14 +57,14 @@ def test_config3_every_node_of_the_bf16_step_at_batch_512(bf16_mode, monkeypatch
     img_b = vqa_amd.ops.cast_bf16(img.view(-1, 2048)).view(img.shape)            # config 3: bf16 feature storage
     del img
 
-    recd = _Recorder(monkeypatch, fns, ["LstmSeqFn", "AttHeadFn", "LinearFn", "ImgFuseFn", "FinalMfbFn", "LogSoftmaxRowsFn",
+    recd = _Recorder(monkeypatch, fns, ["LstmSeqFn", "AttHeadFn", "LinearFn", "Linear2Fn", "ImgFuseFn", "FinalMfbFn", "LogSoftmaxRowsFn",
                                         "ImgProjLateFn", "MfbFuseFn"])
     out = model.forward(img_b, q)
     vqa_amd.KLDivLoss()(out, soft).backward()
     torch.cuda.synchronize()
     kinds = [r["cls"].__name__ for r in recd.records]
     fuse = ["ImgProjLateFn", "MfbFuseFn"] if side else ["ImgFuseFn"]
-    assert kinds == ["LstmSeqFn", "AttHeadFn", "LinearFn"] + fuse + ["AttHeadFn", "FinalMfbFn", "FinalMfbFn", "LinearFn",
+    assert kinds == ["LstmSeqFn", "AttHeadFn", "LinearFn"] + fuse + ["AttHeadFn", "FinalMfbFn", "FinalMfbFn", "Linear2Fn",
                                                                     "LogSoftmaxRowsFn"], kinds
     assert all(r["dout"] is not None for r in recd.records)
     check_every_node(model, recd, "config 3 %s node checks at B=512" % bf16_mode)
@@ -96,13 +96,13 @@ def test_models_in_bf16_modes_every_node_at_full_dims(mhb, bf16_mode, monkeypatc
         model.unit_softmax = False          # live attention so that every tensor carries a gradient
     model.gemm_dtype = bf16_mode
     img_b = vqa_amd.ops.cast_bf16(img.view(-1, img.shape[-1])).view(img.shape)      # bf16 feature storage, as config 3
-    recd = _Recorder(monkeypatch, vqa_amd.functions, ["LstmSeqFn", "LstmBatchFn", "AttHeadFn", "LinearFn", "ImgFuseFn",
+    recd = _Recorder(monkeypatch, vqa_amd.functions, ["LstmSeqFn", "LstmBatchFn", "AttHeadFn", "LinearFn", "Linear2Fn", "ImgFuseFn",
                                                       "FinalMfbFn", "LogSoftmaxRowsFn", "ImgProjLateFn", "MfbFuseFn"])
     out = model.forward(img_b, q)
     (vqa_amd.KLDivLoss()(out, soft) if mhb else vqa_amd.CrossEntropyLoss()(out, hard)).backward()
     torch.cuda.synchronize()
     kinds = [r["cls"].__name__ for r in recd.records]
-    want = (["LstmSeqFn", "AttHeadFn", "LinearFn", "ImgFuseFn", "AttHeadFn", "FinalMfbFn", "FinalMfbFn", "LinearFn", "LogSoftmaxRowsFn"]
+    want = (["LstmSeqFn", "AttHeadFn", "LinearFn", "ImgFuseFn", "AttHeadFn", "FinalMfbFn", "FinalMfbFn", "Linear2Fn", "LogSoftmaxRowsFn"]
             if mhb else ["LstmBatchFn", "AttHeadFn", "LinearFn", "ImgFuseFn", "AttHeadFn", "FinalMfbFn", "LinearFn"])
     assert kinds == want, kinds
     assert all(r["dout"] is not None for r in recd.records)

@@ -5,8 +5,8 @@ Mirrors the reference interface (mfb.py:6-140): `MFB(cfg)`,
 identical state_dict keys/shapes, so it drops into solver.py / train_models.py.
 The question encoder's embedding lookup + tanh (mfb.py:68, csrc/embed.hip), its LSTM
 recursion and everything from the question attention to the logits run in
-libvqa_fusion.so (`use_hip_lstm = False` puts the LSTM back on nn.LSTM / MIOpen);
-dropout_l (mfb.py:70) is torch's nn.Dropout.
+libvqa_fusion.so (`use_hip_lstm = False` puts the LSTM back on nn.LSTM / MIOpen), dropout_l
+(mfb.py:70) included (`vqf_dropout_bt`: the nn.Dropout module only carries the rate).
 """
 import torch
 import torch.nn as nn
