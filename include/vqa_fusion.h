@@ -489,6 +489,12 @@ int vqf_embed_tanh_bwd(const float* dout, const float* out, const long long* ids
 /* the plain lookup e = Embedding(q) and its weight gradient (hieCoAtten.py:27, networks.py:23,56, mhb_coAtt.py:181) */
 int vqf_embed_fwd(const float* W, const long long* ids, int T, int V, int E, float* out, void* stream);
 int vqf_embed_bwd(const float* dout, const long long* ids, int T, int V, int E, float* dW, void* stream);
+/* out = dropout(W[ids]) (hieCoAtten.py:27-28: the lookup and its always-on functional dropout) and its weight gradient, one launch each
+ * way; the mask is the one vqf_dropout_f32 draws over the flat (T, E) tensor (keep: (T, E) uint8 or NULL + seed / p_drop).  E % 4 == 0. */
+int vqf_embed_dropout_fwd(const float* W, const long long* ids, int T, int V, int E, const uint8_t* keep, uint64_t seed, float p_drop,
+                          float* out, void* stream);
+int vqf_embed_dropout_bwd(const float* dout, const long long* ids, int T, int V, int E, const uint8_t* keep, uint64_t seed, float p_drop,
+                          float* dW, void* stream);
 /* time-major forms: ids (N, Tq) as the reference holds them (mfb.py:68), out / dout rows ordered (Tq, N) -- the layout the
  * batch-major LSTM consumes (mfb.py:69 with batch_first=True == T steps of the N-row batch): no transposing copy in between */
 int vqf_embed_tanh_fwd_tm(const float* W, const long long* ids, int N, int Tq, int V, int E, float* out, void* stream);

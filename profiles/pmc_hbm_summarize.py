@@ -38,7 +38,10 @@ BENCH_NAME = {"hie_stream_kernel<0>": "hie_hv_fwd", "hie_stream_kernel<1>": "hie
 def short(name):
     name = re.sub(r"\(anonymous namespace\)::", "", name)
     name = re.sub(r"^void ", "", name)
-    m = re.match(r"(hie_stream_kernel<\d>)", name) or re.match(r"([A-Za-z0-9_]+)", name)
+    m = re.match(r"hie_stream_kernel<(\d)", name)           # hie_stream_kernel<MODE[, TMAX]>
+    if m:
+        return "hie_stream_kernel<%s>" % m.group(1)
+    m = re.match(r"([A-Za-z0-9_]+)", name)
     return m.group(1) if m else name
 
 

@@ -465,11 +465,25 @@ int glimpse_bwd_launch(const float* dpooled, const float* dwts_extra, const FT* 
   if (!dpooled || !feat || !wts || !dlogits || N <= 0 || S <= 0 || C <= 0) return VQF_E_BADARG;
   if (S > MAXS || (G != 1 && G != 2)) return VQF_E_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
+  // one workgroup per sample.  A wave keeps ceil(C / 256) 16-byte loads per lane in flight (a row of the grid); about 64 such
+  // loads per lane and CU stream best: 8 waves per CU at C = 2048 (the headline: 256 threads per sample, two samples per CU; few
+  // resident waves, see VQF_GLIMPSE_BWD_THREADS), 32 at C = 512 (HieCoAtten, one sample per CU: 1024 threads -- 256 left a CU four
+  // waves with two loads each, 30 -> 64 us)
+  int waves = VQF_GLIMPSE_BWD_THREADS / 64;
+  {
+    const int cus = vqf_cu_count() > 0 ? vqf_cu_count() : 256;
+    const int per_row = (C + 255) / 256 > 8 ? 8 : (C + 255) / 256;
+    int target = 64 / per_row;
+    target = target < 8 ? 8 : (target > 32 ? 32 : target);
+    const int want = (target * cus + N - 1) / N;
+    if (want > waves) waves = want > 16 ? 16 : want;
+  }
+  const dim3 block(64 * waves);
   if (G == 2)
-    VQF_LAUNCH(KID_GLIMPSE_BWD, (glimpse_pool_bwd_kernel<2, FT>), dim3(N), dim3(VQF_GLIMPSE_BWD_THREADS), 0, s, dpooled,
+    VQF_LAUNCH(KID_GLIMPSE_BWD, (glimpse_pool_bwd_kernel<2, FT>), dim3(N), block, 0, s, dpooled,
                dwts_extra, feat, wts, N, S, C, unit_softmax, dlogits, dfeat);
   else
-    VQF_LAUNCH(KID_GLIMPSE_BWD, (glimpse_pool_bwd_kernel<1, FT>), dim3(N), dim3(VQF_GLIMPSE_BWD_THREADS), 0, s, dpooled,
+    VQF_LAUNCH(KID_GLIMPSE_BWD, (glimpse_pool_bwd_kernel<1, FT>), dim3(N), block, 0, s, dpooled,
                dwts_extra, feat, wts, N, S, C, unit_softmax, dlogits, dfeat);
   return vqf_last_error();
 }

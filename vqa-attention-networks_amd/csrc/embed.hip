@@ -22,9 +22,21 @@ __device__ __forceinline__ int tok_of_row(int t, int T, int swapN) {
   return swapN > 0 ? (t % swapN) * (T / swapN) + t / swapN : t;
 }
 
-template <bool TANH>
+// keep scale of element e of the flat (T, E) tensor: the draw of the element-wise dropout kernels (elementwise.hip keep4: one Philox
+// call per 4 consecutive elements, or an explicit uint8 keep-mask)
+__device__ __forceinline__ float keep_scale(const uint8_t* __restrict__ keep, uint64_t seed, uint32_t thr, float inv_keep, long long e) {
+  if (keep) return keep[e] ? inv_keep : 0.f;
+  if (thr == 0u) return 1.0f;
+  const uint4 r = philox4x32_10((uint64_t)(e >> 2), seed);
+  const uint32_t w = (e & 3) == 0 ? r.x : (e & 3) == 1 ? r.y : (e & 3) == 2 ? r.z : r.w;
+  return w >= thr ? inv_keep : 0.f;
+}
+
+// DROP: out = dropout(W[ids]) (hieCoAtten.py:27-28: the lookup and its always-on functional dropout in one pass)
+template <bool TANH, bool DROP = false>
 __global__ void embed_fwd_kernel(const float* __restrict__ W, const long long* __restrict__ ids, int T, int V, int E,
-                                      float* __restrict__ out, int swapN) {
+                                      float* __restrict__ out, int swapN, const uint8_t* __restrict__ keep = nullptr, uint64_t seed = 0,
+                                      uint32_t thr = 0u, float inv_keep = 1.0f) {
   const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (t >= T) return;
   const int lane = threadIdx.x & 63;
@@ -37,10 +49,18 @@ __global__ void embed_fwd_kernel(const float* __restrict__ W, const long long* _
       f32x4 x = ok ? *reinterpret_cast<const f32x4*>(w + c) : f32x4{0.f, 0.f, 0.f, 0.f};
       f32x4 y = x;
       if (TANH) y = f32x4{tanhf(x[0]), tanhf(x[1]), tanhf(x[2]), tanhf(x[3])};
+      if (DROP) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[j] *= keep_scale(keep, seed, thr, inv_keep, (long long)t * E + c + j);
+      }
       *reinterpret_cast<f32x4*>(o + c) = y;
     }
   } else {
-    for (int c = lane; c < E; c += 64) o[c] = ok ? (TANH ? tanhf(w[c]) : w[c]) : 0.f;
+    for (int c = lane; c < E; c += 64) {
+      float y = ok ? (TANH ? tanhf(w[c]) : w[c]) : 0.f;
+      if (DROP) y *= keep_scale(keep, seed, thr, inv_keep, (long long)t * E + c);
+      o[c] = y;
+    }
   }
 }
 
@@ -51,10 +71,11 @@ constexpr int EB_ROWS = 16;        // vocabulary rows per workgroup, at most
 // a dataset vocabulary of ~20 k words: 10 rows per workgroup, 2000 workgroups): the token ids of a round are loaded ONCE per
 // workgroup and compared against each of its rows from registers, so the work is O(V / RV * T) id loads + O(V * T / 64) compares,
 // not O(V * T) loads (at V = 20 k the one-row form re-read the whole id list 20 000 times).
-template <bool TANH>
+template <bool TANH, bool DROP = false>
 __global__ void __launch_bounds__(256) embed_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
                                                             const long long* __restrict__ ids, int T, int V, int E, int RV,
-                                                            float* __restrict__ dW, int swapN) {
+                                                            float* __restrict__ dW, int swapN, const uint8_t* __restrict__ keep = nullptr,
+                                                            uint64_t seed = 0, uint32_t thr = 0u, float inv_keep = 1.0f) {
   __shared__ int list[4][EB_CHUNK / 4];
   __shared__ int count[4];
   const int v0 = blockIdx.x * RV, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -99,6 +120,8 @@ __global__ void __launch_bounds__(256) embed_bwd_kernel(const float* __restrict_
               if (TANH) {
                 const float y = out[row + c];
                 acc[r][k] += dout[row + c] * (1.0f - y * y);
+              } else if (DROP) {
+                acc[r][k] += dout[row + c] * keep_scale(keep, seed, thr, inv_keep, row + c);
               } else {
                 acc[r][k] += dout[row + c];
               }
@@ -162,6 +185,34 @@ int vqf_embed_bwd(const float* dout, const long long* ids, int T, int V, int E, 
   const int rv = embed_rows_per_wg(V);
   VQF_LAUNCH(KID_EMBED_BWD, embed_bwd_kernel<false>, dim3((V + rv - 1) / rv), dim3(256), 0, (hipStream_t)stream, dout, none, ids, T, V,
              E, rv, dW, 0);
+  return vqf_last_error();
+}
+
+// out = dropout(W[ids]) and its weight gradient dW[v] = sum_{t: ids[t] == v} dout[t] * keep / (1 - p): hieCoAtten.py:27-28 in one pass
+// each way.  The mask is the one vqf_dropout_f32 draws over the flat (T, E) tensor (same seed -> same bits as lookup + dropout).
+int vqf_embed_dropout_fwd(const float* W, const long long* ids, int T, int V, int E, const uint8_t* keep, uint64_t seed, float p_drop,
+                          float* out, void* stream) {
+  if (!W || !ids || !out || T <= 0 || V <= 0 || E <= 0 || p_drop < 0.f || p_drop >= 1.f) return VQF_E_BADARG;
+  if (E % 4) return VQF_E_UNSUPPORTED;
+  const uint32_t thr = (keep || p_drop == 0.f) ? 0u : drop_threshold_host(p_drop);
+  const float inv_keep = (keep || p_drop > 0.f) ? 1.0f / (1.0f - p_drop) : 1.0f;
+  vqf_prof_dims(T, V, E);
+  VQF_LAUNCH(KID_EMBED_FWD, (embed_fwd_kernel<false, true>), dim3((T + 3) / 4), dim3(256), 0, (hipStream_t)stream, W, ids, T, V, E, out, 0,
+             keep, seed, thr, inv_keep);
+  return vqf_last_error();
+}
+
+int vqf_embed_dropout_bwd(const float* dout, const long long* ids, int T, int V, int E, const uint8_t* keep, uint64_t seed, float p_drop,
+                          float* dW, void* stream) {
+  if (!dout || !ids || !dW || T <= 0 || V <= 0 || E <= 0 || p_drop < 0.f || p_drop >= 1.f) return VQF_E_BADARG;
+  if (E > 1024 || (E % 4)) return VQF_E_UNSUPPORTED;
+  const uint32_t thr = (keep || p_drop == 0.f) ? 0u : drop_threshold_host(p_drop);
+  const float inv_keep = (keep || p_drop > 0.f) ? 1.0f / (1.0f - p_drop) : 1.0f;
+  vqf_prof_dims(T, V, E);
+  const float* none = nullptr;
+  const int rv = embed_rows_per_wg(V);
+  VQF_LAUNCH(KID_EMBED_BWD, (embed_bwd_kernel<false, true>), dim3((V + rv - 1) / rv), dim3(256), 0, (hipStream_t)stream, dout, none, ids, T,
+             V, E, rv, dW, 0, keep, seed, thr, inv_keep);
   return vqf_last_error();
 }
 

@@ -74,7 +74,7 @@ __global__ void __launch_bounds__(HT) hie_stream_kernel(const HieArgs g) {
   const int tid = threadIdx.x, c4 = tid % CT, rs = tid / CT;
   float* Vs = smem;                                          // [T][E]        (RANK)
   float* Us = Vs + (RANK ? T * E : 0);                       // [T][Lc]
-  float* red = Us + T * g.Lc;                                // [RS][E]       (ACC)
+  float* red = smem;                                         // [TG][RS][E]: re-uses the operand images behind the main loop
   if (rows <= 0) return;
   if (RANK)
     for (int i = tid; i < T * CT; i += HT) {
@@ -99,23 +99,40 @@ __global__ void __launch_bounds__(HT) hie_stream_kernel(const HieArgs g) {
   // FMAs and one 16-byte LDS read per element and t are a tenth of the pass): with two rows per trip a CU's 16 waves kept 32 KB
   // in flight, 2.3-2.7 TB/s over the (N*L, E) tensors (profiles/r04_pmc_hie.txt); four rows double that.
   constexpr int NR = 2;        // (four rows per trip: 133-154 VGPRs, fewer waves, measured slower: gpurun_out/r05/b_c4_a.json)
+  // The next trip's rows are requested BEFORE this trip's arithmetic (round 5): a wave's trips were a chain of load latency +
+  // compute (13 of them per sample at 2-3 us each); with the prefetch the latency of trip i+1 hides behind the compute of trip i.
+  long long mn[NR];
+  f32x4 xn[NR];
+  float dn[NR];
+  auto fetch = [&](int r) {
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+      const bool h = r + q * RS < rows;
+      mn[q] = (long long)n * L + l0 + (h ? r + q * RS : min(r, rows - 1));
+      xn[q] = MODE != MODE_LEFT ? vqf_ld_stream(reinterpret_cast<const f32x4*>(g.a + mn[q] * g.lda + 4 * c4))
+                                : vqf_ld_stream(reinterpret_cast<const f32x4*>(g.z + mn[q] * g.ldz + 4 * c4));
+      if (MODE == MODE_HEAD) dn[q] = g.dl[mn[q]];
+    }
+  };
+  if (rs < rows) fetch(rs);
   for (int r = rs; r < rows; r += NR * RS) {
     long long m[NR];
     bool has[NR];
     f32x4 x[NR], o[NR];
+    float dd[NR];
 #pragma unroll
     for (int q = 0; q < NR; ++q) {
       has[q] = r + q * RS < rows;
-      m[q] = (long long)n * L + l0 + (has[q] ? r + q * RS : r);
+      m[q] = mn[q];
+      x[q] = xn[q];
+      dd[q] = dn[q];
     }
-#pragma unroll
-    for (int q = 0; q < NR; ++q)
-      x[q] = MODE != MODE_LEFT ? vqf_ld_stream(reinterpret_cast<const f32x4*>(g.a + m[q] * g.lda + 4 * c4)) : vqf_ld_stream(reinterpret_cast<const f32x4*>(g.z + m[q] * g.ldz + 4 * c4));
+    if (r + NR * RS < rows) fetch(r + NR * RS);
     if (MODE == MODE_HEAD) {
       const float keep_q = 1.0f / g.inv_keep;
 #pragma unroll
       for (int q = 0; q < NR; ++q) {
-        const float d = g.dl[m[q]];
+        const float d = dd[q];
         f32x4 sc;
         keep4v(g.keep, g.seed, g.thr, g.inv_keep, m[q] * CT + c4, sc);
 #pragma unroll
@@ -164,23 +181,32 @@ __global__ void __launch_bounds__(HT) hie_stream_kernel(const HieArgs g) {
       if (has[q]) *reinterpret_cast<f32x4*>(g.out + m[q] * g.ldo + 4 * c4) = o[q];
   }
 
+  // `red` re-uses the LDS of the (T, E) / (T, Lc) operand images: nobody reads them any more behind this barrier
+  __syncthreads();
   if (ACC) {
-    // fold the RS row slots of the workgroup (fixed order), one t at a time through 4 KB of LDS
+    // fold the RS row slots of the workgroup (fixed slot order), TG values of t per round through TG x RS x E floats of LDS:
+    // four rounds of two barriers for T = 14 (round 4 folded one t at a time: 28 barriers across 16 waves)
+    constexpr int TG = 4;
     float* dst = g.part + (((long long)s * g.N + n) * T) * g.ldp;
     const float* add = g.padd ? g.padd + (long long)n * T * g.ldpa : nullptr;
-    for (int t = 0; t < T; ++t) {
-      f32x4 v = tacc[0];
 #pragma unroll
-      for (int q = 1; q < TMAX; ++q)
-        if (q == t) v = tacc[q];
-      __syncthreads();
-      *reinterpret_cast<f32x4*>(red + rs * E + 4 * c4) = v;
-      __syncthreads();
-      if (rs == 0) {
-        f32x4 sum = *reinterpret_cast<const f32x4*>(red + 4 * c4);
-        for (int q = 1; q < RS; ++q) sum += *reinterpret_cast<const f32x4*>(red + q * E + 4 * c4);
-        if (add) sum = *reinterpret_cast<const f32x4*>(add + (long long)t * g.ldpa + 4 * c4) + sum;
-        *reinterpret_cast<f32x4*>(dst + (long long)t * g.ldp + 4 * c4) = sum;
+    for (int rd = 0; rd < (TMAX + TG - 1) / TG; ++rd) {
+      if (rd * TG < T) {                                       // (uniform over the workgroup)
+        if (rd) __syncthreads();
+#pragma unroll
+        for (int tg = 0; tg < TG; ++tg)
+          if (rd * TG + tg < TMAX)
+            *reinterpret_cast<f32x4*>(red + ((tg * RS + rs) * E) + 4 * c4) = tacc[rd * TG + tg < TMAX ? rd * TG + tg : 0];
+        __syncthreads();
+        for (int tg = rs; tg < TG; tg += RS) {                 // row slot tg adds the RS slots of t = rd * TG + tg
+          const int t = rd * TG + tg;
+          if (t < T) {
+            f32x4 sum = *reinterpret_cast<const f32x4*>(red + (tg * RS) * E + 4 * c4);
+            for (int q = 1; q < RS; ++q) sum += *reinterpret_cast<const f32x4*>(red + (tg * RS + q) * E + 4 * c4);
+            if (add) sum = *reinterpret_cast<const f32x4*>(add + (long long)t * g.ldpa + 4 * c4) + sum;
+            *reinterpret_cast<f32x4*>(dst + (long long)t * g.ldp + 4 * c4) = sum;
+          }
+        }
       }
     }
   }
@@ -241,7 +267,9 @@ int chunks_for(int N, int L) {
 
 size_t lds_bytes(int mode, int E, int T, int Lc) {
   const int RS = threads_for(E, Lc) / (E / 4);
-  return sizeof(float) * ((size_t)(mode != MODE_HEAD ? T * E : 0) + (size_t)T * Lc + (size_t)RS * E + 16);
+  const size_t ops_f = (size_t)(mode != MODE_HEAD ? T * E : 0) + (size_t)T * Lc;     // operand images of the main loop ...
+  const size_t red_f = (size_t)4 * RS * E;                                           // ... re-used by the fold (TG = 4 values of t per round)
+  return sizeof(float) * (ops_f > red_f ? ops_f : red_f);
 }
 
 int launch(int mode, HieArgs& g, const uint8_t* keep, uint64_t seed, float p, hipStream_t s) {

@@ -722,8 +722,11 @@ class HieCoreFn(torch.autograd.Function):
         img = ops.gemm_rows(imgf.view(M, D), _c(w_emb), L, bias=b_emb, relu=True)
         ops.dropout(img, *drops["img"], out=img)
         # :27-28  que = dropout(que_emb(que_features))
-        que = ops.embed_tanh_fwd(_c(w_que), ids, False).view(MT, E)
-        ops.dropout(que, *drops["que"], out=que)
+        if E % 4 == 0 and E <= 1024:
+            que = ops.embed_dropout_fwd(_c(w_que), ids, *drops["que"])           # lookup + dropout in one launch
+        else:
+            que = ops.embed_tanh_fwd(_c(w_que), ids, False).view(MT, E)
+            ops.dropout(que, *drops["que"], out=que)
         # :30-31,35-36  the four E x E layers as two products with concatenated weights
         Wi, bi, Wq2, bq2 = new(2 * E, E), new(2 * E), new(2 * E, E), new(2 * E)
         ops.multi_copy([(_c(wbv), Wi[:E]), (_c(wv), Wi[E:]), (bbv, bi[:E]), (bv, bi[E:]),
@@ -835,8 +838,11 @@ class HieCoreFn(torch.autograd.Function):
         dpre, db_emb = ops.relu_bwd_rank1(dimg, img, av.view(M), dv, L, scale, want_bias=True, out=dimg)
         dw_emb = ops.gemm(dpre, imgf.view(M, D), ta=True, tb=True)
         dque2 = dque.view(MT, E)
-        ops.dropout(dque2, *drops["que"], out=dque2)
-        dw_que = ops.embed_tanh_bwd(dque2, None, ids, ctx.V)
+        if E % 4 == 0 and E <= 1024:
+            dw_que = ops.embed_dropout_bwd(dque2, ids, ctx.V, *drops["que"])     # dropout's backward inside the segment sums
+        else:
+            ops.dropout(dque2, *drops["que"], out=dque2)
+            dw_que = ops.embed_tanh_bwd(dque2, None, ids, ctx.V)
         return (None, None, dw_emb, db_emb, dw_que, dwbv, dbbv, dWi[E:], dbi[E:], dWq2[E:], dbq2[E:],
                 dwhv.view_as(whv), dbhv, dwhq.view_as(whq), dbhq, None)
 

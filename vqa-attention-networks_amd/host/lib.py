@@ -112,6 +112,8 @@ SIGNATURES = {
     "vqf_embed_tanh_bwd": (c_i, [c_f, c_f, c_p, c_i, c_i, c_i, c_f, c_p]),
     "vqf_embed_fwd": (c_i, [c_f, c_p, c_i, c_i, c_i, c_f, c_p]),
     "vqf_embed_bwd": (c_i, [c_f, c_p, c_i, c_i, c_i, c_f, c_p]),
+    "vqf_embed_dropout_fwd": (c_i, [c_f, c_p, c_i, c_i, c_i, c_p, c_u64, ctypes.c_float, c_f, c_p]),
+    "vqf_embed_dropout_bwd": (c_i, [c_f, c_p, c_i, c_i, c_i, c_p, c_u64, ctypes.c_float, c_f, c_p]),
     "vqf_embed_tanh_fwd_tm": (c_i, [c_f, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),
     "vqf_embed_tanh_bwd_tm": (c_i, [c_f, c_f, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),
     "vqf_feat_transpose": (c_i, [c_f, c_i, c_i, c_i, c_i, c_p, c_p]),

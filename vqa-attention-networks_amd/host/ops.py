@@ -823,6 +823,28 @@ def embed_tanh_fwd(weight, ids, tanh=True, time_major=False):
     return out
 
 
+def embed_dropout_fwd(weight, ids, keep=None, seed=0, p_drop=0.5):
+    """dropout(weight[ids]) in one launch: -> (ids.numel(), E); the mask of ops.dropout over that flat tensor"""
+    _chk(weight)
+    _chk_ids(ids)
+    V, E = weight.shape
+    out = torch.empty((ids.numel(), E), dtype=torch.float32, device=weight.device)
+    _l.check(_lib().vqf_embed_dropout_fwd(_ptr(weight), ctypes.c_void_p(ids.data_ptr()), ids.numel(), V, E, _keep_ptr(keep), int(seed),
+                                          float(p_drop), _ptr(out), _stream()), "vqf_embed_dropout_fwd")
+    return out
+
+
+def embed_dropout_bwd(dout, ids, V, keep=None, seed=0, p_drop=0.5):
+    """-> dW (V, E) = segment sums of dout * keep / (1 - p) over the tokens of each id, one launch"""
+    _chk(dout)
+    _chk_ids(ids)
+    E = dout.shape[-1]
+    dW = torch.empty((V, E), dtype=torch.float32, device=dout.device)
+    _l.check(_lib().vqf_embed_dropout_bwd(_ptr(dout), ctypes.c_void_p(ids.data_ptr()), ids.numel(), V, E, _keep_ptr(keep), int(seed),
+                                          float(p_drop), _ptr(dW), _stream()), "vqf_embed_dropout_bwd")
+    return dW
+
+
 def embed_tanh_bwd(dout, out, ids, V, time_major=False):
     """-> dW (V,E): deterministic segment sum of dout * (1 - out^2) over the tokens of each id (out=None: of dout, the plain lookup);
     time_major: dout / out are (Tq, N, E) for ids (N, Tq)"""
