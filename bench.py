@@ -861,6 +861,8 @@ def main():
                          "silence (no rank log growing, no rank ending) before the parent kills the job with a diagnosis")
     ap.add_argument("--pg-timeout", type=float, default=None,
                     help="bound in seconds on the torch.distributed rendezvous and on each collective (default 120: host/parallel.py)")
+    ap.add_argument("--final-two-streams", action="store_true",
+                    help="A/B: the two products of a final MFB block (and their gradients) on two streams (functions.FinalMfbFn.TWO_STREAMS)")
     ap.add_argument("--no-dp-one-rank", action="store_true",
                     help="skip the one-rank data-parallel rehearsal (`secondary_summary.dp_one_rank`) of a default 1-GPU run")
     args = ap.parse_args()
@@ -893,6 +895,8 @@ def main():
 
     if args.no_defer:
         import_module("vqa-attention-networks_amd.host.mfb")._SideStream.DEFER = False
+    if args.final_two_streams:
+        vqa_amd.functions.FinalMfbFn.TWO_STREAMS = True
     if os.environ.get("VQF_TEST_STALL_RANK") == os.environ.get("RANK", "0") and multi:
         # test switch (tests/test_launch_deadline.py): this rank never arrives at the rendezvous
         stage("VQF_TEST_STALL_RANK: sleeping %s s before the rendezvous" % os.environ.get("VQF_TEST_STALL_S", "600"))

@@ -486,12 +486,42 @@ class MfbFuseFn(torch.autograd.Function):
         return dP, dbi, dq, None, None, None, None, None, None
 
 
+class _Fork:
+    """Run a block of launches on a second stream beside the caller's (two independent ~100-us products of a final MFB block:
+    each leaves a third of the chip's issue slots idle in its prologue, tail and slab reduce).  with _Fork(dev) as f: ... launches
+    on the side stream ...; f.join(*tensors_made_there) makes the caller's stream wait and tells the allocator who reads them."""
+    _streams = {}
+
+    def __init__(self, device):
+        self.cur = torch.cuda.current_stream(device)
+        self.side = _Fork._streams.get(device)
+        if self.side is None:
+            self.side = _Fork._streams[device] = torch.cuda.Stream(device=device)
+        self.side.wait_stream(self.cur)
+        self._ctx = torch.cuda.stream(self.side)
+
+    def __enter__(self):
+        self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        return self._ctx.__exit__(*exc)
+
+    def join(self, *tensors):
+        self.cur.wait_stream(self.side)
+        for t in tensors:
+            if t is not None:
+                t.record_stream(self.cur)
+
+
 class FinalMfbFn(torch.autograd.Function):
     """a9: y = L2norm_row(ssqrt(pool5(dropout((qa Wq^T + bq) * (va Wv^T + bv))))), (N,1000).
 
     cascade (N,5000) optional third factor and want_zdrop: MHB's high-order block
     (mhb_coAtt.py:201-211) reuses this stage.
     """
+
+    TWO_STREAMS = False    # A/B: the question-side and image-side products (and their gradients) on two streams
 
     @staticmethod
     def forward(ctx, qa, va, wq, bq, wv, bv, keep, seed, p_drop, cascade=None, want_zdrop=False, bf16=False):
@@ -504,6 +534,12 @@ class FinalMfbFn(torch.autograd.Function):
             qa_s, va_s, wqb, wvb = ops.cast_bf16(qa), ops.cast_bf16(va), ops.cast_bf16(wq2), ops.cast_bf16(wv2)
             qq = ops.gemm_bf16(qa_s, wqb, bias=bq)
             vv = ops.gemm_bf16(va_s, wvb, bias=bv)
+        elif FinalMfbFn.TWO_STREAMS:
+            qa_s, va_s, wqb, wvb = qa, va, None, None
+            with _Fork(qa.device) as f:
+                vv = ops.gemm(va, wv2, bias=bv)
+            qq = ops.gemm(qa, wq2, bias=bq)
+            f.join(vv)
         else:
             qa_s, va_s, wqb, wvb = qa, va, None, None
             qq = ops.gemm(qa, wq2, bias=bq)
@@ -531,6 +567,17 @@ class FinalMfbFn(torch.autograd.Function):
             dva = ops.gemm_bf16(dvb, wvb, tb=True) if ctx.needs_input_grad[1] else None
             dwq = ops.gemm_bf16(dqb, qa, ta=True, tb=True).view_as(wq)
             dwv = ops.gemm_bf16(dvb, va, ta=True, tb=True).view_as(wv)
+        elif FinalMfbFn.TWO_STREAMS:
+            wq2, wv2 = _w2d(wq), _w2d(wv)
+            with _Fork(dqq.device) as f:
+                dva = ops.gemm(dvv, wv2, tb=True) if ctx.needs_input_grad[1] else None
+                dwv = ops.gemm(dvv, va, ta=True, tb=True).view_as(wv)
+                dbv = ops.colsum(dvv)
+            dqa = ops.gemm(dqq, wq2, tb=True) if ctx.needs_input_grad[0] else None
+            dwq = ops.gemm(dqq, qa, ta=True, tb=True).view_as(wq)
+            dbq = ops.colsum(dqq)
+            f.join(dva, dwv, dbv)
+            return dqa, dva, dwq, dbq, dwv, dbv, None, None, None, dcasc, None, None
         else:
             wq2, wv2 = _w2d(wq), _w2d(wv)
             dqa = ops.gemm(dqq, wq2, tb=True) if ctx.needs_input_grad[0] else None
