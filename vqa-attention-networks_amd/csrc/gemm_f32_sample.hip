@@ -79,6 +79,14 @@ __device__ __forceinline__ void wait_copies(int later) {     // all but the 4 * 
   else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// The same for slab `sidx` of an item whose first four slabs were issued AHEAD of the previous item's 48 main output stores
+// (`behind_stores`): vector-memory operations complete in issue order, so while sidx < 4 the operations younger than slab sidx's
+// copies are the rest of those four slabs, the 48 stores and the refills of this loop so far -- 60 in every case (see the kernel).
+__device__ __forceinline__ void wait_slab(int sidx, int later, bool behind_stores) {
+  if (behind_stores && sidx < NSLOT - 1) asm volatile("s_waitcnt vmcnt(60)" ::: "memory");
+  else wait_copies(later);
+}
+
 // operand values of one k-step (8 k) for the wave's 3 row tiles / 2 column tiles; MFMA step (ks, e) multiplies k = 8 ks + e (lanes
 // 0-31) and k = 8 ks + 4 + e (lanes 32-63), both operands alike
 struct FragA {
@@ -124,9 +132,10 @@ __global__ void __launch_bounds__(NT, 2) gemm_f32_sample_kernel(const SampleArgs
 
   // The slab ring runs on across a workgroup's items: when a wave leaves an item's K loop every wave has passed that loop's last
   // barrier, i.e. has finished reading every slab but the last one, so the four slots that do not hold the last slab are free and
-  // the NEXT item's first four slabs are issued right behind this item's output stores (gemm_f32_big.hip has the argument); its
-  // fifth slab follows behind the next loop's first barrier, which every wave reaches with its K loop behind it.
+  // the NEXT item's first four slabs are issued from this item's epilogue, AHEAD of its main output stores (see there); its fifth
+  // slab follows behind the next loop's first barrier, which every wave reaches with its K loop behind it.
   int slot = 0;                                            // ring slot of the current item's slab 0, then of slab s
+  bool behind = false;                                     // this item's slabs 0-3 were issued ahead of the previous item's main stores
   gfloat* qa[NG];
   gfloat* qb[NG];
   auto begin_item = [&](int w) {
@@ -212,7 +221,7 @@ __global__ void __launch_bounds__(NT, 2) gemm_f32_sample_kernel(const SampleArgs
     // read of slab s-1 (waves 0-3: consumed by MFMAs issued before the barrier; waves 4-7: the lgkmcnt(0)).
     if (!late) {
       for (int s = 0; s < S; ++s) {
-        wait_copies(min(NSLOT - 2, S - 1 - s));            // my copies of slab s; later slabs stay in flight
+        wait_slab(s, min(NSLOT - 2, S - 1 - s), behind);   // my copies of slab s; later slabs (and the last item's stores) stay in flight
         __builtin_amdgcn_s_barrier();
         const char* sA = smem + slot * SLOT_BYTES;
         const char* sB = sA + OP_BYTES;
@@ -234,7 +243,7 @@ __global__ void __launch_bounds__(NT, 2) gemm_f32_sample_kernel(const SampleArgs
       }
       __builtin_amdgcn_s_barrier();                        // pairs with the mid-slab barrier of waves 4-7 in their last slab
     } else {
-      wait_copies(min(NSLOT - 1, S) - 1);                  // my copies of slab 0
+      wait_slab(0, min(NSLOT - 1, S) - 1, behind);         // my copies of slab 0
       __builtin_amdgcn_s_barrier();                        // pairs with the slab-0 barrier of waves 0-3
       for (int s = 0; s < S; ++s) {
         const char* sA = smem + slot * SLOT_BYTES;
@@ -254,7 +263,7 @@ __global__ void __launch_bounds__(NT, 2) gemm_f32_sample_kernel(const SampleArgs
         mma_kstep(fa[0], fb[0], 0, ragged);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_waitcnt(0xC07F);                // lgkmcnt(0): every read of slab s by this wave has returned
-        wait_copies(min(s + NSLOT - 1, S - 1) - (s + 1));  // my copies of slab s+1; later slabs stay in flight
+        wait_slab(s + 1, min(s + NSLOT - 1, S - 1) - (s + 1), behind);      // my copies of slab s+1; later slabs stay in flight
         __builtin_amdgcn_s_barrier();                      // pairs with the slab-(s+1) barrier of waves 0-3 (their final one for s = S-1)
         __builtin_amdgcn_sched_barrier(0);
         mma_kstep(fa[1], fb[1], 1, ragged);                // (ragged operands in registers: read before the lgkmcnt(0) above)
@@ -262,28 +271,25 @@ __global__ void __launch_bounds__(NT, 2) gemm_f32_sample_kernel(const SampleArgs
       }
     }
 
-    // ---- epilogue: accumulator tile (i, j), register e, lane (cm, h): row wr*96 + 32 i + (e & 3) + 8 (e >> 2) + 4 h, columns
-    // wc*64 + 2 cm + j -> one 8-byte store per (i, e)
+    // ---- epilogue.  Order matters: vector-memory operations retire in issue order and the copy waits count ALL of them, so the next
+    // item's first four slabs are issued AHEAD of this item's 48 main output stores (behind the biases and the few ragged-row
+    // stores): its K loop then starts as soon as those copies have landed, while the stores drain behind them -- issued behind the
+    // stores (round-5 first form) the first slab waited for every store of the previous item, ~8 us per item.  The four slots
+    // written are free: every wave has passed the K loop's last barrier, i.e. finished reading every slab but the last one.
+    // accumulator tile (i, j), register e, lane (cm, h): row wr*96 + 32 i + (e & 3) + 8 (e >> 2) + 4 h, columns wc*64 + 2 cm + j ->
+    // one 8-byte store per (i, e)
     const bool relu = g.flags & VQF_GEMM_RELU;
-    {
-      const int cm = lane & 31, h = lane >> 5;
-      const int col = n0 + wc * 64 + 2 * cm;
-      float bv[2] = {0.f, 0.f};
-      if (g.bias) { bv[0] = g.bias[col]; bv[1] = g.bias[col + 1]; }
-      __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0) for the biases, once, as a builtin (gemm_f32_big.hip store_tile)
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int row = m0 + wr * 96 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
-          float v0 = acc[i][0][e] + bv[0], v1 = acc[i][1][e] + bv[1];
-          if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-          *reinterpret_cast<f32x2*>(g.C + (long long)row * g.ldc + col) = f32x2{v0, v1};
-        }
+    const int cm = lane & 31, h = lane >> 5;
+    const int col = n0 + wc * 64 + 2 * cm;
+    float bv[2] = {0.f, 0.f};
+    float bvr = 0.f;
+    if (g.bias) {
+      bv[0] = g.bias[col]; bv[1] = g.bias[col + 1];
+      if (ragged) bvr = g.bias[n0 + rg * 64 + lane];
     }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0) for the biases, once, as a builtin (gemm_f32_big.hip store_tile)
     if (ragged) {
-      const int col = n0 + rg * 64 + lane;
-      const float bvr = g.bias ? g.bias[col] : 0.f;
+      const int colr = n0 + rg * 64 + lane;
 #pragma unroll
       for (int u = 0; u < MAXRAG; ++u)
         if (u < nrag) {
@@ -291,11 +297,21 @@ __global__ void __launch_bounds__(NT, 2) gemm_f32_sample_kernel(const SampleArgs
           for (int r = 0; r < 4; ++r) {
             float v = rag[u][r] + bvr;
             if (relu) v = fmaxf(v, 0.f);
-            g.C[(long long)(m0 + 192 + 4 * u + r) * g.ldc + col] = v;
+            g.C[(long long)(m0 + 192 + 4 * u + r) * g.ldc + colr] = v;
           }
         }
     }
-    if (w + (int)gridDim.x < items) begin_item(w + gridDim.x);      // behind this wave's output stores (the copy waits count them in)
+    behind = w + (int)gridDim.x < items;
+    if (behind) begin_item(w + gridDim.x);                 // the next item's slabs 0-3, AHEAD of the 48 stores below
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wr * 96 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+        float v0 = acc[i][0][e] + bv[0], v1 = acc[i][1][e] + bv[1];
+        if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+        *reinterpret_cast<f32x2*>(g.C + (long long)row * g.ldc + col) = f32x2{v0, v1};
+      }
   }
 }
 
