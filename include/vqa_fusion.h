@@ -53,7 +53,8 @@ extern "C" {
 
 /* ABI version (2: LSTM entry points take a workspace and flags, large-tile GEMMs, solver tail, staging; 4: library
  * options, row-scaled GEMM; 5: the whole-sequence LSTM entry points left the library, HBM yardsticks, fused epilogues of
- * the HieCoAtten path; 6: vqf_gate_tanh_sigmoid_*, per-sample-tile GEMM entry points, stated tanh accuracy contract) and
+ * the HieCoAtten path; 6: vqf_gate_tanh_sigmoid_*, per-sample-tile GEMM entry points, stated tanh accuracy contract;
+ * 7: vqf_hie_affinity) and
  * build information ("libvqa_fusion gfx950 fp32-mfma(...) tiles ...") */
 int vqf_abi_version(void);
 const char* vqf_build_info(void);
@@ -427,6 +428,19 @@ int vqf_hie_rank_add(const float* a, int lda, const float* U, const float* V, in
 int vqf_hie_rank_left(const float* U, const float* V, int ldv, const float* z, int ldz, int N, int L, int E, int T, float* out,
                       int ldo, float* part, int ldp, void* stream);
 int vqf_hie_slab_sum(const float* part, int S, int R, int W, const float* add, int lda, float* out, int ldo, void* stream);
+/* The ladder's inner-product stage (ABI 7): out[n,t,l] = epi( sum_e x1[n*T+t, e] y1[n*L+l, e]  [+ sum_e x2[..] y2[..]] ), out
+ * (N, T, L) contiguous; x*, y*: rows with strides ldx*, ldy* (column blocks of the concatenated-weight products), 16-byte
+ * aligned.  Replaces the batched 14-row GEMMs of hieCoAtten.py:32 (C = tanh(Cq Cv^T), functions.HieCoreFn) and of its gradient
+ * (dC = dti img_^T + que_ dtq^T: the second pair) with one pass over the y rows on v_mfma_f32_16x16x4_f32 (fp32 exact
+ * products, one k-ordered accumulation per output; the order differs from vqf_gemm_f32_batched's: same value to fp32 rounding).
+ * epi 0: the sums; 1: dropout(tanh(.)) -- mask and tanh exactly those of vqf_tanh_dropout_fwd on the contiguous (N*T, L)
+ * tensor (keep / seed / p_drop as there); 2: its backward, out = sums * sc * (1 - (yprev / sc)^2) with yprev the forward's
+ * output (vqf_tanh_dropout_bwd).  x2 == y2 == NULL: one pair.  Supported: T <= 16, E % 32 == 0, pairs * 16 * (E + 4) floats
+ * of LDS <= 160 KB; any N <= 65535, any L. */
+int vqf_hie_affinity_supported(int N, int L, int E, int T, int pairs);
+int vqf_hie_affinity(const float* x1, int ldx1, const float* y1, int ldy1, const float* x2, int ldx2, const float* y2, int ldy2,
+                     int epi, const float* yprev, const uint8_t* keep, uint64_t seed, float p_drop, int N, int L, int E, int T,
+                     float* out, void* stream);
 
 /* softmax over the last axis of (R,W) and its backward   modules.py:91-92 */
 int vqf_softmax_rows_fwd(const float* x, int R, int W, float* y, void* stream);

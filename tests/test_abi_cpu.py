@@ -39,7 +39,7 @@ def test_library_exports_every_declared_symbol(vqa):
 def test_binding_table_covers_the_header(vqa):
     assert sorted(vqa.lib.SIGNATURES.keys()) == _header_symbols()
     lib = vqa.lib.load()
-    assert lib.vqf_abi_version() == vqa.lib.ABI_VERSION == 6
+    assert lib.vqf_abi_version() == vqa.lib.ABI_VERSION == 7
     assert b"gfx950" in lib.vqf_build_info()
     assert lib.vqf_prof_num_kernels() > 10
     names = [lib.vqf_prof_kernel_name(i) for i in range(lib.vqf_prof_num_kernels())]

@@ -75,6 +75,42 @@ def test_dropout_and_tanh_dropout_kernels():
     assert torch.equal(ops.dropout(ones, p_drop=0.0), ones)
 
 
+@pytest.mark.parametrize("N,L,E,T", [(3, 196, 512, 14), (2, 50, 64, 5), (5, 17, 96, 16), (300, 196, 512, 14), (1, 1000, 1024, 1)])
+def test_hie_affinity_kernel_vs_fp64_and_the_elementwise_masks(N, L, E, T):
+    """vqf_hie_affinity (hieCoAtten.py:32-33 and its gradient): sums vs fp64 within the fp32 bound of a K-term product (one or
+    two operand pairs, strided rows), the fused dropout(tanh(.)) and its backward against the fp64 formula with an explicit
+    mask, and -- Philox -- the SAME zero pattern as vqf_tanh_dropout_fwd on the contiguous (N*T, L) tensor."""
+    ops = _vqa().ops
+    from node_harness import gemm_tol
+    assert ops.hie_affinity_supported(N, L, E, T, 2)
+    wide = _r((N * T, 2 * E), 11).float().cuda()         # column blocks of wider buffers, like [Cq | que_]
+    x1, x2 = wide[:, :E], wide[:, E:]
+    widey = _r((N * L, 2 * E), 12).float().cuda()
+    y1, y2 = widey[:, :E], widey[:, E:]
+    d = lambda t, R: t.double().view(N, R, E)
+    s1 = torch.einsum("nte,nle->ntl", d(x1, T), d(y1, L))
+    s2 = s1 + torch.einsum("nte,nle->ntl", d(x2, T), d(y2, L))
+    c1 = ops.hie_affinity(x1, y1, N, L, T)
+    c2 = ops.hie_affinity(x1, y1, N, L, T, x2=x2, y2=y2)
+    assert _rel(c1, s1) <= gemm_tol(E) and _rel(c2, s2) <= gemm_tol(2 * E)
+    assert _rel(c1, ops.bgemm(x1.reshape(N, T, E).contiguous(), y1.reshape(N, L, E).contiguous())) <= 2 * gemm_tol(E)
+    keep = (torch.rand((N, T, L), generator=torch.Generator().manual_seed(13)) >= 0.5).to(torch.uint8).cuda()
+    sc = keep.double() * 2.0
+    f = ops.hie_affinity(x1, y1, N, L, T, epi=1, drop=(keep, 0, 0.5))
+    smax = float(s1.abs().max())                          # gemm_tol is relative to max|s|; tanh' <= 1 turns it into an absolute bound
+    assert _rel(f, torch.tanh(s1) * sc) <= 2e-6 + gemm_tol(E) * smax
+    b = ops.hie_affinity(x1, y1, N, L, T, x2=x2, y2=y2, epi=2, yprev=f, drop=(keep, 0, 0.5))
+    assert _rel(b, s2 * sc * (1 - torch.tanh(s1) ** 2)) <= 1e-5 + 2 * gemm_tol(E) * smax
+    if N * T * L % 4 == 0:                                # the flat element-wise kernels take whole groups of four
+        fp = ops.hie_affinity(x1, y1, N, L, T, epi=1, drop=(None, 77, 0.5))
+        flat = ops.tanh_dropout_fwd(c1.view(N * T, L), None, seed=77, p_drop=0.5)
+        assert torch.equal(fp.view(N * T, L) == 0, flat == 0) and _rel(fp.view(N * T, L), flat) <= 2e-6
+        bp = ops.hie_affinity(x1, y1, N, L, T, x2=x2, y2=y2, epi=2, yprev=fp, drop=(None, 77, 0.5))
+        assert _rel(bp, ops.tanh_dropout_bwd(c2.view(N * T, L).clone(), fp.view(N * T, L), seed=77, p_drop=0.5).view(N, T, L)) <= 1e-5
+    with pytest.raises(_vqa().lib.VqfError):
+        ops.hie_affinity(wide[:, :40], widey[:, :40], N, L, T)         # E % 32 != 0
+
+
 def test_softmax_rows_kernel():
     ops = _vqa().ops
     for R, W in [(21, 196), (5, 7), (300, 22), (2, 1000)]:
@@ -138,15 +174,18 @@ def _hie_oracle_pair(case, img, q, ans, drop=None):
     return res[0][0], res[0][1], res[1][1]
 
 
-@pytest.fixture(params=["stream", "bgemm", "staged"])
+@pytest.fixture(params=["stream", "stream-bgemm-affinity", "bgemm", "staged"])
 def hie_form(request):
-    """The three executions of the ladder: one node with the tiny-T stages as streaming passes (default; csrc/hie.hip), one
-    node with batched GEMMs + element-wise kernels (what unsupported shapes get: T > 16 ...), one node per stage (rounds 1-3)."""
+    """The executions of the ladder: one node with the tiny-T stages as streaming passes and the affinity products on
+    vqf_hie_affinity (default; csrc/hie.hip), the same with the affinity products as batched GEMMs (round 4's form), one node
+    with batched GEMMs + element-wise kernels throughout (what unsupported shapes get: T > 16 ...), one node per stage
+    (rounds 1-3)."""
     vqa = _vqa()
-    old = vqa.functions.HieCoreFn.STREAM
-    vqa.functions.HieCoreFn.STREAM = request.param == "stream"
+    old = vqa.functions.HieCoreFn.STREAM, vqa.functions.HieCoreFn.AFFINITY
+    vqa.functions.HieCoreFn.STREAM = request.param.startswith("stream")
+    vqa.functions.HieCoreFn.AFFINITY = request.param == "stream"
     yield request.param
-    vqa.functions.HieCoreFn.STREAM = old
+    vqa.functions.HieCoreFn.STREAM, vqa.functions.HieCoreFn.AFFINITY = old
 
 
 @pytest.mark.parametrize("case", [pytest.param(c, id=c["name"]) for c in HIE_CASES])

@@ -54,6 +54,7 @@ enum VqfKernelId {
   KID_HIE_ADD,
   KID_HIE_LEFT,
   KID_HIE_SLABSUM,
+  KID_HIE_AFF,
   KID_COUNT
 };
 

@@ -244,6 +244,102 @@ __global__ void slab_sum_kernel(const float* __restrict__ part, int S, int R, in
   }
 }
 
+// ---- the affinity products: C[n,t,l] = sum_e X[n,t,e] Y[n,l,e] (hieCoAtten.py:32 and its gradient) -------------------------------
+// The inner-product shape of the ladder: T = 14 rows against L = 196, K = E.  On the 128x128-tile batched GEMM a 14-row A panel
+// wastes 8/9 of every MFMA and the launch took 50 us for 103 MB of Y rows (2 TB/s).  Here a wave owns 16 rows of Y
+// (v_mfma_f32_16x16x4_f32: A = the sample's (16, E) X image in LDS, rows T..15 zero; B = the wave's 16 Y rows straight from
+// memory, each lane 32 contiguous bytes per 32-wide k step, eight steps requested before the first is consumed), one
+// workgroup per sample (chunks of row groups for small batches: outputs are disjoint, nothing to reduce).  Optional second
+// pair (X2, Y2) accumulated behind the first (dC = dti img_^T + que_ dtq^T in one launch) and the element-wise neighbour in the
+// epilogue: EPI 1 = dropout(tanh(.)) (:32-33), EPI 2 = its backward given the forward's output.  The dropout index of (n,t,l)
+// is that of the contiguous (N*T, L) tensor: same masks as vqf_tanh_dropout_fwd / _bwd.
+struct AffArgs {
+  const float* x1; int ldx1; const float* y1; int ldy1;
+  const float* x2; int ldx2; const float* y2; int ldy2;
+  const float* yprev; float* out;
+  const uint8_t* keep; uint64_t seed; uint32_t thr; float inv_keep;
+  int N, L, E, T;
+};
+
+__device__ __forceinline__ float keep1(const uint8_t* __restrict__ keep, uint64_t seed, uint32_t thr, float inv_keep, long long idx) {
+  if (keep) return keep[idx] ? inv_keep : 0.f;
+  if (thr == 0u) return 1.0f;
+  const uint4 r = philox4x32_10((uint64_t)(idx >> 2), seed);
+  const int j = (int)(idx & 3);
+  const uint32_t v = j == 0 ? r.x : j == 1 ? r.y : j == 2 ? r.z : r.w;
+  return v >= thr ? inv_keep : 0.f;
+}
+
+template <int EPI>
+__global__ void __launch_bounds__(1024) hie_affinity_kernel(const AffArgs g) {
+  extern __shared__ float smem[];
+  const int E = g.E, T = g.T, L = g.L, ES = E + 4;           // + 4: the 16 rows of a b128 fragment read fall on distinct banks
+  const int n = blockIdx.y, tid = threadIdx.x, W = blockDim.x >> 6, wave = tid >> 6, lane = tid & 63;
+  const int npair = g.x2 ? 2 : 1, CT = E >> 2;
+  for (int p = 0; p < npair; ++p) {
+    const float* x = p ? g.x2 : g.x1;
+    const int ldx = p ? g.ldx2 : g.ldx1;
+    float* Xs = smem + p * 16 * ES;
+    for (int i = tid; i < 16 * CT; i += blockDim.x) {
+      const int t = i / CT, c = i - t * CT;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (t < T) v = *reinterpret_cast<const f32x4*>(x + (long long)(n * T + t) * ldx + 4 * c);
+      *reinterpret_cast<f32x4*>(Xs + t * ES + 4 * c) = v;
+    }
+  }
+  __syncthreads();
+  const int G = (L + 15) >> 4;
+  const int r = lane & 15, kq = lane >> 4;
+  for (int grp = blockIdx.x * W + wave; grp < G; grp += gridDim.x * W) {
+    const int l = grp * 16 + r;
+    const long long row = (long long)n * L + (l < L ? l : L - 1);      // rows past L: a valid row, result not stored
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < npair; ++p) {
+      const float* y = (p ? g.y2 : g.y1) + row * (p ? g.ldy2 : g.ldy1) + 8 * kq;
+      const float* xs = smem + p * 16 * ES + r * ES + 8 * kq;
+      for (int k0 = 0; k0 < E; k0 += 256) {
+        f32x4 b[16];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (k0 + 32 * u < E) {                                       // (uniform)
+            b[2 * u] = vqf_ld_stream(reinterpret_cast<const f32x4*>(y + k0 + 32 * u));
+            b[2 * u + 1] = vqf_ld_stream(reinterpret_cast<const f32x4*>(y + k0 + 32 * u + 4));
+          }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (k0 + 32 * u < E) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(xs + k0 + 32 * u);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(xs + k0 + 32 * u + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], b[2 * u][j], acc, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], b[2 * u + 1][j], acc, 0, 0, 0);
+          }
+      }
+    }
+    if (l < L) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int t = 4 * kq + j;                                      // D: rows 4 (lane / 16) + j, column lane % 16
+        if (t < T) {
+          const long long idx = ((long long)n * T + t) * L + l;
+          float v = acc[j];
+          if (EPI == 1) {
+            v = vqf_tanh_fast(v) * keep1(g.keep, g.seed, g.thr, g.inv_keep, idx);
+          } else if (EPI == 2) {
+            const float sc = keep1(g.keep, g.seed, g.thr, g.inv_keep, idx);
+            const float th = sc > 0.f ? g.yprev[idx] * (1.0f / g.inv_keep) : 0.f;
+            v = v * sc * (1.0f - th * th);
+          }
+          g.out[idx] = v;
+        }
+      }
+    }
+  }
+}
+
+VqfDynLdsFlags g_aff_lds[3];
+
 bool shape_ok(int N, int L, int E, int T) {
   if (N <= 0 || L <= 0 || E <= 0 || T <= 0 || N > 65535 || T > TMAX_ALL || (E % 4)) return false;
   const int CT = E / 4;
@@ -365,6 +461,47 @@ int vqf_hie_rank_left(const float* U, const float* V, int ldv, const float* z, i
   g.z = z; g.ldz = ldz; g.out = out; g.ldo = ldo; g.U = U; g.V = V; g.ldv = ldv; g.part = part; g.ldp = ldp;
   g.N = N; g.L = L; g.E = E; g.T = T;
   return launch(MODE_LEFT, g, nullptr, 0, 0.f, (hipStream_t)stream);
+}
+
+int vqf_hie_affinity_supported(int N, int L, int E, int T, int pairs) {
+  if (N <= 0 || N > 65535 || L <= 0 || T <= 0 || T > 16 || E <= 0 || (E % 32) || pairs < 1 || pairs > 2) return 0;
+  return (size_t)pairs * 16 * (E + 4) * sizeof(float) <= 160 * 1024;
+}
+
+int vqf_hie_affinity(const float* x1, int ldx1, const float* y1, int ldy1, const float* x2, int ldx2, const float* y2, int ldy2,
+                     int epi, const float* yprev, const uint8_t* keep, uint64_t seed, float p_drop, int N, int L, int E, int T,
+                     float* out, void* stream) {
+  const int pairs = x2 ? 2 : 1;
+  if (!out || !rows_ok(x1, ldx1, E) || !rows_ok(y1, ldy1, E) || (!x2) != (!y2) || (x2 && (!rows_ok(x2, ldx2, E) || !rows_ok(y2, ldy2, E))) ||
+      epi < 0 || epi > 2 || (epi == 2 && !yprev) || p_drop < 0.f || p_drop >= 1.f)
+    return VQF_E_BADARG;
+  if (!vqf_hie_affinity_supported(N, L, E, T, pairs)) return VQF_E_UNSUPPORTED;
+  AffArgs g = {};
+  g.x1 = x1; g.ldx1 = ldx1; g.y1 = y1; g.ldy1 = ldy1; g.x2 = x2; g.ldx2 = ldx2; g.y2 = y2; g.ldy2 = ldy2;
+  g.yprev = yprev; g.out = out; g.N = N; g.L = L; g.E = E; g.T = T;
+  g.keep = epi ? keep : nullptr; g.seed = seed;
+  g.thr = (!epi || keep || p_drop == 0.f) ? 0u : drop_threshold_host(p_drop);
+  g.inv_keep = (epi && (keep || p_drop > 0.f)) ? 1.0f / (1.0f - p_drop) : 1.0f;
+  const int cus = vqf_cu_count() > 0 ? vqf_cu_count() : 256;
+  const int G = (L + 15) / 16;
+  int S = (cus + N - 1) / N;                       // whole samples per workgroup once N >= the CU count
+  if (S > G) S = G;
+  int W = (G + S - 1) / S;
+  if (W > 16) W = 16;
+  const int lds = pairs * 16 * (E + 4) * (int)sizeof(float);
+  const void* fn = epi == 0 ? (const void*)hie_affinity_kernel<0> : epi == 1 ? (const void*)hie_affinity_kernel<1> : (const void*)hie_affinity_kernel<2>;
+  if (lds > 64 * 1024) {
+    const int rc = vqf_set_dyn_lds(fn, lds, g_aff_lds[epi]);
+    if (rc != VQF_OK) return rc;
+  }
+  const dim3 grid(S, N), block(64 * W);
+  hipStream_t s = (hipStream_t)stream;
+  switch (epi) {
+    case 0:  VQF_LAUNCH(KID_HIE_AFF, hie_affinity_kernel<0>, grid, block, lds, s, g); break;
+    case 1:  VQF_LAUNCH(KID_HIE_AFF, hie_affinity_kernel<1>, grid, block, lds, s, g); break;
+    default: VQF_LAUNCH(KID_HIE_AFF, hie_affinity_kernel<2>, grid, block, lds, s, g); break;
+  }
+  return vqf_last_error();
 }
 
 }  // extern "C"

@@ -48,7 +48,7 @@ const char* const kNames[KID_COUNT] = {
     "gemm_bf16", "cast_f32_bf16",
     "lstm_seq_fwd(all steps)", "lstm_seq_bwd(all steps)",
     "ce_loss", "kldiv_loss", "adam_step", "feat_transpose",
-    "lstm_cell_fwd", "lstm_cell_bwd", "embed_tanh_fwd", "embed_tanh_bwd", "hbm_copy", "hbm_read_sweep", "multi_add", "multi_copy", "hie_hv_fwd", "hie_head_bwd", "hie_rank_add", "hie_rank_left", "hie_slab_sum"};
+    "lstm_cell_fwd", "lstm_cell_bwd", "embed_tanh_fwd", "embed_tanh_bwd", "hbm_copy", "hbm_read_sweep", "multi_add", "multi_copy", "hie_hv_fwd", "hie_head_bwd", "hie_rank_add", "hie_rank_left", "hie_slab_sum", "hie_affinity"};
 
 hipEvent_t get_event() {
   std::lock_guard<std::mutex> lk(g_mu);
@@ -77,7 +77,7 @@ void vqf_prof_end(int id, hipStream_t s) {
 void vqf_prof_dims(int d0, int d1, int d2) { t_dims[0] = d0; t_dims[1] = d1; t_dims[2] = d2; }
 
 extern "C" {
-int vqf_abi_version(void) { return 6; }
+int vqf_abi_version(void) { return 7; }
 int vqf_set_option(int option, int value, int* previous) {
   if (option < 0 || option >= VQF_OPT_COUNT) return VQF_E_BADARG;
   if (previous) *previous = g_vqf_opt[option];

@@ -754,6 +754,7 @@ class HieCoreFn(torch.autograd.Function):
     Returns (x (N, 2E), av (N,1,L), aq (N,1,T)), all differentiable."""
 
     STREAM = True      # the tiny-T stages as streaming passes (csrc/hie.hip) where supported; False: batched GEMMs + element-wise (A/B)
+    AFFINITY = True    # Cq Cv^T and its gradient on vqf_hie_affinity (needs STREAM); False: batched GEMMs + element-wise (A/B)
 
     @staticmethod
     def forward(ctx, imgf, ids, w_emb, b_emb, w_que, wbv, bbv, wv, bv, wq, bq, whv, bhv, whq, bhq, drops):
@@ -783,10 +784,14 @@ class HieCoreFn(torch.autograd.Function):
         Cv3, img_3 = CI[:, :E].view(N, L, E), CI[:, E:].view(N, L, E)
         Cq3, que_3 = CQ[:, :E].view(N, T, E), CQ[:, E:].view(N, T, E)
         # :32-33  C = dropout(tanh(Cq Cv^T))   (N,T,L)
-        C3 = ops.bgemm(Cq3, Cv3)
-        ops.tanh_dropout_fwd(C3.view(MT, L), None, *drops["C"], out=C3.view(MT, L))
-        # :38-42  Hv = dropout(tanh(img_ + C^T que_)), av = softmax_L(Whv Hv), v = av^T img;  :45  ti = C img_
         stream = HieCoreFn.STREAM and ops.hie_stream_supported(N, L, E, T)
+        aff = stream and HieCoreFn.AFFINITY and ops.hie_affinity_supported(N, L, E, T, 2)
+        if aff:                  # one pass over Cv on 16x16x4 MFMAs, tanh + dropout in its epilogue (csrc/hie.hip)
+            C3 = ops.hie_affinity(CQ[:, :E], CI[:, :E], N, L, T, epi=1, drop=drops["C"])
+        else:
+            C3 = ops.bgemm(Cq3, Cv3)
+            ops.tanh_dropout_fwd(C3.view(MT, L), None, *drops["C"], out=C3.view(MT, L))
+        # :38-42  Hv = dropout(tanh(img_ + C^T que_)), av = softmax_L(Whv Hv), v = av^T img;  :45  ti = C img_
         if stream:
             # ONE pass over img_: the rank-T update, tanh, dropout, and the T-row sums of ti in registers (csrc/hie.hip)
             S = ops.hie_chunks(N, L)
@@ -807,7 +812,7 @@ class HieCoreFn(torch.autograd.Function):
         Hq = ops.tanh_dropout_fwd2d(CQ[:, E:], ti, *drops["Hq"], out=ti)
         aq, _ = ops.glimpse_pool_fwd(que.view(N, T, E), ops.att_logits_fwd(Hq, _w2d(whq), bhq), False, pooled_out=xcat[N:])
         ctx.save_for_backward(imgf, ids, img, que, Wi, Wq2, CI, CQ, C3, Hv, Hq, av, aq, whv, whq)
-        ctx.drops, ctx.dims, ctx.V, ctx.stream = drops, (N, L, T, D, E), w_que.shape[0], stream
+        ctx.drops, ctx.dims, ctx.V, ctx.stream, ctx.aff = drops, (N, L, T, D, E), w_que.shape[0], stream, aff
         # an output nobody differentiates (av / aq under a loss on x: solver.py:84-91) arrives as None in the backward, not as a
         # zero tensor torch has to fill and the pooling kernels have to read
         ctx.set_materialize_grads(False)
@@ -847,13 +852,17 @@ class HieCoreFn(torch.autograd.Function):
                 ops.hie_head_bwd(Hv, dlv.view(M), whv.view(E), C3, drops["Hv"], N, L, T, dCI[:, E:], part, wpart)
             wsum = ops.colsum(wpart)
             dwhv, dbhv = wsum[:E], wsum[E:E + 1]
-            dC3 = ops.bgemm(dti3, img_3)                                           # dC = dti img_^T + que_ dtq^T
-            ops.bgemm(que_3, dtq3, out=dC3, accumulate=True)
+            if ctx.aff:          # dC = dti img_^T + que_ dtq^T and the backward of C = dropout(tanh(.)) in ONE pass over img_ and dtq
+                dC3 = ops.hie_affinity(dti, CI[:, E:], N, L, T, x2=CQ[:, E:], y2=dCI[:, E:], epi=2, yprev=C3, drop=drops["C"])
+            else:
+                dC3 = ops.bgemm(dti3, img_3)                                       # dC = dti img_^T + que_ dtq^T
+                ops.bgemm(que_3, dtq3, out=dC3, accumulate=True)
             if S > 1:
                 ops.hie_slab_sum(part, dCQ[:, E:], add=dti)                        # dque_ = dti + C dtq
             ops.hie_rank_add(dCI[:, E:], C3, dti, N, L, T, dCI[:, E:])             # dimg_ = dtq + C^T dti (dtq's own uses are above)
             # C = dropout(tanh(Cq Cv^T)):  dCv = daff^T Cq,  dCq = daff Cv   (one pass over Cv)
-            ops.tanh_dropout_bwd(dC3.view(MT, L), C3.view(MT, L), *drops["C"], out=dC3.view(MT, L))
+            if not ctx.aff:
+                ops.tanh_dropout_bwd(dC3.view(MT, L), C3.view(MT, L), *drops["C"], out=dC3.view(MT, L))
             if S == 1:
                 ops.hie_rank_left(dC3, CQ[:, :E], CI[:, :E], N, L, T, dCI[:, :E], dCQ[:, :E])      # dCq straight into its column block
             else:

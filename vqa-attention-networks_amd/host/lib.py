@@ -18,7 +18,7 @@ if os.environ.get("VQF_LIB"):          # A/B builds (tools/build_variant.sh); ne
 HEADER_PATH = os.path.join(os.path.dirname(PKG_DIR), "include", "vqa_fusion.h")
 
 # The one place the expected ABI number lives (csrc/prof.hip returns it from vqf_abi_version()).
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _lock = threading.Lock()
 _lib = None
@@ -82,6 +82,8 @@ SIGNATURES = {
     "vqf_hie_rank_add": (c_i, [c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_p]),
     "vqf_hie_rank_left": (c_i, [c_f, c_f, c_i, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_i, c_p]),
     "vqf_hie_slab_sum": (c_i, [c_f, c_i, c_i, c_i, c_f, c_i, c_f, c_i, c_p]),
+    "vqf_hie_affinity_supported": (c_i, [c_i, c_i, c_i, c_i, c_i]),
+    "vqf_hie_affinity": (c_i, [c_f, c_i, c_f, c_i, c_f, c_i, c_f, c_i, c_i, c_f, c_p, c_u64, ctypes.c_float, c_i, c_i, c_i, c_i, c_f, c_p]),
     "vqf_softmax_rows_fwd": (c_i, [c_f, c_i, c_i, c_f, c_p]),
     "vqf_softmax_rows_bwd": (c_i, [c_f, c_f, c_i, c_i, c_f, c_p]),
     "vqf_log_softmax_rows_fwd": (c_i, [c_f, c_i, c_i, c_f, c_p]),

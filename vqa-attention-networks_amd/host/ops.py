@@ -601,6 +601,29 @@ def hie_rank_left(U, V, z, N, L, T, out, part):
     return out
 
 
+def hie_affinity_supported(N, L, E, T, pairs=1):
+    return bool(_lib().vqf_hie_affinity_supported(int(N), int(L), int(E), int(T), int(pairs)))
+
+
+def hie_affinity(x1, y1, N, L, T, x2=None, y2=None, epi=0, yprev=None, drop=(None, 0, 0.0), out=None):
+    """out (N, T, L) = epi(x1 y1^T [+ x2 y2^T]) per sample: x* rows n*T + t, y* rows n*L + l (2-D, rows may be strided).
+    epi 0: the sums; 1: dropout(tanh(.)) with `drop` = (keep | None, seed, p); 2: the backward of epi 1 given its output yprev."""
+    _chk2s(x1, y1, x2, y2)
+    E = x1.shape[1]
+    if x1.shape[0] != N * T or y1.shape != (N * L, E) or (x2 is not None and (x2.shape != x1.shape or y2.shape != y1.shape)):
+        raise _l.VqfError("hie_affinity: operand shapes")
+    if out is None:
+        out = torch.empty((N, T, L), dtype=torch.float32, device=x1.device)
+    _chk(out)
+    if yprev is not None:
+        _chk_ntl(yprev, N, T, L)
+    keep, seed, p = drop
+    _l.check(_lib().vqf_hie_affinity(_ptr(x1), x1.stride(0), _ptr(y1), y1.stride(0), _ptr(x2), x2.stride(0) if x2 is not None else 0,
+                                     _ptr(y2), y2.stride(0) if y2 is not None else 0, int(epi), _ptr(yprev), _keep_ptr(keep),
+                                     int(seed), float(p), N, L, E, T, _ptr(out), _stream()), "vqf_hie_affinity")
+    return out
+
+
 def hie_slab_sum(part, out, add=None):
     """out[r,:] = (add[r,:] if add is given) + sum_s part[s, r, :]; part (S, R, W) contiguous, add / out 2-D, rows may be strided"""
     _chk(part)
