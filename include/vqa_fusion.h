@@ -54,7 +54,7 @@ extern "C" {
 /* ABI version (2: LSTM entry points take a workspace and flags, large-tile GEMMs, solver tail, staging; 4: library
  * options, row-scaled GEMM; 5: the whole-sequence LSTM entry points left the library, HBM yardsticks, fused epilogues of
  * the HieCoAtten path; 6: vqf_gate_tanh_sigmoid_*, per-sample-tile GEMM entry points, stated tanh accuracy contract;
- * 7: vqf_hie_affinity) and
+ * 7: vqf_hie_affinity, column sums and a partial-row pitch in the vqf_hie_* passes) and
  * build information ("libvqa_fusion gfx950 fp32-mfma(...) tiles ...") */
 int vqf_abi_version(void);
 const char* vqf_build_info(void);
@@ -411,10 +411,14 @@ int vqf_tanh_dropout_bwd2d(const float* dy, int lddy, const float* y, int ldy, c
  * T <= 16, E % 4 == 0, E / 4 divides 256, T * E small enough for LDS; else VQF_E_UNSUPPORTED (the caller uses the batched GEMMs).
  *   vqf_hie_hv_fwd     out = dropout(tanh(a + C^T V)) (:38-39, Hv; a = img_, V = que_);  part[t] += C[t,l] a[l]  (:45, ti = C img_)
  *   vqf_hie_head_bwd   out = dl[l] w sc (1 - (hv/sc)^2): gradient of :38-40 w.r.t. img_ + tq from the logit gradient dl (N*L) of
- *                      fc_Whv (weight w (E)), dHv never materialised;  part[t] += C[t,l] out[l]  (-> dque_);  wpart (S*N, E+4):
- *                      partial rows [sum_l dl[l] hv[l,:] | sum_l dl[l] | 0 0 0]  (column sums -> d fc_Whv.weight, d fc_Whv.bias)
+ *                      fc_Whv (weight w (E)), dHv never materialised;  part[t] += C[t,l] out[l]  (-> dque_);  wpart: S*N
+ *                      partial rows of pitch ldw >= E+4 (ABI 7; a column block of a wider buffer), each
+ *                      [sum_l dl[l] hv[l,:] | sum_l dl[l] | 0 0 0]  (column sums -> d fc_Whv.weight, d fc_Whv.bias)
  *   vqf_hie_rank_add   out = a + U^T V                 (dimg_ += C^T dti; in place allowed)
  *   vqf_hie_rank_left  out = U^T V;  part[t] += U[t,l] z[l]      (dCv = daff^T Cq;  dCq = daff Cv)
+ *                      both (ABI 7): colpart != NULL -> row s*N + n of colpart (pitch ldcp) = the column sums of the rows of
+ *                      `out` this workgroup wrote: summed over the S*N rows they are the bias gradients of fc_Wbv / fc_Wv
+ *                      (autograd of hieCoAtten.py:30,35) without a column-sum pass over the (N*L, 2E) gradient buffer
  *   vqf_hie_slab_sum   out[r,:] = (add ? add[r,:] : 0) + sum_s part[s][r][:],  r < R, W columns */
 int vqf_hie_stream_supported(int N, int L, int E, int T);
 int vqf_hie_chunks(int N, int L);
@@ -422,11 +426,11 @@ int vqf_hie_hv_fwd(const float* a, int lda, const float* C, const float* V, int 
                    float p_drop, int N, int L, int E, int T, float* out, int ldo, float* part, int ldp, void* stream);
 int vqf_hie_head_bwd(const float* hv, int ldh, const float* dl, const float* w, const float* C, const uint8_t* keep,
                      uint64_t seed, float p_drop, int N, int L, int E, int T, float* out, int ldo, float* part, int ldp,
-                     const float* padd, int ldpa, float* wpart, void* stream);
+                     const float* padd, int ldpa, float* wpart, int ldw, void* stream);
 int vqf_hie_rank_add(const float* a, int lda, const float* U, const float* V, int ldv, int N, int L, int E, int T, float* out,
-                     int ldo, void* stream);
+                     int ldo, float* colpart, int ldcp, void* stream);
 int vqf_hie_rank_left(const float* U, const float* V, int ldv, const float* z, int ldz, int N, int L, int E, int T, float* out,
-                      int ldo, float* part, int ldp, void* stream);
+                      int ldo, float* part, int ldp, float* colpart, int ldcp, void* stream);
 int vqf_hie_slab_sum(const float* part, int S, int R, int W, const float* add, int lda, float* out, int ldo, void* stream);
 /* The ladder's inner-product stage (ABI 7): out[n,t,l] = epi( sum_e x1[n*T+t, e] y1[n*L+l, e]  [+ sum_e x2[..] y2[..]] ), out
  * (N, T, L) contiguous; x*, y*: rows with strides ldx*, ldy* (column blocks of the concatenated-weight products), 16-byte

@@ -11,6 +11,8 @@
 //                                                                              C dtq -> dque_;  dl^T Hv -> d fc_Whv.weight
 //   mode ADD   out[l,:] = a[l,:] + sum_t U[t,l] V[t,:]                         dimg_ += C^T dti                      (of :45)
 //   mode LEFT  out[l,:] = sum_t U[t,l] V[t,:];  part[t,:] += U[t,l] z[l,:]     dCv = daff^T Cq;  dCq = daff Cv       (of :32)
+//              ADD / LEFT: colpart[:] += out[l,:] -- the two halves of [dCv | dimg_] are final here, their column sums are the
+//              bias gradients of fc_Wbv / fc_Wv (one partial row per workgroup instead of a 205 MB column-sum pass)
 //
 // a, z, out: rows m = n*L + l of 2-D tensors with row strides (column blocks of the concatenated-weight products, functions.
 // HieCoreFn); U (N, T, L) contiguous; V rows n*T + t with stride ldv.  part: (S, N, T, E) partial sums over the S row chunks of
@@ -38,7 +40,8 @@ struct HieArgs {
   float* part; int ldp;                              // partial sums: (S, N*T) rows of pitch ldp (S > 1: ldp == E, contiguous slabs)
   const float* padd; int ldpa;                       // S == 1 only: the sums are written ON TOP of these rows (or nullptr)
   const uint8_t* keep; uint64_t seed; uint32_t thr; float inv_keep;
-  const float* dl; const float* w; float* wpart;     // HEAD: logit gradient (N*L), head weight (E), partial rows (S*N, E + 4)
+  const float* dl; const float* w; float* wpart; int ldw;   // HEAD: logit gradient (N*L), head weight (E), partial rows (S*N) of pitch ldw >= E + 4
+  float* colpart; int ldcp;                          // ADD / LEFT: per-workgroup column sums of `out` (rows s*N + n, pitch ldcp) or nullptr
   int N, L, E, T, S, Lc;
 };
 
@@ -93,6 +96,8 @@ __global__ void __launch_bounds__(HT) hie_stream_kernel(const HieArgs g) {
   f32x4 wacc = {0.f, 0.f, 0.f, 0.f};
   float dlsum = 0.f;
   f32x4 wv = {0.f, 0.f, 0.f, 0.f};
+  constexpr bool COLS = MODE == MODE_ADD || MODE == MODE_LEFT;
+  f32x4 csum = {0.f, 0.f, 0.f, 0.f};
   if (MODE == MODE_HEAD) wv = *reinterpret_cast<const f32x4*>(g.w + 4 * c4);
 
   // NR rows per trip: every row's load is issued before any is consumed.  The pass is latency-bound, not VALU- or LDS-bound (28
@@ -178,7 +183,10 @@ __global__ void __launch_bounds__(HT) hie_stream_kernel(const HieArgs g) {
     }
 #pragma unroll
     for (int q = 0; q < NR; ++q)
-      if (has[q]) *reinterpret_cast<f32x4*>(g.out + m[q] * g.ldo + 4 * c4) = o[q];
+      if (has[q]) {
+        *reinterpret_cast<f32x4*>(g.out + m[q] * g.ldo + 4 * c4) = o[q];
+        if (COLS) csum += o[q];
+      }
   }
 
   // `red` re-uses the LDS of the (T, E) / (T, Lc) operand images: nobody reads them any more behind this barrier
@@ -210,8 +218,18 @@ __global__ void __launch_bounds__(HT) hie_stream_kernel(const HieArgs g) {
       }
     }
   }
+  if (COLS && g.colpart) {                                     // (uniform) column sums of this workgroup's rows, row slots in order
+    __syncthreads();
+    *reinterpret_cast<f32x4*>(red + rs * E + 4 * c4) = csum;
+    __syncthreads();
+    if (rs == 0) {
+      f32x4 sum = *reinterpret_cast<const f32x4*>(red + 4 * c4);
+      for (int q = 1; q < RS; ++q) sum += *reinterpret_cast<const f32x4*>(red + q * E + 4 * c4);
+      *reinterpret_cast<f32x4*>(g.colpart + ((long long)s * g.N + n) * g.ldcp + 4 * c4) = sum;
+    }
+  }
   if (MODE == MODE_HEAD) {
-    float* wrow = g.wpart + ((long long)s * g.N + n) * (E + 4);
+    float* wrow = g.wpart + ((long long)s * g.N + n) * g.ldw;
     __syncthreads();
     *reinterpret_cast<f32x4*>(red + rs * E + 4 * c4) = wacc;
     __syncthreads();
@@ -434,31 +452,35 @@ int vqf_hie_hv_fwd(const float* a, int lda, const float* C, const float* V, int 
 
 int vqf_hie_head_bwd(const float* hv, int ldh, const float* dl, const float* w, const float* C, const uint8_t* keep,
                      uint64_t seed, float p_drop, int N, int L, int E, int T, float* out, int ldo, float* part, int ldp,
-                     const float* padd, int ldpa, float* wpart, void* stream) {
-  if (!C || !dl || !w || !rows_ok(part, ldp, E) || (padd && !rows_ok(padd, ldpa, E)) || !wpart || !rows_ok(hv, ldh, E) ||
-      !rows_ok(out, ldo, E) || !aligned16(w) || p_drop < 0.f || p_drop >= 1.f)
+                     const float* padd, int ldpa, float* wpart, int ldw, void* stream) {
+  if (!C || !dl || !w || !rows_ok(part, ldp, E) || (padd && !rows_ok(padd, ldpa, E)) || !wpart || !aligned16(wpart) || ldw < E + 4 ||
+      (ldw % 4) || !rows_ok(hv, ldh, E) || !rows_ok(out, ldo, E) || !aligned16(w) || p_drop < 0.f || p_drop >= 1.f)
     return VQF_E_BADARG;
   HieArgs g = {};
   g.a = hv; g.lda = ldh; g.out = out; g.ldo = ldo; g.U = C; g.part = part; g.ldp = ldp; g.padd = padd; g.ldpa = ldpa;
-  g.dl = dl; g.w = w; g.wpart = wpart;
+  g.dl = dl; g.w = w; g.wpart = wpart; g.ldw = ldw;
   g.N = N; g.L = L; g.E = E; g.T = T;
   return launch(MODE_HEAD, g, keep, seed, p_drop, (hipStream_t)stream);
 }
 
 int vqf_hie_rank_add(const float* a, int lda, const float* U, const float* V, int ldv, int N, int L, int E, int T, float* out,
-                     int ldo, void* stream) {
-  if (!U || !rows_ok(a, lda, E) || !rows_ok(V, ldv, E) || !rows_ok(out, ldo, E)) return VQF_E_BADARG;
+                     int ldo, float* colpart, int ldcp, void* stream) {
+  if (!U || !rows_ok(a, lda, E) || !rows_ok(V, ldv, E) || !rows_ok(out, ldo, E) || (colpart && !rows_ok(colpart, ldcp, E)))
+    return VQF_E_BADARG;
   HieArgs g = {};
-  g.a = a; g.lda = lda; g.out = out; g.ldo = ldo; g.U = U; g.V = V; g.ldv = ldv;
+  g.a = a; g.lda = lda; g.out = out; g.ldo = ldo; g.U = U; g.V = V; g.ldv = ldv; g.colpart = colpart; g.ldcp = ldcp;
   g.N = N; g.L = L; g.E = E; g.T = T;
   return launch(MODE_ADD, g, nullptr, 0, 0.f, (hipStream_t)stream);
 }
 
 int vqf_hie_rank_left(const float* U, const float* V, int ldv, const float* z, int ldz, int N, int L, int E, int T, float* out,
-                      int ldo, float* part, int ldp, void* stream) {
-  if (!U || !rows_ok(part, ldp, E) || !rows_ok(z, ldz, E) || !rows_ok(V, ldv, E) || !rows_ok(out, ldo, E)) return VQF_E_BADARG;
+                      int ldo, float* part, int ldp, float* colpart, int ldcp, void* stream) {
+  if (!U || !rows_ok(part, ldp, E) || !rows_ok(z, ldz, E) || !rows_ok(V, ldv, E) || !rows_ok(out, ldo, E) ||
+      (colpart && !rows_ok(colpart, ldcp, E)))
+    return VQF_E_BADARG;
   HieArgs g = {};
   g.z = z; g.ldz = ldz; g.out = out; g.ldo = ldo; g.U = U; g.V = V; g.ldv = ldv; g.part = part; g.ldp = ldp;
+  g.colpart = colpart; g.ldcp = ldcp;
   g.N = N; g.L = L; g.E = E; g.T = T;
   return launch(MODE_LEFT, g, nullptr, 0, 0.f, (hipStream_t)stream);
 }

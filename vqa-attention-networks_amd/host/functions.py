@@ -845,13 +845,14 @@ class HieCoreFn(torch.autograd.Function):
         if ctx.stream:
             # dtq = d(img_ + tq) straight from the logit gradient (dHv = dlv (x) whv is never written), C dtq and dlv^T Hv on the way
             S = ops.hie_chunks(N, L)
-            part, wpart = (None if S == 1 else new(S, MT, E)), new(S * N, E + 4)
+            # one buffer of partial rows, one per workgroup: [colsum dCv | colsum dimg_ | dl^T Hv | sum dl | 0 0 0]; its column
+            # sums are the bias gradient of [fc_Wbv; fc_Wv] (no column-sum pass over the 205 MB gradient buffer) and d fc_Whv
+            cpart = new(S * N, 3 * E + 4)
+            part, wpart = (None if S == 1 else new(S, MT, E)), cpart[:, 2 * E:]
             if S == 1:           # dque_ = dti + C dtq written by the pass itself (one workgroup per sample)
                 ops.hie_head_bwd(Hv, dlv.view(M), whv.view(E), C3, drops["Hv"], N, L, T, dCI[:, E:], dCQ[:, E:], wpart, part_add=dti)
             else:
                 ops.hie_head_bwd(Hv, dlv.view(M), whv.view(E), C3, drops["Hv"], N, L, T, dCI[:, E:], part, wpart)
-            wsum = ops.colsum(wpart)
-            dwhv, dbhv = wsum[:E], wsum[E:E + 1]
             if ctx.aff:          # dC = dti img_^T + que_ dtq^T and the backward of C = dropout(tanh(.)) in ONE pass over img_ and dtq
                 dC3 = ops.hie_affinity(dti, CI[:, E:], N, L, T, x2=CQ[:, E:], y2=dCI[:, E:], epi=2, yprev=C3, drop=drops["C"])
             else:
@@ -859,14 +860,14 @@ class HieCoreFn(torch.autograd.Function):
                 ops.bgemm(que_3, dtq3, out=dC3, accumulate=True)
             if S > 1:
                 ops.hie_slab_sum(part, dCQ[:, E:], add=dti)                        # dque_ = dti + C dtq
-            ops.hie_rank_add(dCI[:, E:], C3, dti, N, L, T, dCI[:, E:])             # dimg_ = dtq + C^T dti (dtq's own uses are above)
+            ops.hie_rank_add(dCI[:, E:], C3, dti, N, L, T, dCI[:, E:], colpart=cpart[:, E:2 * E])      # dimg_ = dtq + C^T dti (dtq's own uses are above)
             # C = dropout(tanh(Cq Cv^T)):  dCv = daff^T Cq,  dCq = daff Cv   (one pass over Cv)
             if not ctx.aff:
                 ops.tanh_dropout_bwd(dC3.view(MT, L), C3.view(MT, L), *drops["C"], out=dC3.view(MT, L))
             if S == 1:
-                ops.hie_rank_left(dC3, CQ[:, :E], CI[:, :E], N, L, T, dCI[:, :E], dCQ[:, :E])      # dCq straight into its column block
+                ops.hie_rank_left(dC3, CQ[:, :E], CI[:, :E], N, L, T, dCI[:, :E], dCQ[:, :E], colpart=cpart[:, :E])      # dCq straight into its column block
             else:
-                ops.hie_rank_left(dC3, CQ[:, :E], CI[:, :E], N, L, T, dCI[:, :E], part)
+                ops.hie_rank_left(dC3, CQ[:, :E], CI[:, :E], N, L, T, dCI[:, :E], part, colpart=cpart[:, :E])
                 ops.hie_slab_sum(part, dCQ[:, :E])
         else:
             dHv, dwhv, dbhv, _ = ops.att_logits_bwd(dlv, Hv, _w2d(whv), relu_mask=False)
@@ -885,7 +886,12 @@ class HieCoreFn(torch.autograd.Function):
         dimg = ops.gemm_rows(dCI, Wi, L, tb=True)                              # (M, E); the pool's rank-1 term is added below
         ops.gemm(dCQ, Wq2, tb=True, out=dque.view(MT, E), accumulate=True)     # on top of the pool's gradient into que
         dWi, dWq2 = ops.gemm(dCI, img, ta=True, tb=True), ops.gemm(dCQ, que, ta=True, tb=True)
-        dbi, dbq2 = ops.colsum(dCI), ops.colsum(dCQ)
+        if ctx.stream:
+            csum = ops.colsum(cpart)
+            dbi, dwhv, dbhv = csum[:2 * E], csum[2 * E:3 * E], csum[3 * E:3 * E + 1]
+        else:
+            dbi = ops.colsum(dCI)
+        dbq2 = ops.colsum(dCQ)
         dwbv, dbbv = new(E, E), new(E)
         ops.multi_add([(dWi[:E], dWq2[:E], dwbv), (dbi[:E], dbq2[:E], dbbv)])  # fc_Wbv serves both sides (:30-31)
         # img = dropout(relu(img_emb(.))): mask, 1 / (1 - p) and the pool's av[n,l] * dv[n,:] in one pass, in place

@@ -78,9 +78,9 @@ SIGNATURES = {
     "vqf_hie_chunks": (c_i, [c_i, c_i]),
     "vqf_hie_hv_fwd": (c_i, [c_f, c_i, c_f, c_f, c_i, c_p, c_u64, ctypes.c_float, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_i, c_p]),
     "vqf_hie_head_bwd": (c_i, [c_f, c_i, c_f, c_f, c_f, c_p, c_u64, ctypes.c_float, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_i, c_f, c_i,
-                               c_f, c_p]),
-    "vqf_hie_rank_add": (c_i, [c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_p]),
-    "vqf_hie_rank_left": (c_i, [c_f, c_f, c_i, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_i, c_p]),
+                               c_f, c_i, c_p]),
+    "vqf_hie_rank_add": (c_i, [c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_i, c_p]),
+    "vqf_hie_rank_left": (c_i, [c_f, c_f, c_i, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_i, c_f, c_i, c_p]),
     "vqf_hie_slab_sum": (c_i, [c_f, c_i, c_i, c_i, c_f, c_i, c_f, c_i, c_p]),
     "vqf_hie_affinity_supported": (c_i, [c_i, c_i, c_i, c_i, c_i]),
     "vqf_hie_affinity": (c_i, [c_f, c_i, c_f, c_i, c_f, c_i, c_f, c_i, c_i, c_f, c_p, c_u64, ctypes.c_float, c_i, c_i, c_i, c_i, c_f, c_p]),

@@ -573,31 +573,49 @@ def hie_hv_fwd(a, C, V, drop, N, L, T, out, part):
 
 
 def hie_head_bwd(hv, dl, w, C, drop, N, L, T, out, part, wpart, part_add=None):
-    """part_add (one chunk per sample only): the T-row sums are written on top of these (N*T, E) rows"""
-    _chk2s(hv, out, part_add)
-    _chk(dl, w, wpart)
+    """part_add (one chunk per sample only): the T-row sums are written on top of these (N*T, E) rows.
+    wpart: (S*N, >= E + 4) partial rows, may be a column block of a wider buffer"""
+    _chk2s(hv, out, part_add, wpart)
+    _chk(dl, w)
+    if wpart.shape[1] < hv.shape[1] + 4:
+        raise _l.VqfError("hie_head_bwd: wpart rows hold E + 4 floats")
     _chk_ntl(C, N, T, L)
     E = hv.shape[1]
     keep, seed, p = drop
     _l.check(_lib().vqf_hie_head_bwd(_ptr(hv), hv.stride(0), _ptr(dl), _ptr(w), _ptr(C), _keep_ptr(keep), int(seed), float(p),
                                      N, L, E, T, _ptr(out), out.stride(0), _ptr(part), _part_ld(part, E), _ptr(part_add),
-                                     part_add.stride(0) if part_add is not None else 0, _ptr(wpart), _stream()), "vqf_hie_head_bwd")
+                                     part_add.stride(0) if part_add is not None else 0, _ptr(wpart), wpart.stride(0), _stream()),
+             "vqf_hie_head_bwd")
     return out
 
 
-def hie_rank_add(a, U, V, N, L, T, out):
+def _colpart(colpart, N, L, E):
+    """(S*N, E) column block the streaming pass writes one partial column-sum row per workgroup into -> (pointer, pitch)"""
+    if colpart is None:
+        return ctypes.c_void_p(0), 0
+    _chk2s(colpart)
+    if colpart.shape != (hie_chunks(N, L) * N, E):
+        raise _l.VqfError("hie: colpart must be (chunks * N, E)")
+    return _ptr(colpart), colpart.stride(0)
+
+
+def hie_rank_add(a, U, V, N, L, T, out, colpart=None):
+    """colpart: (S*N, E) rows (a column block of a wider buffer) receiving each workgroup's column sums of `out`"""
     _chk2s(a, V, out)
     _chk_ntl(U, N, T, L)
+    cp, ldcp = _colpart(colpart, N, L, a.shape[1])
     _l.check(_lib().vqf_hie_rank_add(_ptr(a), a.stride(0), _ptr(U), _ptr(V), V.stride(0), N, L, a.shape[1], T, _ptr(out),
-                                     out.stride(0), _stream()), "vqf_hie_rank_add")
+                                     out.stride(0), cp, ldcp, _stream()), "vqf_hie_rank_add")
     return out
 
 
-def hie_rank_left(U, V, z, N, L, T, out, part):
+def hie_rank_left(U, V, z, N, L, T, out, part, colpart=None):
     _chk2s(V, z, out)
     _chk_ntl(U, N, T, L)
+    cp, ldcp = _colpart(colpart, N, L, z.shape[1])
     _l.check(_lib().vqf_hie_rank_left(_ptr(U), _ptr(V), V.stride(0), _ptr(z), z.stride(0), N, L, z.shape[1], T, _ptr(out),
-                                      out.stride(0), _ptr(part), _part_ld(part, z.shape[1]), _stream()), "vqf_hie_rank_left")
+                                      out.stride(0), _ptr(part), _part_ld(part, z.shape[1]), cp, ldcp, _stream()),
+             "vqf_hie_rank_left")
     return out
 
 
