@@ -260,24 +260,29 @@ int launch(const GemmArgs& g, dim3 grid, hipStream_t s) {
   return vqf_last_error();
 }
 
-// y[r, c] = bf16(x[r, c]) for c < C, 0 for C <= c < ldy   (round-to-nearest-even, NaN kept)
+// y[r, c] = bf16(x[r, c]) for c < C, 0 for C <= c < ldy   (round-to-nearest-even, NaN kept).  One launch whatever R (round 4:
+// a workgroup per row with 8 columns per thread -- half of its threads idle at 1024 columns -- and one launch per 65535 rows)
 __global__ void cast_bf16_kernel(const float* __restrict__ x, int R, int C, int ldx,
                                  bf16_t* __restrict__ y, int ldy) {
-  const int c8 = (blockIdx.x * blockDim.x + threadIdx.x) * 8;
-  const int r = blockIdx.y;
-  if (c8 >= ldy) return;
-  const float* xr = x + (long long)r * ldx;
-  __bf16 o[8];
-  if (c8 + 7 < C && ((ldx & 3) == 0) && aligned16_dev(x)) {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(xr + c8);
-    const f32x4 b = *reinterpret_cast<const f32x4*>(xr + c8 + 4);
+  const unsigned W8 = (unsigned)ldy >> 3;
+  const unsigned long long total = (unsigned long long)R * W8, stride = (unsigned long long)gridDim.x * blockDim.x;
+  const bool vec = ((ldx & 3) == 0) && aligned16_dev(x);
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const unsigned r = (unsigned)(i / W8);
+    const int c8 = (int)(i - (unsigned long long)r * W8) * 8;
+    const float* xr = x + (long long)r * ldx;
+    __bf16 o[8];
+    if (c8 + 7 < C && vec) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(xr + c8);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(xr + c8 + 4);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { o[j] = (__bf16)a[j]; o[4 + j] = (__bf16)b[j]; }
-  } else {
+      for (int j = 0; j < 4; ++j) { o[j] = (__bf16)a[j]; o[4 + j] = (__bf16)b[j]; }
+    } else {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (c8 + j < C) ? (__bf16)xr[c8 + j] : (__bf16)0.0f;
+      for (int j = 0; j < 8; ++j) o[j] = (c8 + j < C) ? (__bf16)xr[c8 + j] : (__bf16)0.0f;
+    }
+    *reinterpret_cast<f32x4*>(y + (long long)r * ldy + c8) = *reinterpret_cast<const f32x4*>(o);
   }
-  *reinterpret_cast<f32x4*>(y + (long long)r * ldy + c8) = *reinterpret_cast<const f32x4*>(o);
 }
 
 }  // namespace
@@ -368,15 +373,11 @@ static int gemm_bf16_impl(int ta, int tb, int M, int N, int K, const void* A, in
 int vqf_cast_f32_bf16(const float* x, int R, int C, int ldx, void* y, int ldy, void* stream) {
   if (!x || !y || R <= 0 || C <= 0 || ldx < C || ldy < C) return VQF_E_BADARG;
   if ((ldy % 8) || !aligned16(y)) return VQF_E_ALIGN;
-  // large R: process in slabs of 65535 rows
-  for (long long r0 = 0; r0 < R; r0 += 65535) {
-    const int rr = (int)((R - r0 < 65535) ? (R - r0) : 65535);
-    dim3 gs((ldy / 8 + 255) / 256, rr);
-    VQF_LAUNCH(KID_CAST_BF16, cast_bf16_kernel, gs, dim3(256), 0, (hipStream_t)stream,
-               x + r0 * ldx, rr, C, ldx, (bf16_t*)y + r0 * ldy, ldy);
-    int rc = vqf_last_error();
-    if (rc) return rc;
-  }
+  const unsigned long long total = (unsigned long long)R * (unsigned)(ldy / 8);
+  unsigned long long blocks = (total + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  VQF_LAUNCH(KID_CAST_BF16, cast_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, R, C, ldx, (bf16_t*)y, ldy);
+  if (int rc = vqf_last_error()) return rc;
   return VQF_OK;
 }
 

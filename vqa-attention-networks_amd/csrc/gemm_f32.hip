@@ -622,7 +622,9 @@ static int gemm_tile128(int ta, int tb, int M, int N, int K, const float* A, int
   const int slots = 512;
   // (a chip-filling output with a short K is not split either: 5000 x 2048 x 512, 640 tiles -- two slices + the 123 MB slab
   //  reduce 130 us, unsplit 110, tools/gemm_m512_probe.py)
-  if (ws && tiles < 1024 && ktiles >= 32 && !(tiles >= 512 && K <= 1024)) {
+  // (nor a product that fills most of the CUs once with K <= 512: 3584 x 1024 x 512, 224 tiles -- two slices + reduce 59-61 us,
+  //  unsplit 52-53, tools/small_gemm_splitk_ab.py)
+  if (ws && tiles < 1024 && ktiles >= 32 && !(tiles >= 512 && K <= 1024) && !(tiles >= 192 && tiles <= 256 && K <= 512)) {
     double best = 1e30;
     for (int sp = 1; sp <= 16; ++sp) {
       if (ktiles / sp < 16) break;

@@ -220,7 +220,8 @@ class AttHeadFn(torch.autograd.Function):
                 hid1 = ops.gemm_rowscale(x, _w2d(w1), link.inv, link.L, bias=b1, relu=True)
             logits, lin = ops.att_logits_fwd_lin(hid1, _w2d(w2), b2, b1)
             wts, pooled = ops.glimpse_pool_fwd(feat, logits, unit_softmax)
-            ctx.save_for_backward(x, feat, w1, None, w2, hid1, None, wts, lin)
+            # (bf16 mode: slot 3 -- no "multilayer" conv with a NormLink -- carries the bf16 copy of w1 to the backward: one cast per step)
+            ctx.save_for_backward(x, feat, w1, w1b if ctx.bf16 else None, w2, hid1, None, wts, lin)
             ctx.unit = bool(unit_softmax)
             return pooled
         # (the bf16 GEMM entry point wants K and every K-major operand's row extent to be multiples of 8: here the hidden
@@ -237,7 +238,7 @@ class AttHeadFn(torch.autograd.Function):
         last = hid2 if hid2 is not None else hid1
         logits = ops.att_logits_fwd(last, _w2d(w2), b2)
         wts, pooled = ops.glimpse_pool_fwd(feat, logits, unit_softmax)
-        ctx.save_for_backward(x, feat, w1, wm, w2, hid1, hid2, wts, None)
+        ctx.save_for_backward(x, feat, w1, wm, w2, hid1, hid2, wts, w1b if ctx.bf16 else None)      # (last slot: the bf16 copy of w1)
         ctx.unit = bool(unit_softmax)
         return pooled
 
@@ -249,6 +250,7 @@ class AttHeadFn(torch.autograd.Function):
         dlogits, dfeat = ops.glimpse_pool_bwd(dpooled, feat, wts, ctx.unit, need_dfeat)
         if ctx.link is not None:
             link = ctx.link
+            w1b = wm                                       # (slot 3, see forward)
             d1s, dw2, db2, db1 = ops.att_logits_bwd(dlogits, hid1, _w2d(w2), relu_mask=True, rowscale=link.inv,
                                                     rows_per_scale=link.L)          # stored rows already times 1/norm
             link.lin = (dlogits, lin)                                               # -> sum(Y * dY) in the producer's backward
@@ -256,7 +258,7 @@ class AttHeadFn(torch.autograd.Function):
                 cin = _w2d(w1).shape[1]
                 d1b = ops.cast_bf16(d1s)
                 dw1 = ops.gemm_bf16(d1b, x, ta=True, tb=True)[:, :cin].contiguous().view_as(w1)
-                dx = ops.gemm_bf16(d1b, ops.cast_bf16(_w2d(w1), 32), tb=True, N=cin) if ctx.needs_input_grad[0] else None
+                dx = ops.gemm_bf16(d1b, w1b, tb=True, N=cin) if ctx.needs_input_grad[0] else None
                 return dx, dfeat, dw1, db1, None, None, dw2.view_as(w2), db2, None, None, None, None
             dw1 = ops.gemm(d1s, x, ta=True, tb=True).view_as(w1)                    # = dpre^T Y
             dx = ops.gemm(d1s, _w2d(w1), tb=True) if ctx.needs_input_grad[0] else None   # dYs = dY / norm
@@ -277,8 +279,7 @@ class AttHeadFn(torch.autograd.Function):
             dw1 = ops.gemm_bf16(d1b, x, ta=True, tb=True)[:, :cin].contiguous().view_as(w1)
             dx = None
             if ctx.needs_input_grad[0]:
-                w1b = ops.cast_bf16(_w2d(w1), 32)
-                dx = ops.gemm_bf16(d1b, w1b, tb=True, N=cin)
+                dx = ops.gemm_bf16(d1b, lin, tb=True, N=cin)                  # lin: slot 8 = w1's bf16 copy in this form
         else:
             dw1 = ops.gemm(d1_pre, x, ta=True, tb=True).view_as(w1)
             if ctx.same_src and dfeat is not None:
