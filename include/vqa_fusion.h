@@ -96,7 +96,9 @@ const char* vqf_build_info(void);
 #define VQF_OPT_GEMM_F32_SAMPLE 16    /* 0 = vqf_gemm_f32_sample reports every shape unsupported, i.e. HieCoAtten's per-sample products run on the
                                         256x256 / 128x128 kernels as in round 4 (A/B); 2 = it takes every shape it can run, also batches whose
                                         NS * N / 256 work items fill less than half of the CUs (default: those stay on vqf_gemm_f32) */
-#define VQF_OPT_COUNT 17
+#define VQF_OPT_GEMM_F32_N80 17       /* 0 = never use the one-round 128x80-tile kernel (csrc/gemm_f32_n80.hip) for the M = 512 forward
+                                        projections: they run on the 128x128 kernel with split-K + slab reduce, as before round 5 (A/B) */
+#define VQF_OPT_COUNT 18
 int vqf_set_option(int option, int value, int* previous);
 int vqf_get_option(int option, int* value);
 /* the environment variable read for `option` at load time: "VQF_" + the name of its VQF_OPT_* constant ("" if unknown) */
@@ -111,7 +113,8 @@ const char* vqf_option_env_name(int option);
 #define VQF_STAT_GEMM_BF16_TILE128 3 /* csrc/gemm_bf16.hip                                         */
 #define VQF_STAT_GEMM_BF16_BIG 4     /* csrc/gemm_bf16_big.hip                                     */
 #define VQF_STAT_GEMM_F32_SAMPLE 5   /* csrc/gemm_f32_sample.hip, one sample's rows x 256 columns per workgroup */
-#define VQF_STAT_COUNT 6
+#define VQF_STAT_GEMM_F32_N80 6      /* csrc/gemm_f32_n80.hip, 128 x 80 tiles, one round, no split-K */
+#define VQF_STAT_COUNT 7
 int vqf_stat_get(int stat, long long* value);
 
 /* --------------------------------------------------------------------------
@@ -130,6 +133,12 @@ int vqf_stat_get(int stat, long long* value);
  * `ws`/`ws_bytes`: optional split-K scratch (may be NULL/0: no split).
  * Vector (16-byte) loads are used when pointers and leading dimensions allow
  * it; any shape/alignment is accepted.
+ * Routing (all deterministic; which kernel ran: vqf_stat_get): the 256x256-tile LDS-DMA kernel for large shapes
+ * (vqf_gemm_f32_big_rows), the per-wave-tile kernel for the recurrent small-M products, the one-round 128x80-tile kernel
+ * (csrc/gemm_f32_n80.hip, round 5) for forward products whose 128x80 tiles fill 80..100 % of the CUs once -- M <= 1024,
+ * K % 128 == 0, K >= 512, no VQF_GEMM_ACCUM: the 512 x 5000 projections of mfb.py:76,92,126,127 at batch 512, with or
+ * without `ws` -- and the 128x128-tile kernel (split-K over `ws` + slab reduce) for everything else.  The 128x80 kernel adds
+ * k in a different order (v_mfma_f32_16x16x4_f32) than the others: same value to fp32 rounding, not the same bits.
  */
 /* Scratch vqf_gemm_f32 can use for this shape (deterministic split-K slabs); with less it picks fewer
  * splits.  Never more than 16 * M * N * 4 bytes. */

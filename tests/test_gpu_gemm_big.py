@@ -493,3 +493,39 @@ def test_per_sample_tile_gemm_vs_fp64_and_the_other_kernels(NS, L, N, K, tb):
     assert ops.stat("gemm_f32_sample") == n0 + 2
     ops.gemm_rows(A, Bm, L, tb=tb, bias=bias)                                    # default: only where the items fill half the chip
     assert ops.stat("gemm_f32_sample") == n0 + 2 + (1 if NS * (N // 256) >= 128 else 0)
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 5000, 2048), (512, 5000, 1024), (500, 5000, 512), (384, 6000, 640), (1024, 2500, 512),
+                                   (512, 4970, 4096)])
+def test_one_round_128x80_gemm_vs_fp64_and_the_128x128_kernel(M, N, K):
+    """vqf_gemm_f32's one-round path for the M = 512 forward projections (csrc/gemm_f32_n80.hip: 128 x 80 tiles on
+    v_mfma_f32_16x16x4_f32, one workgroup per CU, no K slices; mfb.py:76,92,126,127 at batch 512): bias, ReLU, row-strided operands
+    and output, ragged M and N edges -- against fp64 (2e-6 * max(1, sqrt(K) / 8), norm-relative, and the last tile's rows and
+    columns on their own) and against the 128x128 kernel it replaces (option gemm_f32_n80 = 0)."""
+    import vqa_amd
+    ops = vqa_amd.ops
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn((M, K + 4), generator=g).cuda()[:, :K]                       # row stride K + 4
+    Bm = (torch.randn((N, K + 8), generator=g) * 0.05).cuda()[:, :K]
+    bias = torch.randn(N, generator=g).cuda()
+    ref0 = A.double() @ Bm.double().t() + bias.double()
+    tol = 2e-6 * max(1.0, K ** 0.5 / 8)
+    n0 = ops.stat("gemm_f32_n80")
+    for relu in (False, True):
+        outbuf = torch.full((M + 1, N + 4), 7.0, device="cuda")                  # strided output, canary row and columns
+        C = ops.gemm(A, Bm, bias=bias, relu=relu, out=outbuf[:M, :N])
+        ref = torch.relu(ref0) if relu else ref0
+        assert float((C.double() - ref).norm() / ref.norm()) <= tol
+        er, ec = (M - 1) // 128 * 128, (N - 1) // 80 * 80                        # the edge tiles
+        assert float((C[er:].double() - ref[er:]).norm() / ref[er:].norm()) <= tol
+        assert float((C[:, ec:].double() - ref[:, ec:]).norm() / ref[:, ec:].norm()) <= tol
+        assert float((outbuf[:, N:] - 7.0).abs().max()) == 0.0 and float((outbuf[M:] - 7.0).abs().max()) == 0.0
+        with ops.options(gemm_f32_n80=0):
+            C2 = ops.gemm(A, Bm, bias=bias, relu=relu)
+        assert float((C.double() - C2.double()).norm() / ref.norm()) <= 2 * tol
+        assert torch.equal(C, ops.gemm(A, Bm, bias=bias, relu=relu, splitk=False))       # the same kernel whatever the caller's split-K wish: same bits
+    assert ops.stat("gemm_f32_n80") == n0 + 4                                    # (not the option-0 launches)
+    # not its shapes: a K that is not a multiple of 128, too few or too many tiles for one round
+    for m, n, k in [(512, 5000, 1000), (128, 2000, 1024), (512, 8000, 1024)]:
+        ops.gemm(torch.randn((m, k), device="cuda"), torch.randn((n, k), device="cuda"))
+    assert ops.stat("gemm_f32_n80") == n0 + 4

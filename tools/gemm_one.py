@@ -1,5 +1,5 @@
 """A few launches of ONE hot GEMM on live random operands, for rocprofv3 --pmc passes.
-    python tools/gemm_one.py --dtype f32|bf16 --shape fwd|wgrad|hie_fwd|hie_wgrad|coatt_fwd [--out-bf16]"""
+    python tools/gemm_one.py --dtype f32|bf16 --shape fwd|wgrad|hie_fwd|hie_dgrad|hie_wgrad|coatt_fwd|m512 [--out-bf16]"""
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, vqa_amd
@@ -23,6 +23,11 @@ elif args.shape == "hie_fwd":  # HieCoAtten img_emb (hieCoAtten.py:25), B = 256:
     B = (torch.randn((512, 2048), generator=g) * 0.03).cuda()
     ta = tb = False
     bias = torch.zeros(512, device="cuda")
+elif args.shape == "m512":     # the M = 512 forward projections (mfb.py:126,127): one round of 128x80 tiles (csrc/gemm_f32_n80.hip)
+    A = torch.randn((512, 2048), generator=g).cuda()
+    B = (torch.randn((5000, 2048), generator=g) * 0.03).cuda()
+    ta = tb = False
+    bias = torch.zeros(5000, device="cuda")
 elif args.shape == "hie_dgrad":  # d img = [dCv | dimg_] [Wbv; Wv]  (input gradient of hieCoAtten.py:30,35), B = 256, per-sample tiles
     A = torch.randn((256 * 196, 1024), generator=g).cuda()
     B = (torch.randn((1024, 512), generator=g) * 0.03).cuda()

@@ -8,6 +8,7 @@
 #   part "hbm":   the HBM-bound kernels at the headline shapes
 #   part "trace": kernel trace + stats of the default bench command (headline + secondary configs)
 #   part "c4":    the per-sample-tile GEMM launches of config 4
+#   part "n80":   the one-round 128x80-tile kernel on the 512 x 5000 x 2048 projection
 set -u
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -39,6 +40,7 @@ for part in "$@"; do
            pmc bf16_wgrad $R/tools/gemm_one.py --dtype bf16 --shape wgrad ;;
     hie)   pmc hie $R/tools/hie_kernels_one.py ;;
     hbm)   pmc hbm $R/tools/hbm_kernels_one.py ;;
+    n80)   pmc m512 $R/tools/gemm_one.py --dtype f32 --shape m512 --reps 10 ;;
     c4)    pmc hie_fwd $R/tools/gemm_one.py --dtype f32 --shape hie_fwd
            pmc hie_dgrad $R/tools/gemm_one.py --dtype f32 --shape hie_dgrad ;;
     trace) timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o r05 -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --secondary-steps 5 --secondary-warmup 2 > $O/trace.log 2>&1 || echo "trace failed" ;;

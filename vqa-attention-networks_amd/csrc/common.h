@@ -99,6 +99,9 @@ int vqf_gemm_f32_big_try(int ta, int tb, int M, int N, int K, const float* A, in
                          hipStream_t s, int* rc, int* rows_done);
 int vqf_gemm_f32_big_rows_impl(int ta, int tb, int M, int N, int K, int flags, size_t ws_bytes);
 size_t vqf_gemm_f32_big_ws_bytes(int ta, int tb, int M, int N, int K);
+// gemm_f32_n80.hip: one-round 128x80 tiles for the M = 512 forward projections (ta == tb == 0); returns 0 when it does not apply
+int vqf_gemm_f32_n80_try(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                         const float* bias, int flags, hipStream_t s, int* rc);
 // gemm_f32_wave.hip: small-M products, one 32x64 tile per wave, no split-K slabs; returns 0 when it does not apply
 int vqf_gemm_f32_wave_try(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
                           int ldc, const float* bias, int flags, hipStream_t s, int* rc);

@@ -565,7 +565,8 @@ extern "C" int vqf_gemm_f32(int ta, int tb, int M, int N, int K, const float* A,
     return VQF_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
   if (aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0)) {
-    int rc = VQF_OK, done = 0;   // large shapes take the 256x256-tile LDS-DMA kernel (gemm_f32_big.hip) ...
+    int rc = VQF_OK, done = 0;
+    // large shapes take the 256x256-tile LDS-DMA kernel (gemm_f32_big.hip) ...
     if (vqf_gemm_f32_big_try(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, nullptr, 1, ws, ws_bytes, s, &rc, &done)) {
       if (rc != VQF_OK || done >= M) return rc;
       // ... mid-size ones its whole-rounds row block only (ta == 0 there): the remaining rows follow below
@@ -575,6 +576,8 @@ extern "C" int vqf_gemm_f32(int ta, int tb, int M, int N, int K, const float* A,
     }
     // small-M products (the LSTM's recurrent GEMMs): one tile per wave, no split-K slabs / reduce launch (gemm_f32_wave.hip)
     else if (vqf_gemm_f32_wave_try(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, s, &rc)) return rc;
+    // the M = 512 forward projections: one round of 128x80 tiles, no K slices (gemm_f32_n80.hip)
+    else if (!ta && !tb && vqf_gemm_f32_n80_try(M, N, K, A, lda, B, ldb, C, ldc, bias, flags, s, &rc)) return rc;
   }
   return gemm_tile128(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, nullptr, 1, 0, ws, ws_bytes, s);
 }

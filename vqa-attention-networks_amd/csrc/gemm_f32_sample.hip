@@ -26,8 +26,8 @@ namespace {
 typedef const float __attribute__((address_space(1))) gfloat;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int TK = 16, NT = 512, TN = 256, RA = 256;     // RA: A rows staged per slab (a sample's L <= 200 rows + the next sample's first ones, unused)
-constexpr int ROW_B = TK * 4, CH = ROW_B / 16;           // K-contiguous image: 64-byte rows, 4 chunks of 16 bytes
+constexpr int TK = 16, NT = 512, TN = 256;               // (256 A rows are staged per slab: a sample's L <= 200 + the next sample's first ones, unused)
+constexpr int ROW_B = TK * 4;                            // K-contiguous image: 64-byte rows, 4 chunks of 16 bytes
 constexpr int OP_BYTES = 256 * ROW_B;                    // 16 KB per operand per slab (either layout)
 constexpr int SLOT_BYTES = 2 * OP_BYTES, NSLOT = 5, SMEM = NSLOT * SLOT_BYTES;
 constexpr int NG = OP_BYTES / (NT * 16);                 // 2 LDS-DMA instructions per thread per operand per slab

@@ -14,7 +14,7 @@ namespace {
 const char* const kOptEnv[VQF_OPT_COUNT] = {
     "VQF_GEMM_F32_PERSIST", "VQF_GEMM_BF16_PERSIST", "VQF_GEMM_F32_LOOP", "VQF_GEMM_BF16_LOOP", "VQF_GEMM_F32_BIG",
     "VQF_GEMM_BF16_BIG", "VQF_GEMM_F32_WAVE", "VQF_FUSE_COAL", "VQF_FUSE_LS", "VQF_FUSE_LS_BWD", "VQF_GEMM_CU_LIMIT",
-    "VQF_GEMM_F32_EDGE", "VQF_GEMM_F32_ROUNDS", "VQF_GEMM_SPLITK_FUSED", "VQF_GEMM_F32_STREAMK", "VQF_GEMM_SPLITK_ORDER", "VQF_GEMM_F32_SAMPLE"};
+    "VQF_GEMM_F32_EDGE", "VQF_GEMM_F32_ROUNDS", "VQF_GEMM_SPLITK_FUSED", "VQF_GEMM_F32_STREAMK", "VQF_GEMM_SPLITK_ORDER", "VQF_GEMM_F32_SAMPLE", "VQF_GEMM_F32_N80"};
 const char* const kOptEnvOld[VQF_OPT_COUNT] = {
     nullptr, nullptr, "VQF_GEMM_F32_PP", "VQF_GEMM_BF16_PP", nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
     nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};

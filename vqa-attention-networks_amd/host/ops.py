@@ -69,7 +69,7 @@ def workspace(device, nbytes):
 OPTIONS = {"gemm_f32_persist": 0, "gemm_bf16_persist": 1, "gemm_f32_loop": 2, "gemm_bf16_loop": 3, "gemm_f32_big": 4,
            "gemm_bf16_big": 5, "gemm_f32_wave": 6, "fuse_coal": 7, "fuse_ls": 8, "fuse_ls_bwd": 9, "gemm_cu_limit": 10,
            "gemm_f32_edge": 11, "gemm_f32_rounds": 12, "gemm_splitk_fused": 13, "gemm_f32_streamk": 14,
-           "gemm_splitk_order": 15, "gemm_f32_sample": 16}
+           "gemm_splitk_order": 15, "gemm_f32_sample": 16, "gemm_f32_n80": 17}
 
 
 def set_option(name, value):
@@ -87,7 +87,7 @@ def get_option(name):
 
 
 STATS = {"gemm_f32_tile128": 0, "gemm_f32_big": 1, "gemm_f32_wave": 2, "gemm_bf16_tile128": 3, "gemm_bf16_big": 4,
-         "gemm_f32_sample": 5}
+         "gemm_f32_sample": 5, "gemm_f32_n80": 6}
 
 
 def stat(name):
