@@ -29,7 +29,10 @@ ALG = {   # bytes one launch must move at the shapes of tools/hbm_kernels_one.py
 HROWS, HE = 256 * 196, 512
 for _m in range(4):
     ALG["hie_stream_kernel<%d>" % _m] = 4.0 * 2 * HROWS * HE
-BENCH_NAME = {"hie_stream_kernel<0>": "hie_hv_fwd", "hie_stream_kernel<1>": "hie_head_bwd", "hie_stream_kernel<2>": "hie_rank_add",
+# round 5: the affinity products (vqf_hie_affinity): one pass over one (epi 1, forward) or two (epi 2, gradient) (N*L, E) tensors
+ALG["hie_affinity_kernel<1>"] = 4.0 * HROWS * HE
+ALG["hie_affinity_kernel<2>"] = 4.0 * 2 * HROWS * HE
+BENCH_NAME = {"hie_affinity_kernel<1>": "hie_affinity", "hie_affinity_kernel<2>": "hie_affinity", "hie_stream_kernel<0>": "hie_hv_fwd", "hie_stream_kernel<1>": "hie_head_bwd", "hie_stream_kernel<2>": "hie_rank_add",
               "hie_stream_kernel<3>": "hie_rank_left","mfb_fuse_fwd_kernel": "mfb_fuse_fwd", "mfb_fuse_bwd_kernel": "mfb_fuse_bwd", "scale_rows_kernel": "scale_rows",
               "rowdot_kernel": "rowdot", "glimpse_pool_fwd_kernel": "glimpse_pool_fwd", "glimpse_pool_bwd_kernel": "glimpse_pool_bwd",
               "att_logits_fwd_kernel": "att_logits_fwd", "att_logits_bwd_kernel": "att_logits_bwd"}
@@ -41,6 +44,9 @@ def short(name):
     m = re.match(r"hie_stream_kernel<(\d)", name)           # hie_stream_kernel<MODE[, TMAX]>
     if m:
         return "hie_stream_kernel<%s>" % m.group(1)
+    m = re.match(r"hie_affinity_kernel<(\d)", name)
+    if m:
+        return "hie_affinity_kernel<%s>" % m.group(1)
     m = re.match(r"([A-Za-z0-9_]+)", name)
     return m.group(1) if m else name
 

@@ -130,8 +130,14 @@ __global__ void __launch_bounds__(NT, 1) gemm_f32_n80_kernel(const N80Args g) {
       for (int t = 0; t < 5; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.a[u][j], cur.b[t][u][j], acc[t], 0, 0, 0);
       // (giving the two waves of a SIMD opposite halves of the slab for their copies and reads -- so that they do not stand in a
       //  piece's issue cycles together -- measured SLOWER: 108 vs 90 us)
+      // (-DVQF_N80_NOCOPY / -DVQF_N80_NOREAD: diagnostic builds that leave the copies / the fragment reads out of the loop -- wrong
+      //  results, the timing says what each costs; tools/build_variant.sh)
+#ifndef VQF_N80_NOCOPY
       if (grp < 4) { if (copy) issue_piece(s + NSLOT, q, grp); }
+#endif
+#ifndef VQF_N80_NOREAD
       if (more && grp < 6) { read_frag((q + 1) % NSLOT, nxt, 2 * grp); read_frag((q + 1) % NSLOT, nxt, 2 * grp + 1); }
+#endif
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -149,7 +155,9 @@ __global__ void __launch_bounds__(NT, 1) gemm_f32_n80_kernel(const N80Args g) {
       const int s = s0 + q;
       if (s + 1 < S) wait_own(min(NSLOT - 2, S - 2 - s), two);     // my copies of slab s+1 have landed
       __builtin_amdgcn_s_waitcnt(0xC07F);                  // lgkmcnt(0): my fragment reads of slab s have returned
+#ifndef VQF_N80_NOBARRIER
       __builtin_amdgcn_s_barrier();                        // slab s+1 is visible; nobody reads slab s from LDS any more
+#endif
       step(s, q, fr[q & 1], fr[(q + 1) & 1]);
     }
   }
