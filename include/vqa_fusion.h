@@ -265,6 +265,12 @@ int vqf_att_logits_bwd(const float* dlogits, const float* hid, const float* w2,
 int vqf_att_logits_bwd_rowscale(const float* dlogits, const float* hid, const float* w2, const float* rowscale,
                                 int rows_per_scale, int M, int Hh, int G, int relu_mask, float* dhid_pre, float* dw2,
                                 float* db2, float* dbias1, void* ws, size_t ws_bytes, void* stream);
+/* The same with the stored rows in bf16 (round-to-nearest-even; dhid_pre_bf16: (M, Hh) bf16, 8-byte aligned, Hh % 4 == 0),
+ * through the ReLU, G = 2: the A operand of the layer's bf16 weight- and input-gradient products (BASELINE config 3,
+ * mhb_coAtt.py:97-98 co_att_conv1) without the fp32 round trip + vqf_cast_f32_bf16 launch (ABI 7).  Sums stay fp32. */
+int vqf_att_logits_bwd_rowscale_obf16(const float* dlogits, const float* hid, const float* w2, const float* rowscale,
+                                      int rows_per_scale, int M, int Hh, int G, void* dhid_pre_bf16, float* dw2, float* db2,
+                                      float* dbias1, void* ws, size_t ws_bytes, void* stream);
 
 /* wts[n,g,:] = softmax_s(logits[n,:,g])   (unit_softmax != 0: wts == 1, the
  * mfb.py:84,118 singleton-axis softmax);  pooled[n, g*C + c] = sum_s wts[n,g,s] feat[n,s,c].

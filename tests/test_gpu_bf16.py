@@ -50,6 +50,24 @@ def test_gemm_bf16_all_layouts(ops, ta, tb, M, N, K):
     assert _rel(out2, torch.relu(ref)) <= 2e-5 * max(1.0, np.sqrt(K) / 16)
 
 
+def test_att_logits_bwd_bf16_rows_are_the_cast_of_the_fp32_rows(ops):
+    """vqf_att_logits_bwd_rowscale_obf16 (config 3: co_att_conv1's gradient rows stored as bf16 by the kernel that makes them):
+    bit-identical to vqf_cast_f32_bf16 of the fp32 form's rows, every fp32 sum identical; ragged last row block."""
+    g = torch.Generator().manual_seed(5)
+    M, Hh, L = 7 * 196 + 3, 512, 196
+    hid = torch.relu(torch.randn((M, Hh), generator=g)).cuda()
+    dl = torch.randn((M, 2), generator=g).cuda()
+    w2 = torch.randn((2, Hh), generator=g).cuda()
+    inv = (torch.rand((M + L - 1) // L, generator=g) + 0.5).cuda()
+    f32 = ops.att_logits_bwd(dl, hid, w2, relu_mask=True, rowscale=inv, rows_per_scale=L)
+    b16 = ops.att_logits_bwd(dl, hid, w2, relu_mask=True, rowscale=inv, rows_per_scale=L, out_bf16=True)
+    assert b16[0].dtype == torch.bfloat16 and torch.equal(b16[0].view(torch.int16), ops.cast_bf16(f32[0]).view(torch.int16))
+    for a, b in zip(f32[1:], b16[1:]):
+        assert torch.equal(a, b)
+    with pytest.raises(Exception):
+        ops.att_logits_bwd(dl, hid, w2, relu_mask=False, out_bf16=True)
+
+
 def test_gemm_bf16_padded_k_and_vs_fp32(ops):
     """K = 1000 padded to 1024 by the cast (the co_att_conv1 shape); error vs un-rounded fp32 inputs."""
     M, N, K = 392, 512, 1000

@@ -97,7 +97,10 @@ inline int att_bwd_rows_per_block(int M) {            // a multiple of the kerne
 
 // rowscale != nullptr: the STORED dhid_pre rows are multiplied by rowscale[row / rps] (the per-sample 1/norm of the layer's
 // un-normalised input: its weight gradient and dgrad GEMMs then need no scaling); the bias partial sums stay unscaled.
-template <int G, bool RELU>
+// OBF16: the stored rows are bf16 (round-to-nearest-even), `dhid_pre` points to (M, Hh) bf16 storage -- the A operand of the
+// layer's bf16 weight-gradient / input-gradient GEMMs (BASELINE config 3) without an fp32 round trip and a cast launch; the
+// partial sums stay fp32 and are those of the fp32 values (Hh % 4 == 0, 8-byte aligned).
+template <int G, bool RELU, bool OBF16 = false>
 __global__ void att_logits_bwd_kernel(const float* __restrict__ dl, const float* __restrict__ hid,
                                       const float* __restrict__ w2, int M, int Hh,
                                       float* __restrict__ dhid_pre, float* __restrict__ part,
@@ -148,6 +151,13 @@ __global__ void att_logits_bwd_kernel(const float* __restrict__ dl, const float*
           for (int g = 0; g < G; ++g) { t += d[q][g] * u[g][j]; s[g][j] += d[q][g] * x[q][j]; }
           gp[j] = (!RELU || x[q][j] > 0.f) ? t : 0.f;
           sb[j] += gp[j];
+        }
+        if (OBF16) {
+          __bf16 ob[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) ob[j] = (__bf16)(gp[j] * rs[q]);
+          *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(dhid_pre) + (long long)r * Hh + c) = *reinterpret_cast<const uint2*>(ob);
+          continue;
         }
         float* o = dhid_pre + (long long)r * Hh + c;
         if (vec) {
@@ -411,9 +421,29 @@ int vqf_att_logits_bwd(const float* dlogits, const float* hid, const float* w2, 
                                      ws_bytes, stream);
 }
 
+static int att_logits_bwd_impl(const float* dlogits, const float* hid, const float* w2, const float* rowscale,
+                               int rows_per_scale, int M, int Hh, int G, int relu_mask, float* dhid_pre, int out_bf16, float* dw2,
+                               float* db2, float* dbias1, void* ws, size_t ws_bytes, void* stream);
+
 int vqf_att_logits_bwd_rowscale(const float* dlogits, const float* hid, const float* w2, const float* rowscale,
                                 int rows_per_scale, int M, int Hh, int G, int relu_mask, float* dhid_pre, float* dw2,
                                 float* db2, float* dbias1, void* ws, size_t ws_bytes, void* stream) {
+  return att_logits_bwd_impl(dlogits, hid, w2, rowscale, rows_per_scale, M, Hh, G, relu_mask, dhid_pre, 0, dw2, db2, dbias1, ws,
+                             ws_bytes, stream);
+}
+
+int vqf_att_logits_bwd_rowscale_obf16(const float* dlogits, const float* hid, const float* w2, const float* rowscale,
+                                      int rows_per_scale, int M, int Hh, int G, void* dhid_pre_bf16, float* dw2, float* db2,
+                                      float* dbias1, void* ws, size_t ws_bytes, void* stream) {
+  if (G != 2 || (Hh % 4)) return VQF_E_UNSUPPORTED;
+  if (((uintptr_t)dhid_pre_bf16) & 7) return VQF_E_ALIGN;
+  return att_logits_bwd_impl(dlogits, hid, w2, rowscale, rows_per_scale, M, Hh, G, 1, (float*)dhid_pre_bf16, 1, dw2, db2, dbias1,
+                             ws, ws_bytes, stream);
+}
+
+static int att_logits_bwd_impl(const float* dlogits, const float* hid, const float* w2, const float* rowscale,
+                               int rows_per_scale, int M, int Hh, int G, int relu_mask, float* dhid_pre, int out_bf16, float* dw2,
+                               float* db2, float* dbias1, void* ws, size_t ws_bytes, void* stream) {
   if (!dlogits || !hid || !w2 || !dhid_pre || !dw2 || !db2 || M <= 0 || Hh <= 0 || rows_per_scale <= 0)
     return VQF_E_BADARG;
   if (G != 1 && G != 2) return VQF_E_UNSUPPORTED;
@@ -427,8 +457,10 @@ int vqf_att_logits_bwd_rowscale(const float* dlogits, const float* hid, const fl
 #define VQF_LB(G_, R_)                                                                           \
   VQF_LAUNCH(KID_ATT_LOGITS_BWD, (att_logits_bwd_kernel<G_, R_>), dim3(nb), dim3(256), 0, s,     \
              dlogits, hid, w2, M, Hh, dhid_pre, part, rowscale, rows_per_scale, lb)
-  if (G == 2) { if (relu_mask) VQF_LB(2, true); else VQF_LB(2, false); }
-  else        { if (relu_mask) VQF_LB(1, true); else VQF_LB(1, false); }
+  if (out_bf16)    VQF_LAUNCH(KID_ATT_LOGITS_BWD, (att_logits_bwd_kernel<2, true, true>), dim3(nb), dim3(256), 0, s, dlogits, hid, w2, M,
+                              Hh, dhid_pre, part, rowscale, rows_per_scale, lb);
+  else if (G == 2) { if (relu_mask) VQF_LB(2, true); else VQF_LB(2, false); }
+  else             { if (relu_mask) VQF_LB(1, true); else VQF_LB(1, false); }
 #undef VQF_LB
   int rc = vqf_last_error();
   if (rc) return rc;

@@ -251,12 +251,13 @@ class AttHeadFn(torch.autograd.Function):
         if ctx.link is not None:
             link = ctx.link
             w1b = wm                                       # (slot 3, see forward)
+            obf = ctx.bf16 and hid1.shape[1] % 8 == 0 and w2.shape[0] == 2          # the kernel stores bf16 rows itself: no cast launch
             d1s, dw2, db2, db1 = ops.att_logits_bwd(dlogits, hid1, _w2d(w2), relu_mask=True, rowscale=link.inv,
-                                                    rows_per_scale=link.L)          # stored rows already times 1/norm
+                                                    rows_per_scale=link.L, out_bf16=obf)   # stored rows already times 1/norm
             link.lin = (dlogits, lin)                                               # -> sum(Y * dY) in the producer's backward
             if ctx.bf16:
                 cin = _w2d(w1).shape[1]
-                d1b = ops.cast_bf16(d1s)
+                d1b = d1s if obf else ops.cast_bf16(d1s)
                 dw1 = ops.gemm_bf16(d1b, x, ta=True, tb=True)[:, :cin].contiguous().view_as(w1)
                 dx = ops.gemm_bf16(d1b, w1b, tb=True, N=cin) if ctx.needs_input_grad[0] else None
                 return dx, dfeat, dw1, db1, None, None, dw2.view_as(w2), db2, None, None, None, None

@@ -57,6 +57,7 @@ SIGNATURES = {
     "vqf_att_logits_fwd_lin": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_p]),
     "vqf_att_logits_bwd_ws_bytes": (c_sz, [c_i, c_i]),
     "vqf_att_logits_bwd_rowscale": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_p, c_sz, c_p]),
+    "vqf_att_logits_bwd_rowscale_obf16": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_p, c_f, c_f, c_f, c_p, c_sz, c_p]),
     "vqf_att_logits_bwd": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_p, c_sz, c_p]),
     "vqf_glimpse_pool_fwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_p]),
     "vqf_glimpse_pool_bwd": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_p]),

@@ -336,16 +336,25 @@ def att_logits_fwd_lin(hid, w2, b2, b1):
     return out, lin
 
 
-def att_logits_bwd(dlogits, hid, w2, relu_mask=True, rowscale=None, rows_per_scale=1):
-    """rowscale (per row group of rows_per_scale rows): the stored dhid_pre is scaled by it, the bias sums are not."""
+def att_logits_bwd(dlogits, hid, w2, relu_mask=True, rowscale=None, rows_per_scale=1, out_bf16=False):
+    """rowscale (per row group of rows_per_scale rows): the stored dhid_pre is scaled by it, the bias sums are not.
+    out_bf16 (two glimpses, through the ReLU, Hh % 8 == 0): dhid_pre is stored as bf16 (the operand of the bf16 gradient GEMMs)."""
     _chk(dlogits, hid, w2, rowscale)
     M, Hh = hid.shape
     G = w2.shape[0]
-    dpre = torch.empty_like(hid)
     dw2 = torch.empty((G, Hh), dtype=torch.float32, device=hid.device)
     db2 = torch.empty(G, dtype=torch.float32, device=hid.device)
     db1 = torch.empty(Hh, dtype=torch.float32, device=hid.device)
     ws = workspace(hid.device, _lib().vqf_att_logits_bwd_ws_bytes(M, Hh))
+    if out_bf16:
+        if not relu_mask or G != 2 or Hh % 8:
+            raise _l.VqfError("att_logits_bwd: bf16 output needs the two-glimpse head through its ReLU and Hh % 8 == 0")
+        dpre = torch.empty((M, Hh), dtype=torch.bfloat16, device=hid.device)
+        _l.check(_lib().vqf_att_logits_bwd_rowscale_obf16(_ptr(dlogits), _ptr(hid), _ptr(w2), _ptr(rowscale), int(rows_per_scale),
+                                                          M, Hh, G, ctypes.c_void_p(dpre.data_ptr()), _ptr(dw2), _ptr(db2), _ptr(db1),
+                                                          _ptr(ws), ws.numel(), _stream()), "vqf_att_logits_bwd_rowscale_obf16")
+        return dpre, dw2, db2, db1
+    dpre = torch.empty_like(hid)
     _l.check(_lib().vqf_att_logits_bwd_rowscale(_ptr(dlogits), _ptr(hid), _ptr(w2), _ptr(rowscale), int(rows_per_scale),
                                                 M, Hh, G, int(bool(relu_mask)), _ptr(dpre), _ptr(dw2), _ptr(db2), _ptr(db1),
                                                 _ptr(ws), ws.numel(), _stream()), "vqf_att_logits_bwd")
