@@ -369,6 +369,11 @@ int vqf_mfb_fuse_bwd_bf16dp(const float* dY, const float* Y, const float* inv, c
  * VQF_GEMM_OUT_BF16: half the bytes of the largest tensor of the step in all three passes over it). */
 int vqf_mfb_fuse_fwd_pbf16(const void* P_bf16, const float* pbias, const float* q, const uint8_t* keep, uint64_t seed,
                            float p_drop, int N, int L, int O, float* R, float* rowssq, void* stream);
+/* The same, leaving ALSO a bf16 copy of R (round-to-nearest-even of the fp32 values; row pitch ldrb >= O elements, ldrb % 4 == 0,
+ * ldrb <= 1024, 8-byte aligned; columns O .. ldrb-1 zero): the K-padded A operand of the co-attention conv's bf16 GEMM
+ * (mhb_coAtt.py:97-98) without a vqf_cast_f32_bf16 pass over R; the fp32 R stays for the backward (ABI 7). */
+int vqf_mfb_fuse_fwd_pbf16_rb(const void* P_bf16, const float* pbias, const float* q, const uint8_t* keep, uint64_t seed,
+                              float p_drop, int N, int L, int O, float* R, void* R_bf16, int ldrb, float* rowssq, void* stream);
 int vqf_mfb_fuse_bwd_pbf16(const float* dY, const float* Y, const float* inv, const float* coefA,
                            const float* coefB, const void* P_bf16, const float* pbias, const float* q,
                            const uint8_t* keep, uint64_t seed, float p_drop, int N, int L, int O, void* dP_bf16,

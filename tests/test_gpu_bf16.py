@@ -277,6 +277,13 @@ def test_bf16_projection_storage_is_exact_rounding_and_fuse_kernels_agree(ops):
     Yb, nb, ib, _ = ops.mfb_fuse_fwd(Pb, q, N, L, O, seed=77, p_drop=0.1)
     Yf, nf, i_f, _ = ops.mfb_fuse_fwd(Pr, q, N, L, O, seed=77, p_drop=0.1)
     assert torch.equal(Yb, Yf) and torch.equal(nb, nf)
+    # the un-normalised form that feeds a NormLink consumer can leave a bf16 copy of R beside the fp32 one (round 5): the bits of
+    # vqf_cast_f32_bf16(R, pad 32), zero pad columns, and the fp32 outputs untouched
+    rb = []
+    R1, n1, i1, _ = ops.mfb_fuse_fwd(Pb, q, N, L, O, seed=77, p_drop=0.1, normalise=False, r_bf16=rb)
+    R0, n0, i0, _ = ops.mfb_fuse_fwd(Pb, q, N, L, O, seed=77, p_drop=0.1, normalise=False)
+    assert torch.equal(R1, R0) and torch.equal(n1, n0) and torch.equal(i1, i0) and len(rb) == 1
+    assert rb[0].shape == (N * L, (O + 31) // 32 * 32) and torch.equal(rb[0].view(torch.int16), ops.cast_bf16(R0, 32).view(torch.int16))
     dY = _r((N * L, O), 35).cuda()
     dPb, dqb, _, dbb = ops.mfb_fuse_bwd(dY, Yb, nb, ib, Pb, q, N, L, O, seed=77, p_drop=0.1, want_dbias=True, dp_bf16=True)
     dPf, dqf, _, dbf = ops.mfb_fuse_bwd(dY, Yf, nf, i_f, Pr, q, N, L, O, seed=77, p_drop=0.1, want_dbias=True, dp_bf16=True)

@@ -205,7 +205,11 @@ mfb_fuse_fwd_kernel(const PT* __restrict__ P, const float* __restrict__ pbias,
                     const float* __restrict__ q,
                     const float* __restrict__ cascade, const uint8_t* __restrict__ keep,
                     uint64_t seed, uint32_t thr, float inv_keep, int L, int O, int LS,
-                    float* __restrict__ R, float* __restrict__ rowssq, float* __restrict__ zdrop) {
+                    float* __restrict__ R, float* __restrict__ rowssq, float* __restrict__ zdrop,
+                    unsigned short* __restrict__ Rb, int ldrb) {
+  // Rb != nullptr: a bf16 copy of R (round-to-nearest-even) with row pitch ldrb >= O, columns O .. ldrb-1 zero: the K-padded A
+  // operand of the co-attention conv's bf16 GEMM (BASELINE config 3) straight from the registers that hold R -- no
+  // vqf_cast_f32_bf16 pass over the 401 MB tensor.  ldrb / 4 <= 256.
 #if VQF_FUSE_ROWBAR
   __shared__ float red[2][4];
 #endif
@@ -265,6 +269,14 @@ mfb_fuse_fwd_kernel(const PT* __restrict__ P, const float* __restrict__ pbias,
         r[j] = s < 0.f ? -rt : rt;                 // sqrt(relu(s)) - sqrt(relu(-s))
       }
       *reinterpret_cast<f32x4*>(R + row * O + TPT * tid) = r;
+      if (Rb) {
+        __bf16 rb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rb[j] = (__bf16)r[j];
+        *reinterpret_cast<uint2*>(Rb + row * ldrb + TPT * tid) = *reinterpret_cast<const uint2*>(rb);
+      }
+    } else if (Rb && TPT * tid < ldrb) {
+      *reinterpret_cast<uint2*>(Rb + row * ldrb + TPT * tid) = make_uint2(0u, 0u);
     }
     ssq = wave_sum(ssq);
 #if VQF_FUSE_ROWBAR
@@ -453,8 +465,9 @@ static int fuse_bwd_impl(const float* dY, const float* dzdrop, const float* Y, c
 
 static int fuse_fwd_impl(const void* P, int p_bf16, const float* pbias, const float* q, const float* cascade,
                          const uint8_t* keep, uint64_t seed, float p_drop, int N, int L, int O, float* R,
-                         float* rowssq, float* zdrop, void* stream) {
+                         float* rowssq, float* zdrop, void* stream, void* R_bf16 = nullptr, int ldrb = 0) {
   if (!P || !q || !R || !rowssq || N <= 0 || L <= 0 || O <= 0) return VQF_E_BADARG;
+  if (R_bf16 && (ldrb < O || (ldrb % 4) || ldrb / 4 > 256 || (((uintptr_t)R_bf16) & 7))) return VQF_E_BADARG;
   if ((O % TPT) || O / TPT > 256) return VQF_E_UNSUPPORTED;     // one thread per 4 pooled outputs: O <= 1024 (the reference's 1000)
   if (p_drop < 0.f || p_drop >= 1.f) return VQF_E_BADARG;
   if (!aligned16(P) || (pbias && !aligned16(pbias)) || !aligned16(q) || !aligned16(R) ||
@@ -468,7 +481,7 @@ static int fuse_fwd_impl(const void* P, int p_bf16, const float* pbias, const fl
   const bool nopf = coal && g_vqf_opt[VQF_OPT_FUSE_COAL] != 1;   // default: no register prefetch (126 VGPRs, 4 blocks per CU)
 #define VQF_FWD(PT_, CO_)                                                                                             \
   VQF_LAUNCH(KID_MFB_FUSE_FWD, (mfb_fuse_fwd_kernel<PT_, CO_>), dim3(N, LS), dim3(256), 0, (hipStream_t)stream,         \
-             (const PT_*)P, pbias, q, cascade, keep, seed, thr, inv_keep, L, O, LS, R, rowssq, zdrop)
+             (const PT_*)P, pbias, q, cascade, keep, seed, thr, inv_keep, L, O, LS, R, rowssq, zdrop, (unsigned short*)R_bf16, ldrb)
   if (p_bf16) { if (nopf) VQF_FWD(__bf16, 2); else if (coal) VQF_FWD(__bf16, 1); else VQF_FWD(__bf16, 0); }
   else        { if (nopf) VQF_FWD(float, 2); else if (coal) VQF_FWD(float, 1); else VQF_FWD(float, 0); }
 #undef VQF_FWD
@@ -487,6 +500,12 @@ int vqf_mfb_fuse_fwd(const float* P, const float* pbias, const float* q, const f
 int vqf_mfb_fuse_fwd_pbf16(const void* P_bf16, const float* pbias, const float* q, const uint8_t* keep, uint64_t seed,
                            float p_drop, int N, int L, int O, float* R, float* rowssq, void* stream) {
   return fuse_fwd_impl(P_bf16, 1, pbias, q, nullptr, keep, seed, p_drop, N, L, O, R, rowssq, nullptr, stream);
+}
+
+int vqf_mfb_fuse_fwd_pbf16_rb(const void* P_bf16, const float* pbias, const float* q, const uint8_t* keep, uint64_t seed,
+                              float p_drop, int N, int L, int O, float* R, void* R_bf16, int ldrb, float* rowssq, void* stream) {
+  if (!R_bf16) return VQF_E_BADARG;
+  return fuse_fwd_impl(P_bf16, 1, pbias, q, nullptr, keep, seed, p_drop, N, L, O, R, rowssq, nullptr, stream, R_bf16, ldrb);
 }
 
 size_t vqf_mfb_fuse_bwd_ws_bytes(int N, int L, int O) {

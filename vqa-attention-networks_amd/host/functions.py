@@ -77,10 +77,10 @@ class NormLink:
     returns (dYs = dY / norm) need no further pass, and leaves (dlogits, lin) here, from which the producer's backward gets
     sum(Y * dY) per sample.  Saves the scale_rows pass (forward) and the rowdot pass (backward) over the (N*L, 1000)
     tensors.  One link per forward call; only valid while the producer's output has exactly this one consumer."""
-    __slots__ = ("inv", "L", "lin")
+    __slots__ = ("inv", "L", "lin", "xb")
 
     def __init__(self):
-        self.inv, self.L, self.lin = None, 0, None
+        self.inv, self.L, self.lin, self.xb = None, 0, None, None    # xb: the producer's bf16 copy of R (K padded to 32), bf16 modes
 
 
 class LinearFn(torch.autograd.Function):
@@ -213,7 +213,9 @@ class AttHeadFn(torch.autograd.Function):
                 raise ops._l.VqfError("AttHeadFn: a NormLink needs the single-hidden-layer head with a bias")
             ctx.bf16 = ctx.bf16 and _bf16_ok(_w2d(w1).shape[0], _w2d(w1).shape[1])
             if ctx.bf16:       # bf16 operands (BASELINE config 3): the un-normalised R is cast, 1/norm rides in the bf16 GEMM's epilogue
-                xb, w1b = ops.cast_bf16(x, 32), ops.cast_bf16(_w2d(w1), 32)
+                w1b = ops.cast_bf16(_w2d(w1), 32)
+                xb = link.xb if (link.xb is not None and link.xb.shape == (x.shape[0], w1b.shape[1])) else ops.cast_bf16(x, 32)
+                link.xb = None
                 hid1 = ops.gemm_bf16_rowscale(xb, w1b, link.inv, link.L, bias=b1, relu=True, K=xb.shape[1])
                 x = xb
             else:
@@ -291,10 +293,11 @@ class AttHeadFn(torch.autograd.Function):
         return dx, dfeat, dw1, db1, dwm, dbm, dw2.view_as(w2), db2, None, None, None, None
 
 
-def _arm_link(link, inv, L):
-    """producer side of a NormLink: publish 1/norm and the row-group size for the consumer's GEMM epilogue"""
+def _arm_link(link, inv, L, xb=None):
+    """producer side of a NormLink: publish 1/norm and the row-group size for the consumer's GEMM epilogue (and, in the bf16 modes,
+    the bf16 copy of R the fusion kernel wrote beside the fp32 one: the consumer's GEMM operand without a cast pass)"""
     if link is not None:
-        link.inv, link.L, link.lin = inv, L, None
+        link.inv, link.L, link.lin, link.xb = inv, L, None, (xb[0] if xb else None)
     return link
 
 
@@ -338,8 +341,9 @@ class ImgFuseFn(torch.autograd.Function):
                 P = ops.gemm_bf16(img, wb, bias=bi)
         else:
             P = ops.gemm(img.view(N * L, D), wi2, bias=bi)
-        Y, norm, inv, _ = ops.mfb_fuse_fwd(P, q, N, L, O, keep=keep, seed=seed, p_drop=p_drop, normalise=link is None)
-        ctx.link = _arm_link(link, inv, L)
+        rb = [] if (link is not None and P.dtype == torch.bfloat16) else None
+        Y, norm, inv, _ = ops.mfb_fuse_fwd(P, q, N, L, O, keep=keep, seed=seed, p_drop=p_drop, normalise=link is None, r_bf16=rb)
+        ctx.link = _arm_link(link, inv, L, rb)
         ctx.save_for_backward(img, wi, q, P, Y, norm, inv, keep)
         ctx.seed, ctx.p_drop, ctx.dims = seed, p_drop, (N, L, D, O)
         return Y
@@ -471,9 +475,10 @@ class MfbFuseFn(torch.autograd.Function):
     def forward(ctx, P0, bi, q, keep, seed, p_drop, N, L, link=None):
         P0, q = _c(P0), _c(q)
         O = P0.shape[1] // ops.POOL_K
+        rb = [] if (link is not None and P0.dtype == torch.bfloat16) else None
         Y, norm, inv, _ = ops.mfb_fuse_fwd(P0, q, N, L, O, keep=keep, seed=seed, p_drop=p_drop, pbias=bi,
-                                           normalise=link is None)
-        ctx.link = _arm_link(link, inv, L)
+                                           normalise=link is None, r_bf16=rb)
+        ctx.link = _arm_link(link, inv, L, rb)
         ctx.save_for_backward(P0, bi, q, Y, norm, inv, keep)
         ctx.seed, ctx.p_drop, ctx.dims = seed, p_drop, (N, L, O)
         return Y

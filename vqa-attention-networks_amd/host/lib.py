@@ -99,6 +99,7 @@ SIGNATURES = {
     "vqf_mfb_fuse_bwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_u64, ctypes.c_float,
                                c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_p, c_sz, c_p]),
     "vqf_mfb_fuse_fwd_pbf16": (c_i, [c_p, c_f, c_f, c_p, c_u64, ctypes.c_float, c_i, c_i, c_i, c_f, c_f, c_p]),
+    "vqf_mfb_fuse_fwd_pbf16_rb": (c_i, [c_p, c_f, c_f, c_p, c_u64, ctypes.c_float, c_i, c_i, c_i, c_f, c_p, c_i, c_f, c_p]),
     "vqf_mfb_fuse_bwd_pbf16": (c_i, [c_f, c_f, c_f, c_f, c_f, c_p, c_f, c_f, c_p, c_u64, ctypes.c_float,
                                      c_i, c_i, c_i, c_p, c_f, c_f, c_p, c_sz, c_p]),
     "vqf_mfb_fuse_bwd_bf16dp": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_u64, ctypes.c_float,

@@ -702,10 +702,12 @@ def _keep_ptr(keep):
 
 
 def mfb_fuse_fwd(P, q, N, L, O, keep=None, seed=0, p_drop=0.0, cascade=None, want_zdrop=False, pbias=None,
-                 normalise=True):
+                 normalise=True, r_bf16=None):
     """-> (Y normalised (N*L,O), norm (N), inv (N), zdrop or None).  pbias: projection bias added on load.
     P may be bf16 (written by gemm_bf16(out_bf16=True)).  normalise=False: the first output is R, the signed square roots
-    WITHOUT the per-sample 1/norm (no vqf_scale_rows pass: the consumer applies inv in its GEMM epilogue)."""
+    WITHOUT the per-sample 1/norm (no vqf_scale_rows pass: the consumer applies inv in its GEMM epilogue).
+    r_bf16 (bf16 P, normalise=False only): a list; it receives a (N*L, O rounded up to 32) bf16 copy of R with zero pad columns,
+    written by the same launch (the operand of the consumer's bf16 GEMM)."""
     (_chk_bf16 if P.dtype == torch.bfloat16 else _chk)(P)
     _chk(q, cascade, pbias)
     dev = P.device
@@ -715,8 +717,15 @@ def mfb_fuse_fwd(P, q, N, L, O, keep=None, seed=0, p_drop=0.0, cascade=None, wan
     if P.dtype == torch.bfloat16:      # the projection itself stored in bf16 (bf16 mode of the image fusion)
         if cascade is not None or want_zdrop:
             raise _l.VqfError("mfb_fuse_fwd: a bf16 P is only available without cascade / zdrop")
-        _l.check(_lib().vqf_mfb_fuse_fwd_pbf16(_ptr(P), _ptr(pbias), _ptr(q), _keep_ptr(keep), int(seed), float(p_drop),
-                                               N, L, O, _ptr(R), _ptr(rowssq), _stream()), "vqf_mfb_fuse_fwd_pbf16")
+        if r_bf16 is not None and not normalise and (O + 31) // 32 * 32 <= 1024:
+            Rb = torch.empty((N * L, (O + 31) // 32 * 32), dtype=torch.bfloat16, device=dev)
+            _l.check(_lib().vqf_mfb_fuse_fwd_pbf16_rb(_ptr(P), _ptr(pbias), _ptr(q), _keep_ptr(keep), int(seed), float(p_drop),
+                                                      N, L, O, _ptr(R), ctypes.c_void_p(Rb.data_ptr()), Rb.shape[1], _ptr(rowssq),
+                                                      _stream()), "vqf_mfb_fuse_fwd_pbf16_rb")
+            r_bf16.append(Rb)
+        else:
+            _l.check(_lib().vqf_mfb_fuse_fwd_pbf16(_ptr(P), _ptr(pbias), _ptr(q), _keep_ptr(keep), int(seed), float(p_drop),
+                                                   N, L, O, _ptr(R), _ptr(rowssq), _stream()), "vqf_mfb_fuse_fwd_pbf16")
     else:
         _l.check(_lib().vqf_mfb_fuse_fwd(_ptr(P), _ptr(pbias), _ptr(q), _ptr(cascade), _keep_ptr(keep), int(seed),
                                          float(p_drop), N, L, O, _ptr(R), _ptr(rowssq), _ptr(zdrop), _stream()),
