@@ -47,6 +47,9 @@ struct HieArgs {
 
 __device__ __forceinline__ void keep4v(const uint8_t* __restrict__ keep, uint64_t seed, uint32_t thr, float inv_keep,
                                        long long i4, f32x4& sc) {
+#ifdef VQF_HIE_DIAG_NOPHILOX                           // (diagnostic build: what the Philox draw costs the passes; wrong masks)
+  if (!keep && thr != 0u) { sc = f32x4{inv_keep, inv_keep, inv_keep, inv_keep}; return; }
+#endif
   if (keep) {
     const uint32_t w = *reinterpret_cast<const uint32_t*>(keep + 4 * i4);
 #pragma unroll
@@ -66,6 +69,13 @@ __device__ __forceinline__ void keep4v(const uint8_t* __restrict__ keep, uint64_
 // 128-register budget of a 1024-thread workgroup)
 template <int MODE, int TMAX>
 __global__ void __launch_bounds__(HT) hie_stream_kernel(const HieArgs g) {
+  // The rank-T sums of this kernel may contract to fused multiply-adds (the library is built with -ffp-contract=off so that the
+  // GEMM kernels and their references add in ONE stated order; these passes have no bit-level counterpart -- the batched-GEMM
+  // form they replace rounds differently anyway -- and are VALU-sensitive: 112 multiply-add pairs per 16 bytes streamed.
+  // Measured with the whole file contracted: forward 77 -> 68 us, head backward 67 -> 62, rank_left 60 -> 52).
+#ifndef VQF_HIE_NO_CONTRACT                           // (A/B build switch)
+#pragma clang fp contract(fast)
+#endif
   const int HT = blockDim.x;                                // (shadows the constant: small problems launch narrower workgroups)
   constexpr bool RANK = MODE != MODE_HEAD;                  // out has the rank-T term sum_t U[t,l] V[t,:]
   constexpr bool ACC = MODE != MODE_ADD;                    // part[t,:] += U[t,l] (a | out | z)[l,:]
@@ -177,7 +187,11 @@ __global__ void __launch_bounds__(HT) hie_stream_kernel(const HieArgs g) {
           f32x4 sc;
           keep4v(g.keep, g.seed, g.thr, g.inv_keep, m[q] * CT + c4, sc);
 #pragma unroll
+#ifdef VQF_HIE_DIAG_NOTANH
+          for (int j = 0; j < 4; ++j) o[q][j] = o[q][j] * sc[j];
+#else
           for (int j = 0; j < 4; ++j) o[q][j] = vqf_tanh_fast(o[q][j]) * sc[j];
+#endif
         }
       }
     }
