@@ -96,8 +96,9 @@ const char* vqf_build_info(void);
 #define VQF_OPT_GEMM_F32_SAMPLE 16    /* 0 = vqf_gemm_f32_sample reports every shape unsupported, i.e. HieCoAtten's per-sample products run on the
                                         256x256 / 128x128 kernels as in round 4 (A/B); 2 = it takes every shape it can run, also batches whose
                                         NS * N / 256 work items fill less than half of the CUs (default: those stay on vqf_gemm_f32) */
-#define VQF_OPT_GEMM_F32_N80 17       /* 0 = never use the one-round 128x80-tile kernel (csrc/gemm_f32_n80.hip) for the M = 512 forward
-                                        projections: they run on the 128x128 kernel with split-K + slab reduce, as before round 5 (A/B) */
+#define VQF_OPT_GEMM_F32_N80 17       /* 0 = never use the one-round 16x16x4-tile kernels of csrc/gemm_f32_n80.hip: the M = 512 forward
+                                        projections run on the 128x128 kernel with split-K + slab reduce and the fused LSTM step on
+                                        the per-wave kernel, as before round 5 (A/B) */
 #define VQF_OPT_COUNT 18
 int vqf_set_option(int option, int value, int* previous);
 int vqf_get_option(int option, int* value);
@@ -508,8 +509,12 @@ int vqf_lstm_seq_bwd(const float* dhs, const float* gates, const float* cs, cons
 int vqf_lstm_cell_fwd(float* gates, const float* c_prev, int B, int H, float* c_out, float* h_out, void* stream);
 /* One whole forward step in ONE launch: gates (B,4H) += h_prev (B,H) W_hh^T, then the cell stage above in the product's epilogue
  * (the wave tile of csrc/gemm_f32_wave.hip holds 16 hidden units x 4 gates: W_hh's rows are gathered gate-interleaved by the
- * LDS-DMA source addresses).  Bit-identical to vqf_gemm_f32(VQF_GEMM_ACCUM) + vqf_lstm_cell_fwd.  Supported
- * (vqf_lstm_step_supported): B % 128 == 0, H % 16 == 0, H >= 256; else VQF_E_UNSUPPORTED. */
+ * LDS-DMA source addresses).  Two forms.  Where B / 128 x H / 16 tiles fill 80..100 % of the CUs once and H % 128 == 0, H >= 512
+ * (the question encoder at batch 512, H = 1024: 256 tiles) one workgroup per CU multiplies 128 rows x 16 units on
+ * v_mfma_f32_16x16x4_f32 with the four column tiles = the four gates of a unit, so the cell is a per-lane epilogue
+ * (csrc/gemm_f32_n80.hip, round 5: 45-47 us against 60-63; same cell arithmetic, the product's k order is that kernel's);
+ * otherwise, or with option gemm_f32_n80 = 0, the per-wave form: bit-identical to vqf_gemm_f32(VQF_GEMM_ACCUM) +
+ * vqf_lstm_cell_fwd.  Supported (vqf_lstm_step_supported): B % 128 == 0, H % 16 == 0, H >= 256; else VQF_E_UNSUPPORTED. */
 int vqf_lstm_step_supported(int B, int H);
 int vqf_lstm_step_fwd(const float* h_prev, const float* w_hh, float* gates, const float* c_prev, int B, int H,
                       float* c_out, float* h_out, void* stream);

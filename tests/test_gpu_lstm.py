@@ -183,9 +183,16 @@ def test_fused_lstm_step_vs_fp64_and_bitwise_where_the_k_order_is_shared(B, H):
     step_tol = gemm_tol(H) + 5e-7
     same_order = True
     worst = 0.0
+    on16 = False
     for cp in (c_prev, None):
         g1, c1, h1 = pre.clone(), torch.empty(B, H, device="cuda"), torch.empty(B, H, device="cuda")
+        n16 = ops.stat("gemm_f32_n80")
         ops.lstm_step_fwd(h_prev, w_hh, g1, cp, c1, h1)
+        on16 = ops.stat("gemm_f32_n80") == n16 + 1            # round 5: one round of 16x16x4 gate tiles (csrc/gemm_f32_n80.hip) took the step
+        g3, c3, h3 = pre.clone(), torch.empty(B, H, device="cuda"), torch.empty(B, H, device="cuda")
+        with ops.options(gemm_f32_n80=0):                     # the per-wave form of the fused step (rounds 3-4), always available
+            ops.lstm_step_fwd(h_prev, w_hh, g3, cp, c3, h3)
+        assert ops.stat("gemm_f32_n80") == n16 + (1 if on16 else 0)
         g2, c2, h2 = pre.clone(), torch.empty(B, H, device="cuda"), torch.empty(B, H, device="cuda")
         n0 = ops.stat("gemm_f32_wave")
         ops.gemm(h_prev, w_hh, out=g2, accumulate=True)
@@ -197,16 +204,20 @@ def test_fused_lstm_step_vs_fp64_and_bitwise_where_the_k_order_is_shared(B, H):
         act64 = torch.cat((torch.sigmoid(i64), torch.sigmoid(f64), torch.tanh(gg64), torch.sigmoid(o64)), 1)
         c64 = torch.sigmoid(i64) * torch.tanh(gg64) + (torch.sigmoid(f64) * cp.double() if cp is not None else 0.0)
         h64 = torch.sigmoid(o64) * torch.tanh(c64)
-        for form, (ga, ca, ha) in (("fused step", (g1, c1, h1)), ("product + cell", (g2, c2, h2))):
+        for form, (ga, ca, ha) in (("fused step", (g1, c1, h1)), ("fused step, per-wave form", (g3, c3, h3)), ("product + cell", (g2, c2, h2))):
             for what, got, ref in (("gates", ga, act64), ("c", ca, c64), ("h", ha, h64)):
                 e = _rel(got, ref)
                 assert e <= step_tol, (form, what, e, step_tol)
                 worst = max(worst, e)
         if same_order:
-            assert torch.equal(g1, g2) and torch.equal(c1, c2) and torch.equal(h1, h2)
-    print("lstm step B=%d H=%d: both forms vs fp64 worst %.2e (bound %.2e); same k order: %s" % (B, H, worst, step_tol, same_order))
+            assert torch.equal(g3, g2) and torch.equal(c3, c2) and torch.equal(h3, h2)
+            if not on16:
+                assert torch.equal(g1, g3) and torch.equal(c1, c3) and torch.equal(h1, h3)
+    print("lstm step B=%d H=%d: all forms vs fp64 worst %.2e (bound %.2e); same k order: %s; gate-tile kernel: %s"
+          % (B, H, worst, step_tol, same_order, on16))
     if B == 512 and H == 1024:
         assert same_order, "the headline shape's two-launch form is the per-wave kernel"
+        assert on16, "the headline shape's fused step is one round of gate tiles"
     fn = vqa_amd.functions.LstmBatchFn
     x = r(5, B, 40)
     ps = [r(4 * H, 40) * 0.1, w_hh, r(4 * H) * 0.1, r(4 * H) * 0.1]
@@ -228,7 +239,17 @@ def test_fused_lstm_step_vs_fp64_and_bitwise_where_the_k_order_is_shared(B, H):
         assert nrel(hs.detach(), hs64.detach()) <= LSTM_BATCH_TOL_F32, ("fused" if fused else "two-launch", "hs")
         for a, b in zip(res[-1][1], l64):
             assert nrel(a, b.grad) <= LSTM_BATCH_TOL_F32, ("fused" if fused else "two-launch", "gradient", nrel(a, b.grad))
-    if same_order:
+    if same_order and not on16:
         assert torch.equal(res[0][0], res[1][0])
         for a, b in zip(res[0][1], res[1][1]):
+            assert torch.equal(a, b)
+    elif same_order:
+        # the gate-tile kernel adds k in its own order: the per-wave form of the fused step is the one that shares the two-launch
+        # form's bits
+        with ops.options(gemm_f32_n80=0):
+            leaves = [p.clone().requires_grad_() for p in ps]
+            hs = fn.apply(x, *leaves)
+            (hs * wgt).sum().backward()
+        assert torch.equal(hs.detach(), res[1][0])
+        for a, b in zip([p.grad for p in leaves], res[1][1]):
             assert torch.equal(a, b)

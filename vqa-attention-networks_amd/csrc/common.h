@@ -102,6 +102,9 @@ size_t vqf_gemm_f32_big_ws_bytes(int ta, int tb, int M, int N, int K);
 // gemm_f32_n80.hip: one-round 128x80 tiles for the M = 512 forward projections (ta == tb == 0); returns 0 when it does not apply
 int vqf_gemm_f32_n80_try(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                          const float* bias, int flags, hipStream_t s, int* rc);
+// gemm_f32_n80.hip: the fused LSTM step (product + cell) on the same kernel, four gate tiles per workgroup; 0 = not its shape
+int vqf_lstm_step16_try(const float* h_prev, const float* w_hh, float* gates, const float* c_prev, int B, int H, float* c_out,
+                        float* h_out, hipStream_t s, int* rc);
 // gemm_f32_wave.hip: small-M products, one 32x64 tile per wave, no split-K slabs; returns 0 when it does not apply
 int vqf_gemm_f32_wave_try(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
                           int ldc, const float* bias, int flags, hipStream_t s, int* rc);

@@ -24,13 +24,19 @@ namespace {
 typedef const float __attribute__((address_space(1))) gfloat;
 
 constexpr int TM = 128, TN = 80, TK = 32, NT = 512, NSLOT = 4;
-constexpr int A_BYTES = TM * TK * 4, B_BYTES = TN * TK * 4, SLOT_BYTES = A_BYTES + B_BYTES;      // 16 + 10 KB
-static_assert(A_BYTES == 16 * 1024 && B_BYTES == 10 * 1024, "per slab: wave w copies A chunks 2w, 2w+1 and B chunk w (and 8 + w for w < 2)");
+constexpr int A_BYTES = TM * TK * 4;                       // 16 KB per slab: wave w copies A chunks 2w, 2w+1
+// B per slab: NTC column tiles x 16 rows x 128 bytes = 2 NTC copies -- NTC = 5 (the GEMM): wave w copies chunk w (and 8 + w for
+// w < 2); NTC = 4 (the LSTM step below): one chunk per wave
+constexpr int b_bytes(int ntc) { return 16 * ntc * TK * 4; }
+constexpr int slot_bytes(int ntc) { return A_BYTES + b_bytes(ntc); }
 
 struct N80Args {
   const float* A; const float* B; float* C; const float* bias;
   int M, N, K, lda, ldb, ldc, flags, tiles_m, tiles;
+  const float* c_prev; float* c_out; float* h_out; int H;      // CELL (the fused LSTM step)
 };
+
+__device__ __forceinline__ float sigm_f(float x) { return 1.0f / (1.0f + expf(-x)); }     // lstm_cell.hip's sigm
 
 // chunk XOR of LDS row rho.  ds_read_b128 serves a wave in four NON-contiguous groups of 16 lanes ({0-3, 12-15, 20-27}, {4-11,
 // 16-19, 28-31} and the same + 32: MI355X_MICROARCH.md, LDS table), i.e. with lane = (c, kq) a group holds all 16 rows c, rows
@@ -57,7 +63,16 @@ __device__ __forceinline__ void wait_own(int later, bool two) {
   }
 }
 
+// NTC = 5, CELL = false: the GEMM above.
+// NTC = 4, CELL = true: ONE STEP of the question encoder's LSTM (mfb.py:69; vqf_lstm_step_fwd) -- A = h_{t-1} (B, H), B = W_hh
+// (4H, H), the tile's 64 columns are the FOUR GATES of 16 hidden units: LDS row 16 t + c of a B slab holds W_hh row t H + u0 + c
+// (the copy's source address is per lane, nothing else moves), so column tile t of a lane is gate t (i, f, g, o) of unit u0 + c
+// for the lane's four rows and THE CELL IS A PER-LANE EPILOGUE: pre = acc + gates_t (x_t W_ih^T + b, fetched at kernel entry),
+// i, f, o = sigmoid, g = tanh, c_t = f c_{t-1} + i g, h_t = o tanh(c_t); gates_t leaves activated (kept for the backward).
+// The arithmetic of vqf_lstm_cell_fwd in its order; the product's k order is this kernel's (not the bits of the per-wave form).
+template <int NTC, bool CELL>
 __global__ void __launch_bounds__(NT, 1) gemm_f32_n80_kernel(const N80Args g) {
+  constexpr int SLOT_BYTES = slot_bytes(NTC), TNC = 16 * NTC;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __attribute__((address_space(3))) char lds_char;
   // XCD-aware order: consecutive workgroups go to the 8 XCDs round-robin; an XCD's workgroups take CONSECUTIVE tiles, row tile
@@ -66,12 +81,26 @@ __global__ void __launch_bounds__(NT, 1) gemm_f32_n80_kernel(const N80Args g) {
   const int lin = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
   if (lin >= g.tiles) return;                              // (whole workgroup, before any barrier)
   const int tn = lin / g.tiles_m, tm = lin - tn * g.tiles_m;
-  const int m0 = tm * TM, n0 = tn * TN;
+  const int m0 = tm * TM, n0 = tn * TNC;                  // (CELL: n0 / 4 = the tile's first hidden unit)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, kq = lane >> 4;
-  const bool two = wave < 2;
+  const bool two = NTC == 5 && wave < 2;
   const int S = g.K / TK;
+
+  // CELL: what the epilogue adds to / multiplies with the accumulators is requested first (older than every copy: any counted
+  // wait for a slab covers it); lane (c, kq), register j: row m0 + 16 wave + 4 kq + j, unit u0 + c
+  float oldg[4][4], cpv[4];
+  if (CELL) {
+    const int u = (n0 >> 2) + c;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long long row = m0 + 16 * wave + 4 * kq + j;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) oldg[t][j] = g.C[row * g.ldc + t * g.H + u];
+      cpv[j] = g.c_prev ? g.c_prev[row * g.H + u] : 0.f;
+    }
+  }
 
   // copy sources (rows past M / N are clamped: computed on a valid row, not stored).  A copy of 1 KB = 8 LDS rows of 128 bytes:
   // lane l writes position l & 7 of row (l >> 3), which holds source chunk (l & 7) ^ swz(row)
@@ -82,7 +111,9 @@ __global__ void __launch_bounds__(NT, 1) gemm_f32_n80_kernel(const N80Args g) {
     const int ra = 16 * wave + 8 * i + (lane >> 3);        // my own 16 rows of A
     qa[i] = (gfloat*)(g.A + (long long)min(m0 + ra, g.M - 1) * g.lda + 4 * ((lane & 7) ^ swz(ra)));
     const int rho = 8 * (wave + 8 * i) + (lane >> 3);
-    qb[i] = (gfloat*)(g.B + (long long)min(n0 + min(rho, TN - 1), g.N - 1) * g.ldb + 4 * ((lane & 7) ^ swz(rho)));
+    const int brow = CELL ? (min(rho, TNC - 1) >> 4) * g.H + (n0 >> 2) + (rho & 15)       // gate (rho >> 4), unit u0 + (rho & 15)
+                          : min(n0 + min(rho, TNC - 1), g.N - 1);
+    qb[i] = (gfloat*)(g.B + (long long)brow * g.ldb + 4 * ((lane & 7) ^ swz(rho)));
   }
   // piece p of slab s: 0, 1 = my two A chunks, 2 = B chunk `wave`, 3 = B chunk 8 + wave (waves 0, 1 only)
   auto issue_piece = [&](int s, int slot, int p) {
@@ -98,12 +129,13 @@ __global__ void __launch_bounds__(NT, 1) gemm_f32_n80_kernel(const N80Args g) {
     for (int p = 0; p < 4; ++p) issue_piece(s, slot, p);
   };
 
-  f32x4 acc[5];
+  f32x4 acc[NTC];
 #pragma unroll
-  for (int t = 0; t < 5; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < NTC; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // fragments of one slab: A 2 x 16 bytes, B 5 tiles x 2 x 16 bytes per lane = 12 reads, numbered 0 (A, u = 0), 1 (A, u = 1), 2 + 2 t + u
-  struct Frag { f32x4 a[2], b[5][2]; };
+  // fragments of one slab: A 2 x 16 bytes, B NTC tiles x 2 x 16 bytes per lane = 2 + 2 NTC reads, numbered 0 (A, u = 0), 1 (A, u = 1), 2 + 2 t + u
+  constexpr int NFR = 2 + 2 * NTC;
+  struct Frag { f32x4 a[2], b[NTC][2]; };
   auto read_frag = [&](int slot, Frag& f, int i) {
     const char* sa = smem + slot * SLOT_BYTES;
     if (i < 2) {
@@ -127,7 +159,7 @@ __global__ void __launch_bounds__(NT, 1) gemm_f32_n80_kernel(const N80Args g) {
     for (int grp = 0; grp < 8; ++grp) {
       const int u = grp >> 2, j = grp & 3;
 #pragma unroll
-      for (int t = 0; t < 5; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.a[u][j], cur.b[t][u][j], acc[t], 0, 0, 0);
+      for (int t = 0; t < NTC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.a[u][j], cur.b[t][u][j], acc[t], 0, 0, 0);
       // (giving the two waves of a SIMD opposite halves of the slab for their copies and reads -- so that they do not stand in a
       //  piece's issue cycles together -- measured SLOWER: 108 vs 90 us)
       // (-DVQF_N80_NOCOPY / -DVQF_N80_NOREAD: diagnostic builds that leave the copies / the fragment reads out of the loop -- wrong
@@ -136,7 +168,7 @@ __global__ void __launch_bounds__(NT, 1) gemm_f32_n80_kernel(const N80Args g) {
       if (grp < 4) { if (copy) issue_piece(s + NSLOT, q, grp); }
 #endif
 #ifndef VQF_N80_NOREAD
-      if (more && grp < 6) { read_frag((q + 1) % NSLOT, nxt, 2 * grp); read_frag((q + 1) % NSLOT, nxt, 2 * grp + 1); }
+      if (more && 2 * grp < NFR) { read_frag((q + 1) % NSLOT, nxt, 2 * grp); read_frag((q + 1) % NSLOT, nxt, 2 * grp + 1); }
 #endif
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -147,7 +179,7 @@ __global__ void __launch_bounds__(NT, 1) gemm_f32_n80_kernel(const N80Args g) {
   wait_own(NSLOT - 1, two);
   __builtin_amdgcn_s_barrier();
 #pragma unroll
-  for (int i = 0; i < 12; ++i) read_frag(0, fr[0], i);
+  for (int i = 0; i < NFR; ++i) read_frag(0, fr[0], i);
   // unrolled by NSLOT so that slots and register sets are compile-time: slab s lives in slot s % 4, set s % 2
   for (int s0 = 0; s0 < S; s0 += NSLOT) {
 #pragma unroll
@@ -162,10 +194,28 @@ __global__ void __launch_bounds__(NT, 1) gemm_f32_n80_kernel(const N80Args g) {
     }
   }
 
+  if (CELL) {
+    // the cell: acc[t][j] = gate t of unit u0 + c, row m0 + 16 wave + 4 kq + j
+    const int u = (n0 >> 2) + c;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long long row = m0 + 16 * wave + 4 * kq + j;
+      const float ig = sigm_f(acc[0][j] + oldg[0][j]);
+      const float fg = sigm_f(acc[1][j] + oldg[1][j]);
+      const float gg = tanhf(acc[2 % NTC][j] + oldg[2][j]);
+      const float og = sigm_f(acc[3 % NTC][j] + oldg[3][j]);
+      float* pg = g.C + row * g.ldc + u;
+      pg[0] = ig; pg[g.H] = fg; pg[2 * g.H] = gg; pg[3 * g.H] = og;
+      const float cn = fg * cpv[j] + ig * gg;
+      g.c_out[row * g.H + u] = cn;
+      g.h_out[row * g.H + u] = og * tanhf(cn);
+    }
+    return;
+  }
   // epilogue: acc[t][j] = row m0 + 16 wave + 4 kq + j, column n0 + 16 t + c
   const bool relu = g.flags & VQF_GEMM_RELU;
 #pragma unroll
-  for (int t = 0; t < 5; ++t) {
+  for (int t = 0; t < NTC; ++t) {
     const int col = n0 + 16 * t + c;
     if (col < g.N) {
       const float bv = g.bias ? g.bias[col] : 0.f;
@@ -201,7 +251,32 @@ int vqf_gemm_f32_n80_try(int M, int N, int K, const float* A, int lda, const flo
   const int nwg = ((int)tiles + 7) & ~7;
   vqf_prof_dims(M, N, K);
   vqf_stat_bump(VQF_STAT_GEMM_F32_N80);
-  VQF_LAUNCH(KID_GEMM_A0B0, gemm_f32_n80_kernel, dim3(nwg), dim3(NT), NSLOT * SLOT_BYTES, s, g);
+  static VqfDynLdsFlags attr = {};
+  if (int e = vqf_set_dyn_lds(reinterpret_cast<const void*>(&gemm_f32_n80_kernel<5, false>), NSLOT * slot_bytes(5), attr)) { *rc = e; return 1; }
+  VQF_LAUNCH(KID_GEMM_A0B0, (gemm_f32_n80_kernel<5, false>), dim3(nwg), dim3(NT), NSLOT * slot_bytes(5), s, g);
+  *rc = vqf_last_error();
+  return 1;
+}
+
+// The fused LSTM step on this kernel (lstm_step_fwd in gemm_f32_wave.hip asks first): 1 = launched (*rc), 0 = not its shape.
+int vqf_lstm_step16_try(const float* h_prev, const float* w_hh, float* gates, const float* c_prev, int B, int H, float* c_out,
+                        float* h_out, hipStream_t s, int* rc) {
+  if (vqf_opt(VQF_OPT_GEMM_F32_N80, 1) == 0 || vqf_opt(VQF_OPT_GEMM_CU_LIMIT, 0) >= 8) return 0;
+  if ((B % TM) || (H % 128) || H < 512) return 0;          // whole row tiles (the cell has no edge guards), K = H in 128-k units
+  const int tiles_m = B / TM, tiles_n = H / 16;
+  const long long tiles = (long long)tiles_m * tiles_n;
+  const int cus = vqf_cu_count() > 0 ? vqf_cu_count() : 256;
+  if (tiles > cus || tiles * 10 < (long long)cus * 8) return 0;
+  N80Args g = {};
+  g.A = h_prev; g.B = w_hh; g.C = gates; g.M = B; g.N = 4 * H; g.K = H; g.lda = H; g.ldb = H; g.ldc = 4 * H;
+  g.tiles_m = tiles_m; g.tiles = (int)tiles;
+  g.c_prev = c_prev; g.c_out = c_out; g.h_out = h_out; g.H = H;
+  const int nwg = ((int)tiles + 7) & ~7;
+  vqf_prof_dims(B, 4 * H, H);
+  vqf_stat_bump(VQF_STAT_GEMM_F32_N80);
+  static VqfDynLdsFlags attr = {};
+  if (int e = vqf_set_dyn_lds(reinterpret_cast<const void*>(&gemm_f32_n80_kernel<4, true>), NSLOT * slot_bytes(4), attr)) { *rc = e; return 1; }
+  VQF_LAUNCH(KID_LSTM_CELL_FWD, (gemm_f32_n80_kernel<4, true>), dim3(nwg), dim3(NT), NSLOT * slot_bytes(4), s, g);
   *rc = vqf_last_error();
   return 1;
 }

@@ -614,6 +614,12 @@ extern "C" int vqf_lstm_step_fwd(const float* h_prev, const float* w_hh, float* 
   if (!aligned16(h_prev) || !aligned16(w_hh) || !aligned16(gates) || !aligned16(c_out) || !aligned16(h_out) ||
       (c_prev && !aligned16(c_prev)))
     return VQF_E_ALIGN;
+  {
+    // round 5: one workgroup per CU on 16x16x4 tiles whose four column tiles are a unit's four gates (gemm_f32_n80.hip) where the
+    // shape gives one round (B = 512, H = 1024: 256 tiles); option gemm_f32_n80 = 0: the per-wave form below
+    int rc = VQF_OK;
+    if (vqf_lstm_step16_try(h_prev, w_hh, gates, c_prev, B, H, c_out, h_out, (hipStream_t)stream, &rc)) return rc;
+  }
   WaveArgs g = {};
   g.A = h_prev; g.B = w_hh; g.C = gates; g.bias = nullptr;
   g.M = B; g.N = 4 * H; g.K = H; g.lda = H; g.ldb = H; g.ldc = 4 * H; g.flags = VQF_GEMM_ACCUM;
