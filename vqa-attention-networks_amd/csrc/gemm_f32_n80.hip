@@ -9,7 +9,7 @@
 // Structure: 8 waves, wave w owns rows 16 w .. 16 w + 15 of the tile and all 80 columns = five v_mfma_f32_16x16x4_f32 tiles
 // (lane = (c, kq) = (lane % 16, lane / 16); one MFMA multiplies the four k values its four lane groups hold).  Operands are
 // staged by LDS-DMA (global_load_lds_dwordx4) in 32-wide k slabs -- A 128 rows = 16 KB, every wave copying its OWN 16 rows; B
-// 80 rows = 10 KB, shared -- into a ring of four 26 KB slots, three slabs in flight, the 16-byte chunks of a row XOR-swizzled
+// 80 rows = 10 KB, shared -- into a ring of four 26 KB slots, three to four slabs in flight, the 16-byte chunks of a row XOR-swizzled
 // (swz below) so that each 16-lane group of a fragment read covers the 16 slots of a bank row.  One s_barrier per slab; a wave
 // waits for its own copies with a counted vmcnt in front of it (no compiler-visible vector loads in the loop: a first form
 // with A loaded straight into registers got a compiler-inserted vmcnt(0) in front of every slab's MFMAs).  Every output
@@ -17,6 +17,8 @@
 // the bit pattern of the 32x32x2 kernels.
 // Preconditions: K % 128 == 0, K >= 512, 16-byte aligned A / B with lda, ldb % 4 == 0; any M, N (edge tiles are clamped on
 // load and masked on store).
+// The same kernel with FOUR column tiles = the four gates of 16 hidden units is the fused LSTM forward step
+// (gemm_f32_n80_kernel<4, true>, vqf_lstm_step16_try below; mfb.py:69).
 #include "common.h"
 
 namespace {
