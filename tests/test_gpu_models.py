@@ -549,10 +549,12 @@ def test_config3_mhbcoatt_batch_512_bf16_mode(bf16_mode):
     soft = torch.softmax(torch.randn((512, 1000), generator=torch.Generator().manual_seed(1236)), 1)
     img_d, q_d, soft_d = img.cuda(), q.cuda(), soft.cuda()
     res = {}
-    for mode in (bf16_mode, "fp32"):
-        model.gemm_dtype = mode
+    img_r = img_d.to(torch.bfloat16).float()          # the image tensor rounded to bf16 values, fed to the FP32 kernels: the conditioning yardstick below
+    for mode in (bf16_mode, "fp32", "fp32-rounded-image"):
+        model.gemm_dtype = "fp32" if mode.startswith("fp32") else mode
         model.zero_grad(set_to_none=True)
-        x = vqa.ops.cast_bf16(img_d.view(-1, 2048)).view(img_d.shape) if mode != "fp32" else img_d   # bf16 feature storage
+        x = (vqa.ops.cast_bf16(img_d.view(-1, 2048)).view(img_d.shape) if not mode.startswith("fp32")   # bf16 feature storage
+             else (img_r if mode == "fp32-rounded-image" else img_d))
         out = model.forward(x, q_d)
         torch.nn.KLDivLoss()(out, soft_d).backward()
         torch.cuda.synchronize()
@@ -567,24 +569,36 @@ def test_config3_mhbcoatt_batch_512_bf16_mode(bf16_mode):
     assert rel_err(res["fp32"][0][:4].cpu().numpy(), ref.numpy()) <= OUT_TOL
     assert not torch.equal(out, res["fp32"][0])                       # the bf16 kernels really ran
     assert rel_err(out.cpu().numpy(), res["fp32"][0].cpu().numpy()) <= 3e-2
-    # gradients, bf16 step vs fp32 step of the same model: asserted (10 % in norm) only for the classifier, the one
-    # tensor downstream of every signed square root.  Everything else is REPORTED, not asserted: each of those
-    # gradients passes through 0.5*|s|^-1/2 of the final MFB blocks' 512 x 2000 pooled sums (and, further upstream, of
-    # the 512 x 196 000 regional ones), whose near-zero entries a bf16 rounding of any upstream product replaces by
-    # noise (measured here: co_att_conv1 76 %, word_embedding 65 %; at N = 2 the same tensors stay within 10 %,
-    # test_gpu_bf16.py).  A property of the model's loss surface at this batch, not of the kernels: the bf16 GEMM
-    # kernels themselves are checked against fp64 in test_gpu_gemm_big.py / test_gpu_bf16.py.
+    # gradients, bf16 step vs fp32 step of the same model.  The classifier -- the one tensor downstream of every signed square
+    # root -- within 10 % in norm.  Every other gradient passes through 0.5*|s|^-1/2 of the final MFB blocks' 512 x 2000 pooled
+    # sums (and, further upstream, of the 512 x 196 000 regional ones), whose near-zero entries ANY rounding of an upstream
+    # product replaces by noise (co_att_conv1 76 %, word_embedding 65 %; at N = 2 the same tensors stay within 10 %,
+    # test_gpu_bf16.py): a property of the model's loss surface at this batch.  Round 5 asserts those tensors too, against a
+    # yardstick that has no bf16 kernel in it: the FP32 kernels on the image tensor rounded to bf16 values (one of the several
+    # roundings the bf16 mode performs).  A tensor may deviate from the fp32 step by at most 2.5x what that single input rounding
+    # already causes (or 10 %; measured 0.9-1.5x: the rounding moves these tensors by 45-130 %, the bf16 mode by 50-115 %): a wrong
+    # bf16 kernel on a tensor the rounding moves by 5 % fails; where the rounding alone moves a
+    # tensor by 70 % nothing at model level can discriminate -- those are the tensors tests/test_gpu_bf16_nodes.py covers node by
+    # node against fp64.
     from golden_util import _report_parity
     checked = ("linear_pred",)
+    g_round = res["fp32-rounded-image"][1]
     worst, worst_k, info = 0.0, "-", []
+    worst_y, worst_yk = 0.0, "-"
     for k, g32 in res["fp32"][1].items():
         if float(g32.norm()) < 1e-9:
             continue
         d = float((gb[k] - g32).norm()) / float(g32.norm())
-        info.append("%s=%.3f" % (k, d))
-        if k.startswith(checked):
-            if d > worst:
-                worst, worst_k = d, k
-            assert d <= 0.1, (k, d)
-    print("config 3 bf16 vs fp32 gradients at B=512 (relative deviation per tensor): " + " ".join(info))
+        dr = float((g_round[k] - g32).norm()) / float(g32.norm())
+        info.append("%s=%.3f(%.3f)" % (k, d, dr))
+        bound = 0.1 if k.startswith(checked) else max(0.1, 2.5 * dr)
+        assert d <= bound, (k, d, "bound", bound, "input rounding alone", dr)
+        if k.startswith(checked) and d > worst:
+            worst, worst_k = d, k
+        if d / bound > worst_y:
+            worst_y, worst_yk = d / bound, k
+    print("config 3 bf16 vs fp32 gradients at B=512, relative deviation per tensor (that of the fp32 step on the bf16-rounded image): "
+          + " ".join(info))
     _report_parity("test_config3_mhbcoatt_batch_512_bf16_mode[%s] (bf16 vs fp32 grads, bound 0.1)" % bf16_mode, worst / 0.1, worst_k)
+    _report_parity("test_config3_mhbcoatt_batch_512_bf16_mode[%s] (every tensor vs max(0.1, 2.5 x input-rounding deviation))" % bf16_mode,
+                   worst_y, worst_yk)
