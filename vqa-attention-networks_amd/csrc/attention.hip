@@ -475,6 +475,66 @@ static int att_logits_bwd_impl(const float* dlogits, const float* hid, const flo
 }  // extern "C"
 
 namespace {
+// The same for a NARROW feature tensor (C / 4 <= 256 threads wide: HieCoAtten's C = 512 at batch 256): the kernel above gives
+// such a sample one workgroup of which half the threads have a channel group and walk all S rows alone -- two active waves per
+// CU, 8 KB in flight: 3.2 TB/s.  Here 1024 threads = RS row slots x C / 4 channel groups; slot rs sums rows rs, rs + RS, ... (two
+// rows per trip in flight), the slots are folded through LDS in slot order: deterministic, a different association than the
+// single chain of the wide kernel (same value to fp32 rounding).
+template <int G, typename FT>
+__global__ void __launch_bounds__(1024) glimpse_pool_fwd_rows_kernel(const FT* __restrict__ feat, const float* __restrict__ logits,
+                                                                     int N, int S, int C, int unit, float* __restrict__ wts,
+                                                                     float* __restrict__ pooled) {
+  extern __shared__ float smem_g[];
+  float* w = smem_g;                                   // [G][S]
+  float* red = smem_g + G * S;                         // [RS][G][C]
+  const int n = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (wave < G) {
+    const int g = wave;
+    const float* lg = logits + (long long)n * S * G + g;
+    if (unit) {
+      for (int s = lane; s < S; s += 64) w[g * S + s] = 1.0f;
+    } else {
+      float mx = -INFINITY;
+      for (int s = lane; s < S; s += 64) mx = fmaxf(mx, lg[G * s]);
+      mx = wave_max(mx);
+      float sum = 0.f;
+      for (int s = lane; s < S; s += 64) { const float e = expf(lg[G * s] - mx); w[g * S + s] = e; sum += e; }
+      sum = wave_sum(sum);
+      const float rs = 1.0f / sum;
+      for (int s = lane; s < S; s += 64) w[g * S + s] *= rs;
+    }
+  }
+  __syncthreads();
+  if (wts)
+    for (int i = tid; i < G * S; i += blockDim.x) wts[(long long)n * G * S + i] = w[i];
+  const int CT = C >> 2, RS = blockDim.x / CT;
+  const int c4 = tid % CT, rs = tid / CT;
+  const FT* f = feat + (long long)n * S * C + 4 * c4;
+  f32x4 a[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) a[g] = f32x4{0, 0, 0, 0};
+  int s = rs;
+  for (; s + RS < S; s += 2 * RS) {
+    const f32x4 x0 = load4<FT>(f + (long long)s * C), x1 = load4<FT>(f + (long long)(s + RS) * C);
+#pragma unroll
+    for (int g = 0; g < G; ++g) { a[g] += x0 * w[g * S + s]; a[g] += x1 * w[g * S + s + RS]; }
+  }
+  if (s < S) {
+    const f32x4 x0 = load4<FT>(f + (long long)s * C);
+#pragma unroll
+    for (int g = 0; g < G; ++g) a[g] += x0 * w[g * S + s];
+  }
+#pragma unroll
+  for (int g = 0; g < G; ++g) *reinterpret_cast<f32x4*>(red + ((rs * G + g) * C) + 4 * c4) = a[g];
+  __syncthreads();
+  for (int g = rs; g < G; g += RS) {                  // row slot g folds glimpse g (RS >= G)
+    f32x4 sum = *reinterpret_cast<const f32x4*>(red + (g * C) + 4 * c4);
+    for (int q = 1; q < RS; ++q) sum += *reinterpret_cast<const f32x4*>(red + ((q * G + g) * C) + 4 * c4);
+    *reinterpret_cast<f32x4*>(pooled + (long long)n * G * C + g * C + 4 * c4) = sum;
+  }
+}
+
 template <typename FT>
 int glimpse_fwd_launch(const FT* feat, const float* logits, int N, int S, int C, int G, int unit_softmax,
                        float* wts, float* pooled, void* stream) {
@@ -482,6 +542,24 @@ int glimpse_fwd_launch(const FT* feat, const float* logits, int N, int S, int C,
   if (S > MAXS || (G != 1 && G != 2) || N > 65535) return VQF_E_UNSUPPORTED;
   dim3 grid((C + 1023) / 1024, N);
   hipStream_t s = (hipStream_t)stream;
+  {
+    // narrow tensors with enough rows: row slots instead of idle threads (glimpse_pool_fwd_rows_kernel)
+    const int CT = C / 4;
+    const bool pow2 = CT > 0 && (CT & (CT - 1)) == 0;
+    if ((C % 4) == 0 && pow2 && CT <= 256 && CT >= 16 && S >= 4 * (1024 / CT) && aligned16(feat) && aligned16(pooled)) {
+      const int RS = 1024 / CT;
+      const size_t lds = sizeof(float) * ((size_t)G * S + (size_t)RS * G * C);
+      if (RS >= G && lds <= 64 * 1024) {
+        if (G == 2)
+          VQF_LAUNCH(KID_GLIMPSE_FWD, (glimpse_pool_fwd_rows_kernel<2, FT>), dim3(N), dim3(1024), lds, s, feat, logits, N, S, C,
+                     unit_softmax, wts, pooled);
+        else
+          VQF_LAUNCH(KID_GLIMPSE_FWD, (glimpse_pool_fwd_rows_kernel<1, FT>), dim3(N), dim3(1024), lds, s, feat, logits, N, S, C,
+                     unit_softmax, wts, pooled);
+        return vqf_last_error();
+      }
+    }
+  }
   if (G == 2)
     VQF_LAUNCH(KID_GLIMPSE_FWD, (glimpse_pool_fwd_kernel<2, FT>), grid, dim3(256), 0, s, feat, logits, N, S,
                C, unit_softmax, wts, pooled);
